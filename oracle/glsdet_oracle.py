@@ -1,0 +1,416 @@
+"""CPU oracle for the GLSDet detection forward pass  --  TEST INFRASTRUCTURE ONLY.
+
+This file is the checker, never the product: only ``tests/``, ``__graft_entry__.smoke()``
+and the ``cpu_baseline`` leg of ``bench.py`` may import it.  The product path
+(``glsdet_amd``) never touches it and fails loudly when its HIP library is missing.
+
+It is a plain fp32 restatement (torch CPU, functional, NCHW) of the reference's
+algorithm, driven directly by a state_dict that uses the *reference's* key names, so a
+reference checkpoint and a reference-generated golden vector can both be fed to it.
+Every function cites the reference file:line it follows (paths relative to
+``/root/reference``; ``drone/`` = ``yolox-drone/``).
+
+Pinning: ``tests/test_oracle_golden.py`` checks this file against golden vectors that
+``tests/golden/make_golden.py`` produced by importing the reference itself
+(``yolox-drone`` tree, CPU) in the build container.  NMS is the one exception: the
+reference calls ``torchvision.ops.boxes.batched_nms`` which is not importable here, so
+``batched_nms`` below is restated from torchvision's documented semantics and is
+"parity unpinned" (see DESIGN.md).
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+Tensor = torch.Tensor
+SD = Dict[str, Tensor]
+
+# drone/models/base/yolox.py:240-241  (depth / width tables of YoloBody)
+DEPTH = {"nano": 0.33, "tiny": 0.33, "s": 0.33, "m": 0.67, "l": 1.00, "x": 1.33}
+WIDTH = {"nano": 0.25, "tiny": 0.375, "s": 0.50, "m": 0.75, "l": 1.00, "x": 1.25}
+BN_EPS = 1e-3  # drone/models/base/baseConv.py:12
+
+
+# --------------------------------------------------------------------------- primitives
+def _act(x: Tensor, kind: str) -> Tensor:
+    # drone/models/base/activation.py:4-17
+    if kind == "silu":
+        return x * torch.sigmoid(x)
+    if kind == "relu":
+        return torch.relu(x)
+    if kind == "lrelu":
+        return F.leaky_relu(x, 0.1)
+    if kind == "none":
+        return x
+    raise AttributeError("Unsupported act type: {}".format(kind))
+
+
+def base_conv(sd: SD, p: str, x: Tensor, stride: int = 1, act: str = "silu") -> Tensor:
+    """act(bn(conv(x))), conv without bias, pad=(k-1)//2, eval-mode BN.
+    drone/models/base/baseConv.py:6-16.  groups is inferred from the weight shape."""
+    w = sd[p + ".conv.weight"]
+    k = w.shape[-1]
+    groups = x.shape[1] // w.shape[1]
+    y = F.conv2d(x, w, None, stride, (k - 1) // 2, 1, groups)
+    y = F.batch_norm(y, sd[p + ".bn.running_mean"], sd[p + ".bn.running_var"],
+                     sd[p + ".bn.weight"], sd[p + ".bn.bias"], False, 0.0, BN_EPS)
+    return _act(y, act)
+
+
+def dw_conv(sd: SD, p: str, x: Tensor, stride: int = 1, act: str = "silu") -> Tensor:
+    # drone/models/base/baseConv.py:22-30  depthwise kxk then pointwise 1x1
+    return base_conv(sd, p + ".pconv", base_conv(sd, p + ".dconv", x, stride, act), 1, act)
+
+
+def any_conv(sd: SD, p: str, x: Tensor, stride: int = 1, act: str = "silu") -> Tensor:
+    """BaseConv or DWConv depending on what the checkpoint holds at prefix p."""
+    if p + ".dconv.conv.weight" in sd:
+        return dw_conv(sd, p, x, stride, act)
+    return base_conv(sd, p, x, stride, act)
+
+
+def plain_conv(sd: SD, p: str, x: Tensor, stride: int = 1, pad: int = 0) -> Tensor:
+    # nn.Conv2d with bias (predictors, non-local projections, Identity_Conv)
+    return F.conv2d(x, sd[p + ".weight"], sd.get(p + ".bias"), stride, pad)
+
+
+# --------------------------------------------------------------------------- backbone
+def focus(sd: SD, p: str, x: Tensor) -> Tensor:
+    # drone/models/base/darknet.py:15-21  order: TL, BL, TR, BR
+    tl, bl = x[..., 0::2, 0::2], x[..., 1::2, 0::2]
+    tr, br = x[..., 0::2, 1::2], x[..., 1::2, 1::2]
+    return base_conv(sd, p + ".conv", torch.cat((tl, bl, tr, br), 1))
+
+
+def spp_bottleneck(sd: SD, p: str, x: Tensor, ks: Sequence[int] = (5, 9, 13)) -> Tensor:
+    # drone/models/base/darknet.py:24-37
+    x = base_conv(sd, p + ".conv1", x)
+    x = torch.cat([x] + [F.max_pool2d(x, k, 1, k // 2) for k in ks], 1)
+    return base_conv(sd, p + ".conv2", x)
+
+
+def bottleneck(sd: SD, p: str, x: Tensor, shortcut: bool) -> Tensor:
+    # drone/models/base/darknet.py:43-63
+    y = any_conv(sd, p + ".conv2", base_conv(sd, p + ".conv1", x))
+    return y + x if (shortcut and y.shape[1] == x.shape[1]) else y
+
+
+def csp_layer(sd: SD, p: str, x: Tensor, shortcut: bool = True) -> Tensor:
+    # drone/models/base/darknet.py:66-112 ; number of bottlenecks read off the checkpoint
+    a = base_conv(sd, p + ".conv1", x)
+    b = base_conv(sd, p + ".conv2", x)
+    i = 0
+    while "{}.m.{}.conv1.conv.weight".format(p, i) in sd:
+        a = bottleneck(sd, "{}.m.{}".format(p, i), a, shortcut)
+        i += 1
+    return base_conv(sd, p + ".conv3", torch.cat((a, b), 1))
+
+
+def csp_darknet(sd: SD, p: str, x: Tensor) -> Dict[str, Tensor]:
+    # drone/models/base/darknet.py:174-195
+    out = {}
+    x = focus(sd, p + ".stem", x)
+    out["stem"] = x
+    for name in ("dark2", "dark3", "dark4"):
+        x = any_conv(sd, "{}.{}.0".format(p, name), x, 2)
+        x = csp_layer(sd, "{}.{}.1".format(p, name), x, True)
+        out[name] = x
+    x = any_conv(sd, p + ".dark5.0", x, 2)
+    x = spp_bottleneck(sd, p + ".dark5.1", x)
+    x = csp_layer(sd, p + ".dark5.2", x, False)
+    out["dark5"] = x
+    return out
+
+
+def _up2(x: Tensor) -> Tensor:
+    return F.interpolate(x, scale_factor=2, mode="nearest")  # nn.Upsample(2,'nearest')
+
+
+# --------------------------------------------------------------------------- necks
+def pafpn(sd: SD, p: str, x: Tensor, with_dark2: bool = False):
+    """drone/models/base/yolox.py:170-234 (lsk/yolox6.py:229-293 adds feat0=dark2)."""
+    f = csp_darknet(sd, p + ".backbone", x)
+    feat1, feat2, feat3 = f["dark3"], f["dark4"], f["dark5"]
+    P5 = base_conv(sd, p + ".lateral_conv0", feat3)
+    t = csp_layer(sd, p + ".C3_p4", torch.cat((_up2(P5), feat2), 1), False)
+    P4 = base_conv(sd, p + ".reduce_conv1", t)
+    P3_out = csp_layer(sd, p + ".C3_p3", torch.cat((_up2(P4), feat1), 1), False)
+    d = any_conv(sd, p + ".bu_conv2", P3_out, 2)
+    P4_out = csp_layer(sd, p + ".C3_n3", torch.cat((d, P4), 1), False)
+    d = any_conv(sd, p + ".bu_conv1", P4_out, 2)
+    P5_out = csp_layer(sd, p + ".C3_n4", torch.cat((d, P5), 1), False)
+    if with_dark2:
+        return f["dark2"], P3_out, P4_out, P5_out
+    return P3_out, P4_out, P5_out
+
+
+def non_local_block(sd: SD, p: str, x: Tensor) -> Tensor:
+    """x + conv_out( (theta^T phi / N) g^T ) -- dot-product form, divide by N, no softmax.
+    drone/models/block/non_local/Identity_Conv.py:152-173."""
+    n, _, h, w = x.shape
+    g = plain_conv(sd, p + ".g", x).flatten(2).transpose(1, 2)          # [n, N, C]
+    th = plain_conv(sd, p + ".theta", x).flatten(2).transpose(1, 2)     # [n, N, C]
+    ph = plain_conv(sd, p + ".phi", x).flatten(2)                       # [n, C, N]
+    pw = torch.matmul(th, ph)
+    pw = pw / pw.shape[-1]
+    y = torch.matmul(pw, g).transpose(1, 2).reshape(n, -1, h, w)
+    return x + plain_conv(sd, p + ".conv_out", y)
+
+
+def _quadrants(x: Tensor):
+    # floor split exactly in half whatever patch_scale says: Identity_Conv.py:293-296
+    hh, hw = int(x.shape[2] / 2), int(x.shape[3] / 2)
+    return x[:, :, :hh, :hw], x[:, :, hh:, :hw], x[:, :, :hh, hw:], x[:, :, hh:, hw:]
+
+
+def patch_conv(sd: SD, p: str, x: Tensor, stride: int, nonlocal_: bool) -> Tensor:
+    """Patch_Conv (Identity_Conv.py:267-320) and Patch_Conv_NonLocal (:323-387):
+    per-quadrant 3x3 (stride s) [-> non-local], re-stitch halves l/r/t/b, 3x3 on each,
+    stitch lr (along W) and tb (along H), channel-concat, 1x1 'linear' conv with bias."""
+    lt, lb, rt, rb = _quadrants(x)
+    q = {}
+    for name, t in (("lt", lt), ("lb", lb), ("rt", rt), ("rb", rb)):
+        t = base_conv(sd, "{}.feat_patchconv_{}".format(p, name), t, stride)
+        if nonlocal_:
+            t = non_local_block(sd, "{}.feat_patchconv_{}_nonlocal".format(p, name), t)
+        q[name] = t
+    l = base_conv(sd, p + ".feat_patchconv_l", torch.cat((q["lt"], q["lb"]), 2))
+    r = base_conv(sd, p + ".feat_patchconv_r", torch.cat((q["rt"], q["rb"]), 2))
+    t = base_conv(sd, p + ".feat_patchconv_t", torch.cat((q["lt"], q["rt"]), 3))
+    b = base_conv(sd, p + ".feat_patchconv_b", torch.cat((q["lb"], q["rb"]), 3))
+    both = torch.cat((torch.cat((l, r), 3), torch.cat((t, b), 2)), 1)
+    if p + ".channel_conv.weight" in sd:           # channel_cat == 'linear'
+        return plain_conv(sd, p + ".channel_conv", both)
+    return base_conv(sd, p + ".channel_conv", both)
+
+
+def identity_conv(sd: SD, p: str, x: Tensor) -> Tensor:
+    # Identity_Conv_{three,five,seven}: dense kxk conv with bias, pad k//2
+    # (Identity_Conv.py:27-84); identity only at init, trained weights are arbitrary.
+    k = sd[p + ".conv.weight"].shape[-1]
+    return plain_conv(sd, p + ".conv", x, 1, k // 2)
+
+
+def gl_pafpn(sd: SD, p: str, x: Tensor):
+    """GL-fusion neck: drone/models/block/non_local/yolo_patch_nonlocal_plus.py:180-247."""
+    f = csp_darknet(sd, p + ".backbone", x)
+    feat1, feat2, feat3 = f["dark3"], f["dark4"], f["dark5"]
+    feat1_patch = patch_conv(sd, p + ".Patch_conv_feat1", feat1, 2, True)    # global branch
+    feat2_patch = patch_conv(sd, p + ".Patch_conv_feat2", feat2, 1, False)   # local branch
+    P5 = base_conv(sd, p + ".lateral_conv0", feat3)
+    t = csp_layer(sd, p + ".C3_p4", torch.cat((_up2(P5), feat2, feat1_patch), 1), False)
+    P4 = base_conv(sd, p + ".reduce_conv1", t)
+    P3_out = csp_layer(sd, p + ".C3_p3", torch.cat((_up2(P4), feat1), 1), False)
+    P3_out = identity_conv(sd, p + ".P3_Identity", P3_out)
+    d = any_conv(sd, p + ".bu_conv2", P3_out, 2)
+    P4_out = csp_layer(sd, p + ".C3_n3", torch.cat((d, P4, feat2_patch), 1), False)
+    P4_out = identity_conv(sd, p + ".P4_Identity", P4_out)
+    d = any_conv(sd, p + ".bu_conv1", P4_out, 2)
+    P5_out = csp_layer(sd, p + ".C3_n4", torch.cat((d, P5), 1), False)
+    P5_out = identity_conv(sd, p + ".P5_Identity", P5_out)
+    return P3_out, P4_out, P5_out
+
+
+# --------------------------------------------------------------------------- heads
+def _tower(sd: SD, p: str, x: Tensor) -> Tensor:
+    i = 0
+    while ("{}.{}.conv.weight".format(p, i) in sd) or ("{}.{}.dconv.conv.weight".format(p, i) in sd):
+        x = any_conv(sd, "{}.{}".format(p, i), x)
+        i += 1
+    return x
+
+
+def yolox_head(sd: SD, p: str, feats: Sequence[Tensor]) -> List[Tensor]:
+    # drone/models/base/yolox.py:46-92 ; output channel order reg(4), obj(1), cls(nc)
+    outs = []
+    for k, x in enumerate(feats):
+        x = base_conv(sd, "{}.stems.{}".format(p, k), x)
+        cls_feat = _tower(sd, "{}.cls_convs.{}".format(p, k), x)
+        reg_feat = _tower(sd, "{}.reg_convs.{}".format(p, k), x)
+        outs.append(torch.cat((plain_conv(sd, "{}.reg_preds.{}".format(p, k), reg_feat),
+                               plain_conv(sd, "{}.obj_preds.{}".format(p, k), reg_feat),
+                               plain_conv(sd, "{}.cls_preds.{}".format(p, k), cls_feat)), 1))
+    return outs
+
+
+def cross_scale_head(sd: SD, p: str, feats: Sequence[Tensor]) -> List[Tensor]:
+    """Cross-scale decoupled head, drone/models/lsk/yolox6.py:69-153
+    (text-identical to new/yolox6.py).  feats = (dark2, P3, P4, P5)."""
+    feat0 = csp_layer(sd, p + ".csp_feat0", feats[0], False)
+    lv = [base_conv(sd, "{}.stems.{}".format(p, k), x) for k, x in enumerate(feats[1:])]
+
+    def down(k, t):      # up_convs[k]: 3x3 s1 then 3x3 s2
+        t = any_conv(sd, "{}.up_convs.{}.0".format(p, k), t, 1)
+        return any_conv(sd, "{}.up_convs.{}.1".format(p, k), t, 2)
+
+    outs = []
+    for k, x in enumerate(lv):
+        finer = feat0 if k == 0 else lv[k - 1]
+        parts = [x, down(k, finer)]
+        if k < len(lv) - 1:
+            parts.append(_up2(lv[k + 1]))
+        cls_feat = _tower(sd, "{}.cls_convs.{}".format(p, k), torch.cat(parts, 1))
+        reg_feat = _tower(sd, "{}.reg_convs.{}".format(p, k), x)
+        outs.append(torch.cat((plain_conv(sd, "{}.reg_preds.{}".format(p, k), reg_feat),
+                               plain_conv(sd, "{}.obj_preds.{}".format(p, k), reg_feat),
+                               plain_conv(sd, "{}.cls_preds.{}".format(p, k), cls_feat)), 1))
+    return outs
+
+
+# --------------------------------------------------------------------------- whole models
+def yolox_base_forward(sd: SD, x: Tensor) -> List[Tensor]:
+    """models.base.yolox.YoloBody.forward  (drone/models/base/yolox.py:248-251)."""
+    return yolox_head(sd, "head", pafpn(sd, "backbone", x))
+
+
+def yolox_gl_forward(sd: SD, x: Tensor) -> List[Tensor]:
+    """models.block.non_local.yolo_patch_nonlocal_plus.YoloBody.forward (:260-263)."""
+    return yolox_head(sd, "head", gl_pafpn(sd, "backbone", x))
+
+
+def yolox_cross_forward(sd: SD, x: Tensor) -> List[Tensor]:
+    """models.lsk.yolox6.YoloBody.forward (drone/models/lsk/yolox6.py:309-312).
+    NOTE: that file's backbone is darknet_lsk.CSPDarknet; this restatement covers the
+    plain-CSPDarknet twin (new/yolox6.py, whose `models.decouple` import is missing)."""
+    return cross_scale_head(sd, "head", pafpn(sd, "backbone", x, with_dark2=True))
+
+
+FORWARDS = {"base": yolox_base_forward, "gl": yolox_gl_forward, "cross": yolox_cross_forward}
+
+
+# --------------------------------------------------------------------------- post-process
+def decode_outputs(outputs: Sequence[Tensor], input_shape: Sequence[int]) -> Tensor:
+    """drone/models/core/utils_bbox.py:254-306.  [B,5+nc,H,W]x3 -> [B,A,5+nc] with
+    sigmoid on [4:], xy=(xy+grid)*stride, wh=exp(wh)*stride, normalised by (W,H).
+    stride = input_shape[0] / h for both axes (Appendix D.6).  Does not mutate inputs."""
+    flat = torch.cat([o.flatten(2) for o in outputs], 2).permute(0, 2, 1).clone()
+    flat[:, :, 4:] = torch.sigmoid(flat[:, :, 4:])
+    grids, strides = [], []
+    for o in outputs:
+        h, w = o.shape[-2:]
+        gy, gx = torch.meshgrid(torch.arange(h), torch.arange(w), indexing="ij")
+        grids.append(torch.stack((gx, gy), 2).reshape(1, -1, 2).to(flat.dtype))
+        strides.append(torch.full((1, h * w, 1), input_shape[0] / h, dtype=flat.dtype))
+    grids, strides = torch.cat(grids, 1), torch.cat(strides, 1)
+    flat[..., :2] = (flat[..., :2] + grids) * strides
+    flat[..., 2:4] = torch.exp(flat[..., 2:4]) * strides
+    flat[..., [0, 2]] = flat[..., [0, 2]] / input_shape[1]
+    flat[..., [1, 3]] = flat[..., [1, 3]] / input_shape[0]
+    return flat
+
+
+def nms_single(boxes: np.ndarray, scores: np.ndarray, thr: float) -> np.ndarray:
+    """Greedy NMS, torchvision.ops.nms semantics (source not in /root/reference; restated
+    from its documented behaviour): visit by descending score,
+    suppress when IoU > thr, areas without '+1', result ordered by descending score."""
+    order = np.argsort(-scores, kind="stable")
+    x1, y1, x2, y2 = (boxes[:, i].astype(np.float32) for i in range(4))
+    areas = (x2 - x1) * (y2 - y1)
+    dead = np.zeros(len(order), bool)
+    keep = []
+    for a in range(len(order)):
+        i = order[a]
+        if dead[i]:
+            continue
+        keep.append(i)
+        rest = order[a + 1:]
+        w = np.maximum(np.float32(0), np.minimum(x2[i], x2[rest]) - np.maximum(x1[i], x1[rest]))
+        h = np.maximum(np.float32(0), np.minimum(y2[i], y2[rest]) - np.maximum(y1[i], y1[rest]))
+        inter = w * h
+        with np.errstate(divide="ignore", invalid="ignore"):
+            iou = inter / (areas[i] + areas[rest] - inter)
+        dead[rest[iou > np.float32(thr)]] = True
+    return np.asarray(keep, np.int64)
+
+
+def batched_nms(boxes: np.ndarray, scores: np.ndarray, labels: np.ndarray, thr: float) -> np.ndarray:
+    """torchvision.ops.boxes.batched_nms semantics (per-class NMS; result indices sorted
+    by descending score) in its 'vanilla' per-class-loop form, which torchvision
+    documents as equivalent to the coordinate-offset form.  PARITY UNPINNED."""
+    keep = []
+    for c in np.unique(labels):
+        idx = np.nonzero(labels == c)[0]
+        keep.append(idx[nms_single(boxes[idx], scores[idx], thr)])
+    if not keep:
+        return np.zeros((0,), np.int64)
+    keep = np.concatenate(keep)
+    return keep[np.argsort(-scores[keep], kind="stable")]
+
+
+def yolo_correct_boxes(box_xy, box_wh, input_shape, image_shape, letterbox_image):
+    # drone/models/core/utils_bbox.py:8-33 ; returns [y1,x1,y2,x2] in original-image pixels
+    box_yx, box_hw = box_xy[..., ::-1], box_wh[..., ::-1]
+    input_shape = np.array(input_shape, np.float64)
+    image_shape = np.array(image_shape, np.float64)
+    if letterbox_image:
+        new_shape = np.round(image_shape * np.min(input_shape / image_shape))
+        offset = (input_shape - new_shape) / 2.0 / input_shape
+        scale = input_shape / new_shape
+        box_yx = (box_yx - offset) * scale
+        box_hw = box_hw * scale
+    mins, maxes = box_yx - box_hw / 2.0, box_yx + box_hw / 2.0
+    out = np.concatenate([mins[..., 0:1], mins[..., 1:2], maxes[..., 0:1], maxes[..., 1:2]], -1)
+    return out * np.concatenate([image_shape, image_shape], -1)
+
+
+def non_max_suppression(prediction: Tensor, num_classes: int, input_shape, image_shape,
+                        letterbox_image: bool, conf_thres: float = 0.5, nms_thres: float = 0.4):
+    """drone/models/core/utils_bbox.py:375-484.  prediction [B,A,5+nc] (decode_outputs
+    result).  Per image: None, or ndarray(n,7) = [y1,x1,y2,x2,obj,cls_conf,cls_id]."""
+    pred = prediction.clone().float()
+    cxcywh = pred[:, :, :4].clone()
+    pred[:, :, 0] = cxcywh[:, :, 0] - cxcywh[:, :, 2] / 2
+    pred[:, :, 1] = cxcywh[:, :, 1] - cxcywh[:, :, 3] / 2
+    pred[:, :, 2] = cxcywh[:, :, 0] + cxcywh[:, :, 2] / 2
+    pred[:, :, 3] = cxcywh[:, :, 1] + cxcywh[:, :, 3] / 2
+    out: List[Optional[np.ndarray]] = [None] * len(pred)
+    for i, ip in enumerate(pred):
+        if not ip.size(0):
+            continue
+        class_conf, class_pred = torch.max(ip[:, 5:5 + num_classes], 1, keepdim=True)
+        mask = ip[:, 4] * class_conf[:, 0] >= conf_thres
+        det = torch.cat((ip[:, :5], class_conf, class_pred.float()), 1)[mask].numpy()
+        keep = batched_nms(det[:, :4], det[:, 4] * det[:, 5], det[:, 6], nms_thres)
+        det = det[keep]
+        xy, wh = (det[:, 0:2] + det[:, 2:4]) / 2, det[:, 2:4] - det[:, 0:2]
+        det[:, :4] = yolo_correct_boxes(xy, wh, input_shape, image_shape, letterbox_image)
+        out[i] = det
+    return out
+
+
+# --------------------------------------------------------------------------- synthetic weights
+def synth_tensor(key: str, shape: Tuple[int, ...], seed: int) -> np.ndarray:
+    """Deterministic parameter filler shared by the golden generator, the oracle tests and
+    the product tests/bench: every tensor depends only on (key, shape, seed), so a
+    state_dict never has to be stored.  BN stats/affine and every bias are perturbed
+    (default init yields near-constant logits)."""
+    import zlib
+    rng = np.random.default_rng([seed, zlib.crc32(key.encode())])
+    leaf = key.rsplit(".", 1)[-1]
+    if leaf == "num_batches_tracked":
+        return np.zeros(shape, np.int64)
+    if leaf == "running_var":
+        return rng.uniform(0.5, 1.5, shape).astype(np.float32)
+    if leaf == "running_mean":
+        return (0.1 * rng.standard_normal(shape)).astype(np.float32)
+    if leaf == "weight" and len(shape) == 1:            # BN gamma
+        return rng.uniform(0.8, 1.6, shape).astype(np.float32)
+    if leaf == "bias":
+        return (0.2 * rng.standard_normal(shape)).astype(np.float32)
+    if leaf == "weight":
+        fan_in = int(np.prod(shape[1:]))
+        return (rng.standard_normal(shape) * math.sqrt(1.0 / fan_in)).astype(np.float32)
+    raise KeyError(key)
+
+
+def synth_state_dict(shapes: Dict[str, Tuple[int, ...]], seed: int) -> SD:
+    return {k: torch.from_numpy(synth_tensor(k, tuple(s), seed)) for k, s in shapes.items()}
+
+
+def synth_input(shape: Tuple[int, ...], seed: int) -> Tensor:
+    rng = np.random.default_rng([seed, 0x1234])
+    return torch.from_numpy(rng.standard_normal(shape).astype(np.float32))
