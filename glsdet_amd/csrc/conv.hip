@@ -1,0 +1,418 @@
+// conv2d + folded BN + activation (+ residual) as an implicit GEMM on CDNA4 MFMA.
+//
+// GEMM view (operands swapped so that the contiguous NHWC channel run of the OUTPUT is
+// register-local in the accumulator):
+//     D[co][px] = sum_k  Wt[co][k] * Im2col[px][k],   k = (r*S + s)*Cin + ci
+//   A operand = weight tile  [CO_T rows x KB bytes]  (rows contiguous in memory)
+//   B operand = im2col tile  [PX_T rows x KB bytes]  (each 16-byte chunk = 8 f16 / 4 f32
+//               consecutive input channels of ONE tap -> one coalesced 16-B global load,
+//               zero-filled for padding / tails)
+// Both tiles are staged global -> registers -> LDS (rows padded by 16 B: conflict-free
+// ds_read_b128 fragments), double buffered, one barrier per K step, next tile's global
+// loads in flight under the current tile's MFMAs.  Accumulation is fp32.
+//   f16: v_mfma_f32_32x32x16_f16  (16 B of an A row x 16 B of a B row per lane)
+//   f32: 4 x v_mfma_f32_32x32x2_f32 on the same 16-B fragments (k order permuted
+//        identically for A and B, so the dot product is unchanged) -- exact f32.
+// Epilogue: scale/bias/activation in fp32 on the accumulator, tile transposed through LDS,
+// written (and the residual read) as full 16-byte channel chunks per pixel.
+#include "common.h"
+
+namespace glsdet {
+
+struct ConvArgs {
+  const unsigned char* x;   // bytes
+  const unsigned char* w;
+  const float* scale;
+  const float* bias;
+  unsigned char* y;
+  const unsigned char* res;
+  long x_sn, x_sh, x_sw;    // element strides
+  long y_sn, y_sh, y_sw;
+  long r_sn, r_sh, r_sw;
+  int N, H, W, Cin;
+  int Ho, Wo, Cout, cout_pad;
+  int R, S, stride, pad, act;
+  int kreal, kpad;          // elements
+  int M;                    // N*Ho*Wo
+  int n_co_tiles, n_px_tiles;
+};
+
+template <typename T>
+struct MMA;
+template <>
+struct MMA<f16> {
+  static __device__ __forceinline__ void run(const u32x4& a, const u32x4& b, f32x16& c) {
+    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a),
+                                               __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  }
+};
+template <>
+struct MMA<float> {
+  static __device__ __forceinline__ void run(const u32x4& a, const u32x4& b, f32x16& c) {
+    const f32x4 af = __builtin_bit_cast(f32x4, a), bf = __builtin_bit_cast(f32x4, b);
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(af[0], bf[0], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(af[1], bf[1], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(af[2], bf[2], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(af[3], bf[3], c, 0, 0, 0);
+  }
+};
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+  if (act == GLSDET_ACT_SILU) return v / (1.0f + __expf(-v));
+  if (act == GLSDET_ACT_RELU) return fmaxf(v, 0.0f);
+  if (act == GLSDET_ACT_LRELU) return v > 0.0f ? v : 0.1f * v;
+  return v;
+}
+
+// pack 4 fp32 -> 4 TO, stored at p (8 B for f16, 16 B for f32)
+__device__ __forceinline__ void store4(unsigned char* p, const float (&v)[4], f16*) {
+  f16x4 h = {(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
+  *reinterpret_cast<f16x4*>(p) = h;
+}
+__device__ __forceinline__ void store4(unsigned char* p, const float (&v)[4], float*) {
+  f32x4 h = {v[0], v[1], v[2], v[3]};
+  *reinterpret_cast<f32x4*>(p) = h;
+}
+// 16-byte chunk (+)= residual chunk, in fp32
+__device__ __forceinline__ u32x4 add_chunk(u32x4 a, u32x4 b, f16*) {
+  f16x8 x = __builtin_bit_cast(f16x8, a), y = __builtin_bit_cast(f16x8, b);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) x[i] = (f16)((float)x[i] + (float)y[i]);
+  return __builtin_bit_cast(u32x4, x);
+}
+__device__ __forceinline__ u32x4 add_chunk(u32x4 a, u32x4 b, float*) {
+  f32x4 x = __builtin_bit_cast(f32x4, a), y = __builtin_bit_cast(f32x4, b);
+  x += y;
+  return __builtin_bit_cast(u32x4, x);
+}
+
+template <int CO_T, int PX_T, int KB, typename TO>
+constexpr int conv_lds_bytes() {
+  constexpr int stage = 2 * (CO_T + PX_T) * (KB + 16);
+  constexpr int epi = PX_T * (CO_T * (int)sizeof(TO) + 16);
+  return stage > epi ? stage : epi;
+}
+
+template <typename T, typename TO, int CO_T, int PX_T, int KB, int WCO>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
+  constexpr int RS = KB + 16;                    // LDS row stride, bytes
+  constexpr int VEC = 16 / (int)sizeof(T);       // elements per 16-B chunk
+  constexpr int KE = KB / (int)sizeof(T);        // k elements per step
+  constexpr int CPR = KB / 16;                   // chunks per tile row
+  constexpr int NA = (CO_T * CPR + 255) / 256;   // chunks per thread, weight tile
+  constexpr int NB = (PX_T * CPR + 255) / 256;   // chunks per thread, im2col tile
+  constexpr int WPX = 4 / WCO;
+  constexpr int WT_CO = CO_T / WCO, WT_PX = PX_T / WPX;
+  constexpr int TM = WT_CO / 32, TN = WT_PX / 32;
+  constexpr int STAGE = (CO_T + PX_T) * RS;
+  static_assert(TM >= 1 && TN >= 1 && 256 % CPR == 0, "tile shape");
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+
+  // XCD-aware tile order: blocks that land on one XCD (bid % 8 equal) walk a contiguous
+  // run of tiles, cout tile fastest, so the im2col rows they share stay in that XCD's L2.
+  int tile;
+  {
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, local = bid >> 3;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+  }
+  const int co0 = (tile % a.n_co_tiles) * CO_T;
+  const int px0 = (tile / a.n_co_tiles) * PX_T;
+
+  const int kc = tid % CPR;
+  const int row0 = tid / CPR;                    // row of chunk i is row0 + i*(256/CPR)
+  constexpr int ROWS_PER_PASS = 256 / CPR;
+
+  // ---- weight tile: per-thread row pointers
+  const unsigned char* wp[NA];
+  bool wok[NA];
+#pragma unroll
+  for (int i = 0; i < NA; ++i) {
+    const int row = row0 + i * ROWS_PER_PASS;
+    wok[i] = row < CO_T && (co0 + row) < a.cout_pad;
+    wp[i] = a.w + ((long)(co0 + row) * a.kpad + kc * VEC) * (long)sizeof(T);
+  }
+  // ---- im2col tile: per-thread pixel coordinates
+  long boff[NB];
+  int hi0[NB], wi0[NB];
+  bool pok[NB];
+  const int HoWo = a.Ho * a.Wo;
+#pragma unroll
+  for (int i = 0; i < NB; ++i) {
+    const int row = row0 + i * ROWS_PER_PASS;
+    const int p = px0 + row;
+    pok[i] = row < PX_T && p < a.M;
+    const int pp = pok[i] ? p : 0;
+    const int n = pp / HoWo, rem = pp - n * HoWo;
+    const int ho = rem / a.Wo, wo = rem - ho * a.Wo;
+    hi0[i] = ho * a.stride - a.pad;
+    wi0[i] = wo * a.stride - a.pad;
+    boff[i] = (long)n * a.x_sn + (long)hi0[i] * a.x_sh + (long)wi0[i] * a.x_sw;
+  }
+  // ---- k position of this thread's chunk column: (r, s, c)
+  int kr, ks, kci;
+  {
+    const int k = kc * VEC;
+    const int tap = k / a.Cin;
+    kci = k - tap * a.Cin;
+    kr = tap / a.S;
+    ks = tap - kr * a.S;
+  }
+
+  u32x4 ra[NA], rb[NB];
+  const u32x4 zero4 = {0u, 0u, 0u, 0u};
+  const int nsteps = (a.kreal + KE - 1) / KE;
+
+  auto gload = [&](int step) __attribute__((always_inline)) {
+    const long kbyte = (long)step * KB;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) ra[i] = wok[i] ? *reinterpret_cast<const u32x4*>(wp[i] + kbyte) : zero4;
+    const bool kval = kr < a.R;
+    const long tapoff = (long)kr * a.x_sh + (long)ks * a.x_sw + kci;
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int hi = hi0[i] + kr, wi = wi0[i] + ks;
+      const bool ok = pok[i] && kval && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
+      rb[i] = ok ? *reinterpret_cast<const u32x4*>(a.x + (boff[i] + tapoff) * (long)sizeof(T)) : zero4;
+    }
+    kci += KE;
+    while (kci >= a.Cin) {
+      kci -= a.Cin;
+      if (++ks == a.S) {
+        ks = 0;
+        ++kr;
+      }
+    }
+  };
+  auto lstore = [&](int buf) __attribute__((always_inline)) {
+    unsigned char* sa = smem + buf * STAGE + kc * 16;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      const int row = row0 + i * ROWS_PER_PASS;
+      if (row < CO_T) *reinterpret_cast<u32x4*>(sa + row * RS) = ra[i];
+    }
+    unsigned char* sb = sa + CO_T * RS;
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int row = row0 + i * ROWS_PER_PASS;
+      if (row < PX_T) *reinterpret_cast<u32x4*>(sb + row * RS) = rb[i];
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+  const int wco = wave % WCO, wpx = wave / WCO;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int a_off = (wco * WT_CO + l31) * RS + lh * 16;
+  const int b_off = CO_T * RS + (wpx * WT_PX + l31) * RS + lh * 16;
+
+  gload(0);
+  lstore(0);
+  __syncthreads();
+
+  for (int t = 0; t < nsteps; ++t) {
+    const int cur = t & 1;
+    if (t + 1 < nsteps) gload(t + 1);
+    const unsigned char* sbuf = smem + cur * STAGE;
+#pragma unroll
+    for (int kk = 0; kk < KB / 32; ++kk) {
+      u32x4 af[TM], bf[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+        af[i] = *reinterpret_cast<const u32x4*>(sbuf + a_off + i * 32 * RS + kk * 32);
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        bf[j] = *reinterpret_cast<const u32x4*>(sbuf + b_off + j * 32 * RS + kk * 32);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) MMA<T>::run(af[i], bf[j], acc[i][j]);
+    }
+    if (t + 1 < nsteps) lstore(cur ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: fp32 scale/bias/act, transpose through LDS, 16-B channel chunks out
+  constexpr int ORS = CO_T * (int)sizeof(TO) + 16;
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int co_l = wco * WT_CO + i * 32 + 8 * g + 4 * lh;
+      f32x4 sc = {0.f, 0.f, 0.f, 0.f}, bi = {0.f, 0.f, 0.f, 0.f};
+      if (co0 + co_l < a.cout_pad) {
+        sc = *reinterpret_cast<const f32x4*>(a.scale + co0 + co_l);
+        bi = *reinterpret_cast<const f32x4*>(a.bias + co0 + co_l);
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int px_l = wpx * WT_PX + j * 32 + l31;
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = apply_act(acc[i][j][4 * g + e] * sc[e] + bi[e], a.act);
+        store4(smem + px_l * ORS + co_l * (int)sizeof(TO), v, (TO*)nullptr);
+      }
+    }
+  }
+  __syncthreads();
+  constexpr int VO = 16 / (int)sizeof(TO);
+  constexpr int OCPR = CO_T / VO;                // 16-B chunks per pixel row of the tile
+  for (int q = tid; q < PX_T * OCPR; q += 256) {
+    const int px_l = q / OCPR, cc = q - px_l * OCPR;
+    const int p = px0 + px_l, co = co0 + cc * VO;
+    if (p < a.M && co < a.Cout) {
+      const int n = p / HoWo, rem = p - n * HoWo;
+      const int ho = rem / a.Wo, wo = rem - ho * a.Wo;
+      u32x4 v = *reinterpret_cast<const u32x4*>(smem + px_l * ORS + cc * 16);
+      if (a.res) {
+        const long ro = (long)n * a.r_sn + (long)ho * a.r_sh + (long)wo * a.r_sw + co;
+        v = add_chunk(v, *reinterpret_cast<const u32x4*>(a.res + ro * (long)sizeof(TO)), (TO*)nullptr);
+      }
+      const long yo = (long)n * a.y_sn + (long)ho * a.y_sh + (long)wo * a.y_sw + co;
+      *reinterpret_cast<u32x4*>(a.y + yo * (long)sizeof(TO)) = v;
+    }
+  }
+}
+
+// ---- host side --------------------------------------------------------------------------
+template <typename T, typename TO, int CO_T, int PX_T, int KB, int WCO>
+static int launch_conv(const ConvArgs& a, hipStream_t st) {
+  constexpr int lds = conv_lds_bytes<CO_T, PX_T, KB, TO>();
+  static bool attr_set = false;
+  auto kern = conv_igemm_kernel<T, TO, CO_T, PX_T, KB, WCO>;
+  if (!attr_set && lds > 64 * 1024) {
+    GLS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    attr_set = true;
+  }
+  ConvArgs b = a;
+  b.n_co_tiles = (a.cout_pad + CO_T - 1) / CO_T;
+  // tiles that would only cover the zero padding of cout_pad are never created
+  if ((b.n_co_tiles - 1) * CO_T >= a.Cout) b.n_co_tiles = (a.Cout + CO_T - 1) / CO_T;
+  b.n_px_tiles = (a.M + PX_T - 1) / PX_T;
+  const long grid = (long)b.n_co_tiles * b.n_px_tiles;
+  if (grid <= 0 || grid > 0x7fffffffL) GLS_FAIL(GLSDET_E_ARG, "conv2d: grid %ld out of range", grid);
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, st, b);
+  GLS_HIP(hipGetLastError());
+  return 0;
+}
+
+template <typename T, typename TO>
+static int dispatch_tile(const ConvArgs& a, int co_t, int px_t, int kb, hipStream_t st) {
+#define GLS_CASE(CO, PX, WCO_)                                              \
+  if (co_t == CO && px_t == PX) {                                           \
+    return kb == 128 ? launch_conv<T, TO, CO, PX, 128, WCO_>(a, st)         \
+                     : launch_conv<T, TO, CO, PX, 64, WCO_>(a, st);         \
+  }
+  GLS_CASE(128, 128, 2)
+  GLS_CASE(64, 128, 2)
+  GLS_CASE(32, 128, 1)
+  GLS_CASE(64, 64, 2)
+#undef GLS_CASE
+  GLS_FAIL(GLSDET_E_ARG, "conv2d: no kernel for tile %dx%d", co_t, px_t);
+}
+
+static void pick_tile(const ConvArgs& a, int elem, int hint, int* co_t, int* px_t, int* kb) {
+  if (hint) {
+    *co_t = hint >> 16;
+    *px_t = hint & 0xffff;
+  } else {
+    *co_t = a.cout_pad <= 32 ? 32 : (a.cout_pad <= 64 || ((a.cout_pad % 128) == 64 && a.cout_pad < 256)) ? 64 : 128;
+    *px_t = 128;
+    // few pixels: smaller pixel tile keeps more CUs busy
+    const long tiles = (long)((a.cout_pad + *co_t - 1) / *co_t) * ((a.M + 127) / 128);
+    if (*co_t == 64 && tiles < 256) *px_t = 64;
+  }
+  *kb = ((long)a.kreal * elem) % 128 == 0 ? 128 : 64;
+}
+
+}  // namespace glsdet
+
+using namespace glsdet;
+
+extern "C" int32_t glsdet_conv_kpad(int32_t R, int32_t S, int32_t cin, int32_t dtype) {
+  const int es = dtype_size(dtype);
+  const long kb = (long)R * S * cin * es;
+  return (int32_t)(((kb + 127) / 128 * 128) / es);
+}
+extern "C" int32_t glsdet_conv_cout_pad(int32_t cout) { return (cout + 31) / 32 * 32; }
+extern "C" int64_t glsdet_conv_weight_elems(int32_t cout, int32_t R, int32_t S, int32_t cin, int32_t dtype) {
+  return (int64_t)glsdet_conv_cout_pad(cout) * glsdet_conv_kpad(R, S, cin, dtype);
+}
+
+extern "C" int glsdet_conv2d(const glsdet_conv_desc* d, void* stream) {
+  if (!d) GLS_FAIL(GLSDET_E_ARG, "conv2d: null descriptor");
+  const glsdet_view &x = d->x, &y = d->y;
+  int rc;
+  if ((rc = check_view(x, "conv2d.x"))) return rc;
+  if ((rc = check_view(y, "conv2d.y"))) return rc;
+  if (x.dtype == GLSDET_F32 && y.dtype != GLSDET_F32)
+    GLS_FAIL(GLSDET_E_ARG, "conv2d: f32 input needs f32 output");
+  if (d->R < 1 || d->S < 1 || d->R > 15 || d->S > 15 || d->stride < 1 || d->stride > 4 || d->pad < 0)
+    GLS_FAIL(GLSDET_E_ARG, "conv2d: bad R/S/stride/pad %d %d %d %d", d->R, d->S, d->stride, d->pad);
+  if (x.c % 8 || y.c % 8) GLS_FAIL(GLSDET_E_ARG, "conv2d: channels must be multiples of 8 (%d,%d)", x.c, y.c);
+  const int Ho = (x.h + 2 * d->pad - d->R) / d->stride + 1;
+  const int Wo = (x.w + 2 * d->pad - d->S) / d->stride + 1;
+  if (y.n != x.n || y.h != Ho || y.w != Wo)
+    GLS_FAIL(GLSDET_E_ARG, "conv2d: output extent [%d,%d,%d] != expected [%d,%d,%d]", y.n, y.h, y.w, x.n, Ho, Wo);
+  if (!d->w || !d->scale || !d->bias) GLS_FAIL(GLSDET_E_ARG, "conv2d: null weight/scale/bias");
+  if (((uintptr_t)d->w | (uintptr_t)d->scale | (uintptr_t)d->bias) & 15)
+    GLS_FAIL(GLSDET_E_ALIGN, "conv2d: weight/scale/bias must be 16-byte aligned");
+  if (d->act < 0 || d->act > 3) GLS_FAIL(GLSDET_E_ARG, "conv2d: bad act %d", d->act);
+  const bool has_res = d->res.base != nullptr;
+  if (has_res) {
+    if ((rc = check_view(d->res, "conv2d.res"))) return rc;
+    if (!same_extent(d->res, y) || d->res.dtype != y.dtype)
+      GLS_FAIL(GLSDET_E_ARG, "conv2d: residual must match the output extent and dtype");
+  }
+  const long M = (long)x.n * Ho * Wo;
+  if (M <= 0 || M > 0x7fffffffL) GLS_FAIL(GLSDET_E_ARG, "conv2d: pixel count %ld out of range", M);
+
+  ConvArgs a;
+  a.x = (const unsigned char*)x.base;
+  a.w = (const unsigned char*)d->w;
+  a.scale = d->scale;
+  a.bias = d->bias;
+  a.y = (unsigned char*)y.base;
+  a.res = has_res ? (const unsigned char*)d->res.base : nullptr;
+  a.x_sn = x.sn; a.x_sh = x.sh; a.x_sw = x.sw;
+  a.y_sn = y.sn; a.y_sh = y.sh; a.y_sw = y.sw;
+  a.r_sn = d->res.sn; a.r_sh = d->res.sh; a.r_sw = d->res.sw;
+  a.N = x.n; a.H = x.h; a.W = x.w; a.Cin = x.c;
+  a.Ho = Ho; a.Wo = Wo; a.Cout = y.c; a.cout_pad = glsdet_conv_cout_pad(y.c);
+  a.R = d->R; a.S = d->S; a.stride = d->stride; a.pad = d->pad; a.act = d->act;
+  a.kreal = d->R * d->S * x.c;
+  a.kpad = glsdet_conv_kpad(d->R, d->S, x.c, x.dtype);
+  a.M = (int)M;
+  a.n_co_tiles = a.n_px_tiles = 0;
+
+  int co_t, px_t, kb;
+  pick_tile(a, dtype_size(x.dtype), d->tile_hint, &co_t, &px_t, &kb);
+  const int xdt = x.dtype, ydt = y.dtype;
+
+  OpRecord op;
+  op.kind = 0;
+  op.flops = 2.0 * (double)M * y.c * a.kreal;
+  op.bytes = (double)x.n * x.h * x.w * x.c * dtype_size(xdt) + (double)M * y.c * dtype_size(ydt) * (has_res ? 2 : 1) +
+             (double)a.cout_pad * a.kpad * dtype_size(xdt);
+  char nm[96];
+  snprintf(nm, sizeof nm, "conv_igemm<%s,%s,%dx%d,kb%d> %dx%d s%d cin%d cout%d", xdt ? "f32" : "f16",
+           ydt ? "f32" : "f16", co_t, px_t, kb, d->R, d->S, d->stride, x.c, y.c);
+  op.name = nm;
+  op.launch = [a, co_t, px_t, kb, xdt, ydt](hipStream_t st) -> int {
+    if (xdt == GLSDET_F16 && ydt == GLSDET_F16) return dispatch_tile<f16, f16>(a, co_t, px_t, kb, st);
+    if (xdt == GLSDET_F16 && ydt == GLSDET_F32) return dispatch_tile<f16, float>(a, co_t, px_t, kb, st);
+    return dispatch_tile<float, float>(a, co_t, px_t, kb, st);
+  };
+  return submit(std::move(op), stream);
+}

@@ -1,0 +1,312 @@
+// HBM-bound helpers of the forward pass: Focus space-to-depth, SPP max pool, nearest
+// resample / strided copy, and the non-local block (re-associated dot-product form).
+// All are coalesced 16-byte-per-lane NHWC kernels; none of them is GEMM shaped enough to
+// deserve MFMA (the non-local block is 0.35 % of the model's MACs before re-association).
+#include "common.h"
+
+namespace glsdet {
+
+template <typename T> struct Vec16;
+template <> struct Vec16<f16> { typedef f16x8 type; static constexpr int N = 8; };
+template <> struct Vec16<float> { typedef f32x4 type; static constexpr int N = 4; };
+
+// ---------------------------------------------------------------- Focus space-to-depth
+// drone/models/base/darknet.py:15-21 : cat(TL, BL, TR, BR) on channels.
+template <typename T>
+__global__ __launch_bounds__(256) void focus_pack_kernel(const float* __restrict__ img, int n, int cin, int H, int W,
+                                                         unsigned char* y, long sn, long sh, long sw, int cy) {
+  const int Ho = H >> 1, Wo = W >> 1;
+  const long total = (long)n * Ho * Wo;
+  for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += (long)gridDim.x * blockDim.x) {
+    const int wo = (int)(p % Wo);
+    const int ho = (int)((p / Wo) % Ho);
+    const int b = (int)(p / ((long)Wo * Ho));
+    T* out = reinterpret_cast<T*>(y) + b * sn + ho * sh + wo * sw;
+    int ch = 0;
+    // patch order: (dy,dx) = (0,0) TL, (1,0) BL, (0,1) TR, (1,1) BR
+    for (int patch = 0; patch < 4; ++patch) {
+      const int dy = patch & 1, dx = patch >> 1;
+      for (int c = 0; c < cin; ++c, ++ch)
+        out[ch] = (T)img[(((long)b * cin + c) * H + (2 * ho + dy)) * W + (2 * wo + dx)];
+    }
+    for (; ch < cy; ++ch) out[ch] = (T)0.0f;
+  }
+}
+
+// ---------------------------------------------------------------- max pool k x k, s1
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_kernel(const unsigned char* x, long xsn, long xsh, long xsw,
+                                                      unsigned char* y, long ysn, long ysh, long ysw, int n, int H,
+                                                      int W, int C, int k) {
+  typedef typename Vec16<T>::type V;
+  constexpr int VN = Vec16<T>::N;
+  const int cchunks = C / VN;
+  const long total = (long)n * H * W * cchunks;
+  const int r = k / 2;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int cc = (int)(i % cchunks);
+    long p = i / cchunks;
+    const int w = (int)(p % W);
+    p /= W;
+    const int h = (int)(p % H);
+    const int b = (int)(p / H);
+    V m;
+#pragma unroll
+    for (int e = 0; e < VN; ++e) m[e] = (T)(-INFINITY);
+    for (int dy = -r; dy <= r; ++dy) {
+      const int hh = h + dy;
+      if (hh < 0 || hh >= H) continue;
+      for (int dx = -r; dx <= r; ++dx) {
+        const int ww = w + dx;
+        if (ww < 0 || ww >= W) continue;
+        const V v = *reinterpret_cast<const V*>(x + (b * xsn + hh * xsh + ww * xsw + cc * VN) * (long)sizeof(T));
+#pragma unroll
+        for (int e = 0; e < VN; ++e) m[e] = v[e] > m[e] ? v[e] : m[e];
+      }
+    }
+    *reinterpret_cast<V*>(y + (b * ysn + h * ysh + w * ysw + cc * VN) * (long)sizeof(T)) = m;
+  }
+}
+
+// ---------------------------------------------------------------- nearest resample / copy
+template <typename T>
+__global__ __launch_bounds__(256) void resample_kernel(const unsigned char* x, long xsn, long xsh, long xsw,
+                                                       unsigned char* y, long ysn, long ysh, long ysw, int n, int Ho,
+                                                       int Wo, int C, int f) {
+  constexpr int VN = Vec16<T>::N;
+  const int cchunks = C / VN;
+  const long total = (long)n * Ho * Wo * cchunks;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int cc = (int)(i % cchunks);
+    long p = i / cchunks;
+    const int w = (int)(p % Wo);
+    p /= Wo;
+    const int h = (int)(p % Ho);
+    const int b = (int)(p / Ho);
+    const uint4 v = *reinterpret_cast<const uint4*>(x + (b * xsn + (h / f) * xsh + (w / f) * xsw + cc * VN) * (long)sizeof(T));
+    *reinterpret_cast<uint4*>(y + (b * ysn + h * ysh + w * ysw + cc * VN) * (long)sizeof(T)) = v;
+  }
+}
+
+// ---------------------------------------------------------------- non-local block
+// G[b][c1][c2] = sum_j phi[b,j,c1] * g[b,j,c2]          (16x16 output block per workgroup)
+template <typename T>
+__global__ __launch_bounds__(256) void nl_gram_kernel(const unsigned char* tpg, long sn, long sh, long sw, int H, int W,
+                                                      int ci, float* G) {
+  __shared__ float ph[64][17], gg[64][17];
+  const int nb = (ci + 15) / 16;
+  const int c1_0 = (blockIdx.x / nb) * 16, c2_0 = (blockIdx.x % nb) * 16;
+  const int b = blockIdx.y;
+  const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
+  const int N = H * W;
+  const T* base = reinterpret_cast<const T*>(tpg) + b * sn;
+  float acc = 0.f;
+  for (int j0 = 0; j0 < N; j0 += 64) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int idx = threadIdx.x + e * 256;
+      const int jj = idx >> 4, cc = idx & 15;
+      const int j = j0 + jj;
+      float vp = 0.f, vg = 0.f;
+      if (j < N) {
+        const T* px = base + (j / W) * sh + (j % W) * sw;
+        if (c1_0 + cc < ci) vp = (float)px[ci + c1_0 + cc];
+        if (c2_0 + cc < ci) vg = (float)px[2 * ci + c2_0 + cc];
+      }
+      ph[jj][cc] = vp;
+      gg[jj][cc] = vg;
+    }
+    __syncthreads();
+#pragma unroll 16
+    for (int jj = 0; jj < 64; ++jj) acc += ph[jj][ty] * gg[jj][tx];
+    __syncthreads();
+  }
+  if (c1_0 + ty < ci && c2_0 + tx < ci) G[((long)b * ci + c1_0 + ty) * ci + c2_0 + tx] = acc;
+}
+
+// P[b][co][c1] = (1/N) sum_c2 Wout[co][c2] * G[b][c1][c2]
+__global__ __launch_bounds__(256) void nl_fold_kernel(const float* __restrict__ G, const float* __restrict__ wout,
+                                                      int ci, int cx, float invN, float* P) {
+  extern __shared__ float wrow[];
+  const int co = blockIdx.x, b = blockIdx.y;
+  for (int c = threadIdx.x; c < ci; c += blockDim.x) wrow[c] = wout[(long)co * ci + c];
+  __syncthreads();
+  for (int c1 = threadIdx.x; c1 < ci; c1 += blockDim.x) {
+    const float* g = G + ((long)b * ci + c1) * ci;
+    float acc = 0.f;
+    for (int c2 = 0; c2 < ci; ++c2) acc += wrow[c2] * g[c2];
+    P[((long)b * cx + co) * ci + c1] = acc * invN;
+  }
+}
+
+// out[b,i,co] = x[b,i,co] + bout[co] + sum_c1 theta[b,i,c1] * P[b][co][c1]
+// workgroup = 64 pixels of one image; theta tile in LDS (row stride ci+1: lanes = pixels,
+// conflict-free); P rows are wave-uniform reads.
+template <typename T>
+__global__ __launch_bounds__(256) void nl_apply_kernel(const unsigned char* x, long xsn, long xsh, long xsw,
+                                                       const unsigned char* tpg, long tsn, long tsh, long tsw,
+                                                       unsigned char* out, long osn, long osh, long osw, int H, int W,
+                                                       int ci, int cx, const float* __restrict__ P,
+                                                       const float* __restrict__ bout) {
+  extern __shared__ float th[];   // [64][ci+1]
+  const int N = H * W;
+  const int b = blockIdx.y, j0 = blockIdx.x * 64;
+  const int ld = ci + 1;
+  for (int idx = threadIdx.x; idx < 64 * ci; idx += 256) {
+    const int jj = idx / ci, c = idx - jj * ci;
+    const int j = j0 + jj;
+    float v = 0.f;
+    if (j < N) v = (float)(reinterpret_cast<const T*>(tpg) + b * tsn + (j / W) * tsh + (j % W) * tsw)[c];
+    th[jj * ld + c] = v;
+  }
+  __syncthreads();
+  const int jj = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int j = j0 + jj;
+  if (j >= N) return;
+  const long poff_x = b * xsn + (j / W) * xsh + (j % W) * xsw;
+  const long poff_o = b * osn + (j / W) * osh + (j % W) * osw;
+  const float* Pb = P + (long)b * cx * ci;
+  const float* t = th + jj * ld;
+  for (int co = grp; co < cx; co += 4) {
+    const float* pr = Pb + (long)co * ci;
+    float acc = 0.f;
+    for (int c = 0; c < ci; ++c) acc += t[c] * pr[c];
+    const float xv = (float)(reinterpret_cast<const T*>(x) + poff_x)[co];
+    (reinterpret_cast<T*>(out) + poff_o)[co] = (T)(xv + bout[co] + acc);
+  }
+}
+
+static inline unsigned grid_for(long work_items, int block = 256, long cap = 256L * 32) {
+  long g = (work_items + block - 1) / block;
+  if (g < 1) g = 1;
+  if (g > cap) g = cap;
+  return (unsigned)g;
+}
+
+}  // namespace glsdet
+
+using namespace glsdet;
+
+extern "C" int glsdet_focus_pack(const float* img, int32_t n, int32_t cin, int32_t H, int32_t W,
+                                 const glsdet_view* y, void* stream) {
+  if (!img || !y) GLS_FAIL(GLSDET_E_ARG, "focus_pack: null argument");
+  int rc;
+  if ((rc = check_view(*y, "focus_pack.y"))) return rc;
+  if (H % 2 || W % 2 || n < 1 || cin < 1) GLS_FAIL(GLSDET_E_ARG, "focus_pack: H,W must be even");
+  if (y->n != n || y->h != H / 2 || y->w != W / 2 || y->c < 4 * cin)
+    GLS_FAIL(GLSDET_E_ARG, "focus_pack: output extent mismatch");
+  const glsdet_view v = *y;
+  OpRecord op;
+  op.kind = 1;
+  op.flops = 0;
+  op.bytes = (double)n * cin * H * W * 4 + (double)n * (H / 2) * (W / 2) * v.c * dtype_size(v.dtype);
+  op.name = "focus_pack";
+  op.launch = [=](hipStream_t st) -> int {
+    const unsigned g = grid_for((long)n * (H / 2) * (W / 2));
+    if (v.dtype == GLSDET_F16)
+      hipLaunchKernelGGL(focus_pack_kernel<f16>, dim3(g), dim3(256), 0, st, img, n, cin, H, W, (unsigned char*)v.base, v.sn, v.sh, v.sw, v.c);
+    else
+      hipLaunchKernelGGL(focus_pack_kernel<float>, dim3(g), dim3(256), 0, st, img, n, cin, H, W, (unsigned char*)v.base, v.sn, v.sh, v.sw, v.c);
+    GLS_HIP(hipGetLastError());
+    return 0;
+  };
+  return submit(std::move(op), stream);
+}
+
+extern "C" int glsdet_maxpool2d(const glsdet_view* x, const glsdet_view* y, int32_t k, void* stream) {
+  if (!x || !y) GLS_FAIL(GLSDET_E_ARG, "maxpool2d: null argument");
+  int rc;
+  if ((rc = check_view(*x, "maxpool2d.x"))) return rc;
+  if ((rc = check_view(*y, "maxpool2d.y"))) return rc;
+  if (!same_extent(*x, *y) || x->dtype != y->dtype) GLS_FAIL(GLSDET_E_ARG, "maxpool2d: x/y extent or dtype mismatch");
+  if (k < 1 || !(k & 1) || k > 31) GLS_FAIL(GLSDET_E_ARG, "maxpool2d: k must be odd in [1,31]");
+  if (x->c % 8) GLS_FAIL(GLSDET_E_ARG, "maxpool2d: channels must be a multiple of 8");
+  const glsdet_view a = *x, b = *y;
+  OpRecord op;
+  op.kind = 2;
+  op.flops = 0;
+  op.bytes = 2.0 * a.n * a.h * a.w * a.c * dtype_size(a.dtype);
+  op.name = "maxpool";
+  op.launch = [=](hipStream_t st) -> int {
+    const int vn = 16 / dtype_size(a.dtype);
+    const unsigned g = grid_for((long)a.n * a.h * a.w * (a.c / vn));
+    if (a.dtype == GLSDET_F16)
+      hipLaunchKernelGGL(maxpool_kernel<f16>, dim3(g), dim3(256), 0, st, (const unsigned char*)a.base, a.sn, a.sh, a.sw, (unsigned char*)b.base, b.sn, b.sh, b.sw, a.n, a.h, a.w, a.c, k);
+    else
+      hipLaunchKernelGGL(maxpool_kernel<float>, dim3(g), dim3(256), 0, st, (const unsigned char*)a.base, a.sn, a.sh, a.sw, (unsigned char*)b.base, b.sn, b.sh, b.sw, a.n, a.h, a.w, a.c, k);
+    GLS_HIP(hipGetLastError());
+    return 0;
+  };
+  return submit(std::move(op), stream);
+}
+
+extern "C" int glsdet_resample_copy(const glsdet_view* x, const glsdet_view* y, int32_t factor, void* stream) {
+  if (!x || !y) GLS_FAIL(GLSDET_E_ARG, "resample_copy: null argument");
+  int rc;
+  if ((rc = check_view(*x, "resample_copy.x"))) return rc;
+  if ((rc = check_view(*y, "resample_copy.y"))) return rc;
+  if (factor < 1 || factor > 8) GLS_FAIL(GLSDET_E_ARG, "resample_copy: bad factor %d", factor);
+  if (x->dtype != y->dtype || y->n != x->n || y->c != x->c || y->h != x->h * factor || y->w != x->w * factor)
+    GLS_FAIL(GLSDET_E_ARG, "resample_copy: extent mismatch");
+  if (x->c % 8) GLS_FAIL(GLSDET_E_ARG, "resample_copy: channels must be a multiple of 8");
+  const glsdet_view a = *x, b = *y;
+  OpRecord op;
+  op.kind = 3;
+  op.flops = 0;
+  op.bytes = ((double)a.n * a.h * a.w + (double)b.n * b.h * b.w) * a.c * dtype_size(a.dtype);
+  op.name = factor == 1 ? "copy" : "upsample_nearest";
+  op.launch = [=](hipStream_t st) -> int {
+    const int vn = 16 / dtype_size(a.dtype);
+    const unsigned g = grid_for((long)b.n * b.h * b.w * (b.c / vn));
+    if (a.dtype == GLSDET_F16)
+      hipLaunchKernelGGL(resample_kernel<f16>, dim3(g), dim3(256), 0, st, (const unsigned char*)a.base, a.sn, a.sh, a.sw, (unsigned char*)b.base, b.sn, b.sh, b.sw, b.n, b.h, b.w, b.c, factor);
+    else
+      hipLaunchKernelGGL(resample_kernel<float>, dim3(g), dim3(256), 0, st, (const unsigned char*)a.base, a.sn, a.sh, a.sw, (unsigned char*)b.base, b.sn, b.sh, b.sw, b.n, b.h, b.w, b.c, factor);
+    GLS_HIP(hipGetLastError());
+    return 0;
+  };
+  return submit(std::move(op), stream);
+}
+
+extern "C" int glsdet_nonlocal(const glsdet_view* x, const glsdet_view* tpg, int32_t ci, const float* wout,
+                               const float* bout, float* gram, const glsdet_view* out, void* stream) {
+  if (!x || !tpg || !out || !wout || !bout || !gram) GLS_FAIL(GLSDET_E_ARG, "nonlocal: null argument");
+  int rc;
+  if ((rc = check_view(*x, "nonlocal.x", false))) return rc;
+  if ((rc = check_view(*tpg, "nonlocal.tpg", false))) return rc;
+  if ((rc = check_view(*out, "nonlocal.out", false))) return rc;
+  if (!same_extent(*x, *out) || x->dtype != out->dtype || tpg->dtype != x->dtype)
+    GLS_FAIL(GLSDET_E_ARG, "nonlocal: x/out extent or dtype mismatch");
+  if (tpg->n != x->n || tpg->h != x->h || tpg->w != x->w || ci < 1 || tpg->c < 3 * ci)
+    GLS_FAIL(GLSDET_E_ARG, "nonlocal: theta|phi|g view must be [n,h,w,>=3*ci]");
+  const int cx = x->c;
+  if ((long)64 * (ci + 1) * 4 > 150 * 1024) GLS_FAIL(GLSDET_E_ARG, "nonlocal: ci=%d too large for the LDS tile", ci);
+  const glsdet_view vx = *x, vt = *tpg, vo = *out;
+  const int N = vx.h * vx.w;
+  OpRecord op;
+  op.kind = 4;
+  // algorithmic count of the reference's two matmuls: 2 * (N*N*ci) MACs per image
+  op.flops = 2.0 * 2.0 * (double)vx.n * N * (double)N * ci;
+  op.bytes = (double)vx.n * N * (3.0 * ci + 2.0 * cx) * dtype_size(vx.dtype);
+  op.name = "nonlocal(gram+fold+apply)";
+  float* P = gram + (long)vx.n * ci * ci;
+  op.launch = [=](hipStream_t st) -> int {
+    const int nb = (ci + 15) / 16;
+    const dim3 g1(nb * nb, vx.n), g2(cx, vx.n), g3((N + 63) / 64, vx.n);
+    const size_t lds3 = (size_t)64 * (ci + 1) * 4;
+    if (vx.dtype == GLSDET_F16) {
+      hipLaunchKernelGGL(nl_gram_kernel<f16>, g1, dim3(256), 0, st, (const unsigned char*)vt.base, vt.sn, vt.sh, vt.sw, vt.h, vt.w, ci, gram);
+      hipLaunchKernelGGL(nl_fold_kernel, g2, dim3(256), ci * sizeof(float), st, gram, wout, ci, cx, 1.0f / (float)N, P);
+      if (lds3 > 64 * 1024) GLS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(nl_apply_kernel<f16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3));
+      hipLaunchKernelGGL(nl_apply_kernel<f16>, g3, dim3(256), lds3, st, (const unsigned char*)vx.base, vx.sn, vx.sh, vx.sw, (const unsigned char*)vt.base, vt.sn, vt.sh, vt.sw, (unsigned char*)vo.base, vo.sn, vo.sh, vo.sw, vx.h, vx.w, ci, cx, P, bout);
+    } else {
+      hipLaunchKernelGGL(nl_gram_kernel<float>, g1, dim3(256), 0, st, (const unsigned char*)vt.base, vt.sn, vt.sh, vt.sw, vt.h, vt.w, ci, gram);
+      hipLaunchKernelGGL(nl_fold_kernel, g2, dim3(256), ci * sizeof(float), st, gram, wout, ci, cx, 1.0f / (float)N, P);
+      if (lds3 > 64 * 1024) GLS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(nl_apply_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3));
+      hipLaunchKernelGGL(nl_apply_kernel<float>, g3, dim3(256), lds3, st, (const unsigned char*)vx.base, vx.sn, vx.sh, vx.sw, (const unsigned char*)vt.base, vt.sn, vt.sh, vt.sw, (unsigned char*)vo.base, vo.sn, vo.sh, vo.sw, vx.h, vx.w, ci, cx, P, bout);
+    }
+    GLS_HIP(hipGetLastError());
+    return 0;
+  };
+  return submit(std::move(op), stream);
+}

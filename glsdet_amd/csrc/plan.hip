@@ -1,0 +1,150 @@
+// Error text, view validation, and the plan (record -> eager replay / hipGraph replay).
+#include <stdarg.h>
+#include <string.h>
+#include <vector>
+
+#include "common.h"
+
+namespace glsdet {
+
+static thread_local char g_err[512] = "";
+static thread_local glsdet_plan* g_recording = nullptr;
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof g_err, fmt, ap);
+  va_end(ap);
+}
+
+int check_view(const glsdet_view& v, const char* what, bool need16) {
+  if (!v.base) GLS_FAIL(GLSDET_E_ARG, "%s: null base", what);
+  if (v.dtype != GLSDET_F16 && v.dtype != GLSDET_F32) GLS_FAIL(GLSDET_E_ARG, "%s: bad dtype %d", what, v.dtype);
+  if (v.n < 1 || v.h < 1 || v.w < 1 || v.c < 1) GLS_FAIL(GLSDET_E_ARG, "%s: empty extent [%d,%d,%d,%d]", what, v.n, v.h, v.w, v.c);
+  if (v.sn < 0 || v.sh < 0 || v.sw < 0) GLS_FAIL(GLSDET_E_ARG, "%s: negative stride", what);
+  const int es = dtype_size(v.dtype);
+  if (need16) {
+    const int vec = 16 / es;
+    if (((uintptr_t)v.base & 15) || (v.sn % vec) || (v.sh % vec) || (v.sw % vec))
+      GLS_FAIL(GLSDET_E_ALIGN, "%s: base/strides not 16-byte compatible", what);
+  }
+  if (v.sw < v.c && v.w > 1) GLS_FAIL(GLSDET_E_ARG, "%s: pixel stride %ld < channels %d", what, (long)v.sw, v.c);
+  const char* lo = (const char*)v.base;
+  const char* hi = lo + ((int64_t)(v.n - 1) * v.sn + (int64_t)(v.h - 1) * v.sh + (int64_t)(v.w - 1) * v.sw + v.c) * es;
+  if (!v.alloc_lo || !v.alloc_hi || lo < (const char*)v.alloc_lo || hi > (const char*)v.alloc_hi)
+    GLS_FAIL(GLSDET_E_BOUNDS, "%s: view [%p,%p) leaves its allocation [%p,%p)", what, (const void*)lo,
+             (const void*)hi, v.alloc_lo, v.alloc_hi);
+  return 0;
+}
+
+}  // namespace glsdet
+
+struct glsdet_plan {
+  std::vector<glsdet::OpRecord> ops;
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t exec = nullptr;
+};
+
+namespace glsdet {
+int submit(OpRecord&& op, void* stream) {
+  if (g_recording) {
+    g_recording->ops.emplace_back(std::move(op));
+    return 0;
+  }
+  return op.launch((hipStream_t)stream);
+}
+}  // namespace glsdet
+
+using namespace glsdet;
+
+extern "C" const char* glsdet_last_error(void) { return g_err; }
+extern "C" int32_t glsdet_abi_version(void) { return GLSDET_ABI_VERSION; }
+
+extern "C" glsdet_plan* glsdet_plan_create(void) { return new glsdet_plan(); }
+extern "C" void glsdet_plan_destroy(glsdet_plan* p) {
+  if (!p) return;
+  if (g_recording == p) g_recording = nullptr;
+  if (p->exec) (void)hipGraphExecDestroy(p->exec);
+  if (p->graph) (void)hipGraphDestroy(p->graph);
+  delete p;
+}
+extern "C" int glsdet_plan_begin(glsdet_plan* p) {
+  if (!p) GLS_FAIL(GLSDET_E_ARG, "plan_begin: null plan");
+  if (g_recording) GLS_FAIL(GLSDET_E_ARG, "plan_begin: this thread is already recording");
+  g_recording = p;
+  return 0;
+}
+extern "C" int glsdet_plan_end(glsdet_plan* p) {
+  if (g_recording != p) GLS_FAIL(GLSDET_E_ARG, "plan_end: plan is not the one being recorded");
+  g_recording = nullptr;
+  return 0;
+}
+extern "C" int32_t glsdet_plan_num_ops(const glsdet_plan* p) { return p ? (int32_t)p->ops.size() : 0; }
+extern "C" int glsdet_plan_op_info(const glsdet_plan* p, int32_t i, int32_t* kind, double* flops, double* bytes,
+                                   char* name, int32_t name_cap) {
+  if (!p || i < 0 || i >= (int32_t)p->ops.size()) GLS_FAIL(GLSDET_E_ARG, "plan_op_info: bad index");
+  const OpRecord& o = p->ops[i];
+  if (kind) *kind = o.kind;
+  if (flops) *flops = o.flops;
+  if (bytes) *bytes = o.bytes;
+  if (name && name_cap > 0) {
+    strncpy(name, o.name.c_str(), name_cap - 1);
+    name[name_cap - 1] = 0;
+  }
+  return 0;
+}
+extern "C" int glsdet_plan_run(glsdet_plan* p, void* stream) {
+  if (!p) GLS_FAIL(GLSDET_E_ARG, "plan_run: null plan");
+  for (auto& o : p->ops) {
+    int rc = o.launch((hipStream_t)stream);
+    if (rc) return rc;
+  }
+  return 0;
+}
+extern "C" int glsdet_plan_capture(glsdet_plan* p, void* stream) {
+  if (!p) GLS_FAIL(GLSDET_E_ARG, "plan_capture: null plan");
+  hipStream_t st = (hipStream_t)stream;
+  if (!st) GLS_FAIL(GLSDET_E_ARG, "plan_capture: needs a non-default stream");
+  if (p->exec) { (void)hipGraphExecDestroy(p->exec); p->exec = nullptr; }
+  if (p->graph) { (void)hipGraphDestroy(p->graph); p->graph = nullptr; }
+  GLS_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+  int rc = 0;
+  for (auto& o : p->ops) {
+    rc = o.launch(st);
+    if (rc) break;
+  }
+  hipGraph_t g = nullptr;
+  hipError_t e = hipStreamEndCapture(st, &g);
+  if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }
+  if (e != hipSuccess) GLS_FAIL(GLSDET_E_HIP, "hipStreamEndCapture: %s", hipGetErrorString(e));
+  p->graph = g;
+  GLS_HIP(hipGraphInstantiate(&p->exec, p->graph, nullptr, nullptr, 0));
+  return 0;
+}
+extern "C" int glsdet_plan_launch(glsdet_plan* p, void* stream) {
+  if (!p || !p->exec) GLS_FAIL(GLSDET_E_ARG, "plan_launch: plan not captured");
+  GLS_HIP(hipGraphLaunch(p->exec, (hipStream_t)stream));
+  return 0;
+}
+extern "C" int glsdet_plan_run_timed(glsdet_plan* p, void* stream, float* ms) {
+  if (!p || !ms) GLS_FAIL(GLSDET_E_ARG, "plan_run_timed: null argument");
+  hipStream_t st = (hipStream_t)stream;
+  const size_t n = p->ops.size();
+  std::vector<hipEvent_t> ev(n + 1);
+  for (auto& e : ev) GLS_HIP(hipEventCreate(&e));
+  int rc = 0;
+  GLS_HIP(hipEventRecord(ev[0], st));
+  for (size_t i = 0; i < n && !rc; ++i) {
+    rc = p->ops[i].launch(st);
+    if (!rc && hipEventRecord(ev[i + 1], st) != hipSuccess) rc = GLSDET_E_HIP;
+  }
+  if (!rc && hipEventSynchronize(ev[n]) != hipSuccess) rc = GLSDET_E_HIP;
+  for (size_t i = 0; i < n && !rc; ++i) {
+    float t = 0.f;
+    if (hipEventElapsedTime(&t, ev[i], ev[i + 1]) != hipSuccess) { rc = GLSDET_E_HIP; break; }
+    ms[i] += t;
+  }
+  for (auto& e : ev) (void)hipEventDestroy(e);
+  if (rc == GLSDET_E_HIP) set_error("plan_run_timed: HIP event error");
+  return rc;
+}

@@ -1,0 +1,259 @@
+"""Host side of the HIP path: device memory, NHWC views, weight packing and the plan.
+
+PyTorch is plumbing here (device allocations, streams); every arithmetic step of the
+forward pass is a kernel of libglsdet_hip.so reached through the C ABI (``_lib``).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import F16, F32, ACT, View, ConvDesc, check
+
+_TORCH_DT = {F16: torch.float16, F32: torch.float32}
+_ESIZE = {F16: 2, F32: 4}
+
+
+def ceil_to(v: int, m: int) -> int:
+    return (v + m - 1) // m * m
+
+
+class TView:
+    """NHWC view into a device allocation (mirrors glsdet_view).  Strides in elements."""
+    __slots__ = ("buf", "off", "n", "h", "w", "c", "sn", "sh", "sw", "dtype")
+
+    def __init__(self, buf: torch.Tensor, off: int, n: int, h: int, w: int, c: int,
+                 sn: int, sh: int, sw: int, dtype: int):
+        self.buf, self.off = buf, off
+        self.n, self.h, self.w, self.c = n, h, w, c
+        self.sn, self.sh, self.sw, self.dtype = sn, sh, sw, dtype
+
+    # ---- sub-views (no copies: this is how torch.cat / slicing of the reference is realised)
+    def channels(self, c0: int, c1: int) -> "TView":
+        assert 0 <= c0 < c1 <= self.c and c0 % 8 == 0, (c0, c1, self.c)
+        return TView(self.buf, self.off + c0, self.n, self.h, self.w, c1 - c0, self.sn, self.sh, self.sw, self.dtype)
+
+    def window(self, h0: int, h1: int, w0: int, w1: int) -> "TView":
+        assert 0 <= h0 < h1 <= self.h and 0 <= w0 < w1 <= self.w
+        return TView(self.buf, self.off + h0 * self.sh + w0 * self.sw, self.n, h1 - h0, w1 - w0, self.c,
+                     self.sn, self.sh, self.sw, self.dtype)
+
+    def as_c(self) -> View:
+        es = _ESIZE[self.dtype]
+        lo = self.buf.data_ptr()
+        return View(lo + self.off * es, self.sn, self.sh, self.sw, self.n, self.h, self.w, self.c,
+                    self.dtype, 0, lo, lo + self.buf.numel() * self.buf.element_size())
+
+    def to_nchw(self, c: Optional[int] = None) -> torch.Tensor:
+        """Materialise as a dense NCHW fp32 torch tensor (tests / the drop-in surface)."""
+        t = torch.as_strided(self.buf.view(_TORCH_DT[self.dtype]), (self.n, self.h, self.w, self.c),
+                             (self.sn, self.sh, self.sw, 1), self.off)
+        t = t[..., : (c or self.c)]
+        return t.permute(0, 3, 1, 2).float().contiguous()
+
+    def __repr__(self):
+        return "TView[%d,%d,%d,%d %s]" % (self.n, self.h, self.w, self.c, "f16" if self.dtype == F16 else "f32")
+
+
+class Plan:
+    """Recorded op sequence (glsdet_plan): eager replay, hipGraph capture/replay, timing."""
+
+    def __init__(self, lib):
+        self.lib = lib
+        self.h = lib.glsdet_plan_create()
+        self.captured = False
+
+    def __del__(self):
+        try:
+            if self.h:
+                self.lib.glsdet_plan_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def __enter__(self):
+        check(self.lib.glsdet_plan_begin(self.h), "plan_begin")
+        return self
+
+    def __exit__(self, *exc):
+        check(self.lib.glsdet_plan_end(self.h), "plan_end")
+        return False
+
+    @property
+    def num_ops(self) -> int:
+        return self.lib.glsdet_plan_num_ops(self.h)
+
+    def ops(self):
+        out = []
+        name = C.create_string_buffer(160)
+        kind, fl, by = C.c_int32(), C.c_double(), C.c_double()
+        for i in range(self.num_ops):
+            check(self.lib.glsdet_plan_op_info(self.h, i, C.byref(kind), C.byref(fl), C.byref(by), name, 160))
+            out.append({"kind": kind.value, "flops": fl.value, "bytes": by.value, "name": name.value.decode()})
+        return out
+
+    def run(self, stream=None):
+        check(self.lib.glsdet_plan_run(self.h, _stream_ptr(stream)), "plan_run")
+
+    def capture(self, stream):
+        check(self.lib.glsdet_plan_capture(self.h, _stream_ptr(stream)), "plan_capture")
+        self.captured = True
+
+    def launch(self, stream=None):
+        check(self.lib.glsdet_plan_launch(self.h, _stream_ptr(stream)), "plan_launch")
+
+    def run_timed(self, stream=None, reps: int = 1) -> np.ndarray:
+        ms = (C.c_float * self.num_ops)()
+        for _ in range(reps):
+            check(self.lib.glsdet_plan_run_timed(self.h, _stream_ptr(stream), ms), "plan_run_timed")
+        return np.asarray(ms[:], np.float64) / reps
+
+
+def _stream_ptr(stream) -> int:
+    if stream is None:
+        stream = torch.cuda.current_stream()
+    return stream.cuda_stream
+
+
+class Engine:
+    """Owns device buffers and packed weights; emits ops (eagerly or into a Plan)."""
+
+    def __init__(self, dtype: str = "f16", device: str = "cuda:0"):
+        self.lib = _lib.load()          # raises GlsdetLibraryError when the .so is missing
+        if not torch.cuda.is_available():
+            raise _lib.GlsdetLibraryError("glsdet_amd needs an MI355X visible to PyTorch-ROCm (no CPU fallback)")
+        assert dtype in ("f16", "f32")
+        self.dt = F16 if dtype == "f16" else F32
+        self.device = torch.device(device)
+        self.stream = None              # None -> torch current stream at call time
+        self._keep: List[torch.Tensor] = []
+        self.alloc_bytes = 0
+
+    # ---- memory
+    def raw(self, nbytes: int) -> torch.Tensor:
+        t = torch.zeros(ceil_to(max(nbytes, 16), 256), dtype=torch.uint8, device=self.device)
+        self._keep.append(t)
+        self.alloc_bytes += t.numel()
+        return t
+
+    def tensor(self, n: int, h: int, w: int, c: int, dtype: Optional[int] = None) -> TView:
+        dt = self.dt if dtype is None else dtype
+        cp = ceil_to(c, 8)
+        buf = self.raw(n * h * w * cp * _ESIZE[dt])
+        return TView(buf, 0, n, h, w, cp, h * w * cp, w * cp, cp, dt)
+
+    def upload(self, arr: torch.Tensor) -> torch.Tensor:
+        t = arr.contiguous().to(self.device)
+        self._keep.append(t)
+        self.alloc_bytes += t.numel() * t.element_size()
+        return t
+
+    # ---- weights
+    def pack_conv(self, parts: Sequence[Tuple[torch.Tensor, torch.Tensor, torch.Tensor]], cin_pad: int):
+        """parts: [(w OIHW fp32, scale[O], bias[O])...] concatenated along O.
+        -> (w_dev [cout_pad][kpad] in engine dtype, scale_dev, bias_dev, cout, R, S)"""
+        w = torch.cat([p[0].float() for p in parts], 0)
+        scale = torch.cat([p[1].float() for p in parts], 0)
+        bias = torch.cat([p[2].float() for p in parts], 0)
+        cout, cin, R, S = w.shape
+        assert cin <= cin_pad and cin_pad % 8 == 0
+        kpad = self.lib.glsdet_conv_kpad(R, S, cin_pad, self.dt)
+        cpad = self.lib.glsdet_conv_cout_pad(ceil_to(cout, 8))
+        wp = torch.zeros(cpad, R, S, cin_pad, dtype=torch.float32)
+        wp[:cout, :, :, :cin] = w.permute(0, 2, 3, 1)
+        flat = torch.zeros(cpad, kpad, dtype=torch.float32)
+        flat[:, : R * S * cin_pad] = wp.reshape(cpad, -1)
+        sc = torch.ones(cpad, dtype=torch.float32)
+        bi = torch.zeros(cpad, dtype=torch.float32)
+        sc[:cout], bi[:cout] = scale, bias
+        return (self.upload(flat.to(_TORCH_DT[self.dt])), self.upload(sc), self.upload(bi), cout, R, S)
+
+    # ---- ops (each is one C-ABI call)
+    def conv(self, x: TView, packed, stride: int, pad: int, act: str, out: Optional[TView] = None,
+             res: Optional[TView] = None, out_dtype: Optional[int] = None, tile_hint: int = 0) -> TView:
+        wdev, sdev, bdev, cout, R, S = packed
+        ho = (x.h + 2 * pad - R) // stride + 1
+        wo = (x.w + 2 * pad - S) // stride + 1
+        if out is None:
+            out = self.tensor(x.n, ho, wo, cout, out_dtype)
+        assert out.c == ceil_to(cout, 8), (out.c, cout)
+        d = ConvDesc()
+        d.x, d.y = x.as_c(), out.as_c()
+        d.res = res.as_c() if res is not None else View()
+        d.w, d.scale, d.bias = wdev.data_ptr(), sdev.data_ptr(), bdev.data_ptr()
+        d.R, d.S, d.stride, d.pad, d.act, d.tile_hint = R, S, stride, pad, ACT[act], tile_hint
+        check(self.lib.glsdet_conv2d(C.byref(d), _stream_ptr(self.stream)), "conv2d")
+        return out
+
+    def focus_pack(self, img: torch.Tensor, out: Optional[TView] = None) -> TView:
+        assert img.dtype == torch.float32 and img.is_contiguous() and img.device.type == "cuda"
+        n, cin, H, W = img.shape
+        if out is None:
+            out = self.tensor(n, H // 2, W // 2, ceil_to(4 * cin, 8))
+        check(self.lib.glsdet_focus_pack(img.data_ptr(), n, cin, H, W, C.byref(out.as_c()),
+                                         _stream_ptr(self.stream)), "focus_pack")
+        return out
+
+    def maxpool(self, x: TView, k: int, out: Optional[TView] = None) -> TView:
+        if out is None:
+            out = self.tensor(x.n, x.h, x.w, x.c, x.dtype)
+        check(self.lib.glsdet_maxpool2d(C.byref(x.as_c()), C.byref(out.as_c()), k, _stream_ptr(self.stream)), "maxpool2d")
+        return out
+
+    def resample(self, x: TView, factor: int, out: Optional[TView] = None) -> TView:
+        if out is None:
+            out = self.tensor(x.n, x.h * factor, x.w * factor, x.c, x.dtype)
+        check(self.lib.glsdet_resample_copy(C.byref(x.as_c()), C.byref(out.as_c()), factor,
+                                            _stream_ptr(self.stream)), "resample_copy")
+        return out
+
+    def nonlocal_(self, x: TView, tpg: TView, ci: int, wout: torch.Tensor, bout: torch.Tensor,
+                  out: Optional[TView] = None) -> TView:
+        if out is None:
+            out = self.tensor(x.n, x.h, x.w, x.c, x.dtype)
+        ws = self.raw(x.n * (ci * ci + x.c * ci) * 4)
+        check(self.lib.glsdet_nonlocal(C.byref(x.as_c()), C.byref(tpg.as_c()), ci, wout.data_ptr(), bout.data_ptr(),
+                                       ws.data_ptr(), C.byref(out.as_c()), _stream_ptr(self.stream)), "nonlocal")
+        return out
+
+    def decode(self, levels: Sequence[TView], num_classes: int, in_h: int, in_w: int,
+               strides: Optional[Sequence[int]] = None, mode: int = 0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        A = sum(l.h * l.w for l in levels)
+        n = levels[0].n
+        if out is None:
+            out = torch.empty(n, A, 5 + num_classes, dtype=torch.float32, device=self.device)
+            self._keep.append(out)
+        arr = (View * len(levels))(*[l.as_c() for l in levels])
+        st = (C.c_int32 * len(levels))(*strides) if strides is not None else None
+        check(self.lib.glsdet_yolox_decode(arr, len(levels), num_classes, in_h, in_w, st, mode,
+                                           out.data_ptr(), out.numel(), _stream_ptr(self.stream)), "yolox_decode")
+        return out
+
+    def nms_buffers(self, n: int, A: int, max_cand: int, max_det: int):
+        nbytes = self.lib.glsdet_nms_workspace_bytes(n, A, max_cand)
+        return {"ws": self.raw(nbytes), "n": n, "A": A, "max_cand": max_cand, "max_det": max_det,
+                "dets": torch.zeros(n, max_det, 7, dtype=torch.float32, device=self.device),
+                "count": torch.zeros(2 * n, dtype=torch.int32, device=self.device),
+                "status": torch.zeros(1, dtype=torch.int32, device=self.device)}
+
+    def nms(self, pred: torch.Tensor, num_classes: int, box_mode: int, conf_thres: float, nms_thres: float, nb):
+        n, A = pred.shape[0], pred.shape[1]
+        assert pred.is_contiguous() and pred.dtype == torch.float32 and n == nb["n"] and A == nb["A"]
+        check(self.lib.glsdet_nms(pred.data_ptr(), n, A, num_classes, box_mode, conf_thres, nms_thres,
+                                  nb["max_cand"], nb["max_det"], nb["dets"].data_ptr(), nb["count"].data_ptr(),
+                                  nb["status"].data_ptr(), nb["ws"].data_ptr(), nb["ws"].numel(),
+                                  _stream_ptr(self.stream)), "nms")
+        return nb["dets"], nb["count"], nb["status"]
+
+    def new_plan(self) -> Plan:
+        return Plan(self.lib)
+
+
+def fold_bn(gamma, beta, mean, var, eps: float):
+    """BatchNorm (eval) -> per-channel scale/bias, computed in fp64."""
+    s = gamma.double() / torch.sqrt(var.double() + eps)
+    return s.float(), (beta.double() - mean.double() * s).float()

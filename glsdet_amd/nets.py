@@ -1,0 +1,242 @@
+"""Graph builders: lower a GLSDet detector (given as a reference-named state_dict) to a
+sequence of libglsdet_hip ops on NHWC views.
+
+What the reference does with separate tensors and ``torch.cat`` / slicing is done here
+with views into shared buffers, so no concat, quadrant slice or re-stitch ever moves data:
+
+* every concat input is written by its producer straight into its channel slice;
+* CSP ``conv1``/``conv2`` (same input, both 1x1) run as ONE GEMM with Cout = 2*hidden that
+  lands directly in the concat buffer ``conv3`` reads; bottlenecks update their half in place;
+* SPP pools 5/9/13 are three chained 5x5 pools (exact for stride-1 max pools);
+* the four quadrant convs of a Patch_Conv write into one full-size buffer whose
+  left/right/top/bottom halves ARE the reference's l/r/t/b stitches;
+* the first convs of the cls and reg towers share their input and run as one GEMM; the three
+  predictors of a level run as one 1x1 GEMM with block-structured weights that emits the
+  reference's ``cat([reg, obj, cls])`` channel order (fp32 logits).
+
+Reference topology: drone/models/base/{darknet,yolox}.py,
+drone/models/block/non_local/{Identity_Conv,yolo_patch_nonlocal_plus}.py.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Sequence
+
+import torch
+
+from ._lib import F32
+from .engine import Engine, TView, ceil_to, fold_bn
+
+BN_EPS = 1e-3   # drone/models/base/baseConv.py:12
+
+
+class NetBuilder:
+    def __init__(self, eng: Engine, sd: Dict[str, torch.Tensor]):
+        self.e = eng
+        self.sd = {k: v.detach().cpu() for k, v in sd.items()}
+        self._packed = {}
+
+    # ------------------------------------------------------------------ weights
+    def _bn_part(self, p: str):
+        s, b = fold_bn(self.sd[p + ".bn.weight"], self.sd[p + ".bn.bias"],
+                       self.sd[p + ".bn.running_mean"], self.sd[p + ".bn.running_var"], BN_EPS)
+        return self.sd[p + ".conv.weight"], s, b
+
+    def _plain_part(self, p: str):
+        w = self.sd[p + ".weight"]
+        b = self.sd.get(p + ".bias")
+        if b is None:
+            b = torch.zeros(w.shape[0])
+        return w, torch.ones(w.shape[0]), b
+
+    def _pack(self, key, parts, cin_pad):
+        k = (key, cin_pad)
+        if k not in self._packed:
+            self._packed[k] = self.e.pack_conv(parts, cin_pad)
+        return self._packed[k]
+
+    def has(self, key: str) -> bool:
+        return key in self.sd
+
+    def is_depthwise(self, p: str) -> bool:
+        return (p + ".dconv.conv.weight") in self.sd
+
+    # ------------------------------------------------------------------ conv flavours
+    def cba(self, prefixes, x: TView, stride: int = 1, act: str = "silu", out: Optional[TView] = None,
+            res: Optional[TView] = None) -> TView:
+        """BaseConv(s): conv (no bias) + BN + act; several prefixes = fused along Cout."""
+        if isinstance(prefixes, str):
+            prefixes = [prefixes]
+        for p in prefixes:
+            if self.is_depthwise(p):
+                raise NotImplementedError("depthwise (phi='nano') towers are not lowered yet: " + p)
+        parts = [self._bn_part(p) for p in prefixes]
+        k = parts[0][0].shape[-1]
+        pk = self._pack("+".join(prefixes), parts, x.c)
+        return self.e.conv(x, pk, stride, (k - 1) // 2, act, out=out, res=res)
+
+    def plain(self, p: str, x: TView, pad: int = 0, out: Optional[TView] = None) -> TView:
+        """nn.Conv2d with bias, no norm / activation."""
+        pk = self._pack(p, [self._plain_part(p)], x.c)
+        return self.e.conv(x, pk, 1, pad, "none", out=out)
+
+    def conv_out_channels(self, p: str) -> int:
+        return self.sd[p + ".conv.weight"].shape[0]
+
+    # ------------------------------------------------------------------ blocks
+    def csp(self, p: str, x: TView, shortcut: bool, out: Optional[TView] = None) -> TView:
+        hid = self.conv_out_channels(p + ".conv1")
+        cat = self.e.tensor(x.n, x.h, x.w, 2 * hid)
+        self.cba([p + ".conv1", p + ".conv2"], x, out=cat)          # [main | short]
+        a = cat.channels(0, hid)
+        i = 0
+        while self.has("%s.m.%d.conv1.conv.weight" % (p, i)):
+            t = self.cba("%s.m.%d.conv1" % (p, i), a)
+            self.cba("%s.m.%d.conv2" % (p, i), t, out=a, res=a if shortcut else None)   # in place
+            i += 1
+        return self.cba(p + ".conv3", cat, out=out)
+
+    def spp(self, p: str, x: TView, out: Optional[TView] = None) -> TView:
+        hid = self.conv_out_channels(p + ".conv1")
+        cat = self.e.tensor(x.n, x.h, x.w, 4 * hid)
+        self.cba(p + ".conv1", x, out=cat.channels(0, hid))
+        for i in range(3):      # 5 -> 9 -> 13 by chaining 5x5 pools
+            self.e.maxpool(cat.channels(i * hid, (i + 1) * hid), 5, out=cat.channels((i + 1) * hid, (i + 2) * hid))
+        return self.cba(p + ".conv2", cat, out=out)
+
+    def darknet(self, p: str, img: torch.Tensor, homes: Dict[str, Optional[TView]]) -> Dict[str, TView]:
+        """CSPDarknet.  homes[name] = view the named output must be written to (or None)."""
+        f = {}
+        x = self.e.focus_pack(img)
+        x = self.cba(p + ".stem.conv", x)
+        for name in ("dark2", "dark3", "dark4"):
+            x = self.cba("%s.%s.0" % (p, name), x, 2)
+            x = self.csp("%s.%s.1" % (p, name), x, True, out=homes.get(name))
+            f[name] = x
+        x = self.cba(p + ".dark5.0", x, 2)
+        x = self.spp(p + ".dark5.1", x)
+        x = self.csp(p + ".dark5.2", x, False, out=homes.get("dark5"))
+        f["dark5"] = x
+        return f
+
+    def nonlocal_block(self, p: str, x: TView) -> TView:
+        """In place on x.  theta|phi|g as one 1x1 GEMM, then the re-associated bilinear form."""
+        ci = self.sd[p + ".theta.weight"].shape[0]
+        key = p + ".tpg"
+        parts = [self._plain_part(p + ".theta"), self._plain_part(p + ".phi"), self._plain_part(p + ".g")]
+        tpg = self.e.conv(x, self._pack(key, parts, x.c), 1, 0, "none")
+        if key + ".out" not in self._packed:
+            w = self.sd[p + ".conv_out.weight"].float().reshape(-1, ci)
+            self._packed[key + ".out"] = (self.e.upload(w), self.e.upload(self.sd[p + ".conv_out.bias"].float()))
+        wout, bout = self._packed[key + ".out"]
+        assert wout.shape[0] == x.c, "Non_local_Block conv_out must map back to the input channels"
+        return self.e.nonlocal_(x, tpg, ci, wout, bout, out=x)
+
+    def patch_conv(self, p: str, x: TView, stride: int, with_nonlocal: bool, out: Optional[TView] = None) -> TView:
+        """Patch_Conv / Patch_Conv_NonLocal (Identity_Conv.py:267-387)."""
+        mid = self.conv_out_channels(p + ".feat_patchconv_lt")
+        hh, hw = x.h // 2, x.w // 2               # int(H/2): floor split
+        osz = lambda v: (v + 2 - 3) // stride + 1
+        ht, hb, wl, wr = osz(hh), osz(x.h - hh), osz(hw), osz(x.w - hw)
+        Q = self.e.tensor(x.n, ht + hb, wl + wr, mid)
+        quads = {"lt": (x.window(0, hh, 0, hw), Q.window(0, ht, 0, wl)),
+                 "lb": (x.window(hh, x.h, 0, hw), Q.window(ht, ht + hb, 0, wl)),
+                 "rt": (x.window(0, hh, hw, x.w), Q.window(0, ht, wl, wl + wr)),
+                 "rb": (x.window(hh, x.h, hw, x.w), Q.window(ht, ht + hb, wl, wl + wr))}
+        for name, (src, dst) in quads.items():
+            self.cba("%s.feat_patchconv_%s" % (p, name), src, stride, out=dst)
+            if with_nonlocal:
+                self.nonlocal_block("%s.feat_patchconv_%s_nonlocal" % (p, name), dst)
+        H, W = ht + hb, wl + wr
+        Z = self.e.tensor(x.n, H, W, 2 * mid)
+        lr, tb = Z.channels(0, mid), Z.channels(mid, 2 * mid)
+        self.cba(p + ".feat_patchconv_l", Q.window(0, H, 0, wl), out=lr.window(0, H, 0, wl))
+        self.cba(p + ".feat_patchconv_r", Q.window(0, H, wl, W), out=lr.window(0, H, wl, W))
+        self.cba(p + ".feat_patchconv_t", Q.window(0, ht, 0, W), out=tb.window(0, ht, 0, W))
+        self.cba(p + ".feat_patchconv_b", Q.window(ht, H, 0, W), out=tb.window(ht, H, 0, W))
+        if self.has(p + ".channel_conv.weight"):
+            return self.plain(p + ".channel_conv", Z, out=out)
+        return self.cba(p + ".channel_conv", Z, out=out)
+
+    def identity_conv(self, p: str, x: TView, out: Optional[TView] = None) -> TView:
+        k = self.sd[p + ".conv.weight"].shape[-1]
+        return self.plain(p + ".conv", x, pad=k // 2, out=out)
+
+    # ------------------------------------------------------------------ necks
+    def pafpn(self, p: str, img: torch.Tensor, gl: bool) -> List[TView]:
+        """YOLOPAFPN (base/yolox.py:170-234) or its GL-fusion variant
+        (block/non_local/yolo_patch_nonlocal_plus.py:180-247) when gl=True."""
+        sd = self.sd
+        c3 = self.conv_out_channels(p + ".backbone.dark3.1.conv3")
+        c4 = self.conv_out_channels(p + ".backbone.dark4.1.conv3")
+        n, _, H, W = img.shape
+        h3, w3, h4, w4, h5, w5 = H // 8, W // 8, H // 16, W // 16, H // 32, W // 32
+        e = self.e
+        extra = 1 if gl else 0
+        cat_p4 = e.tensor(n, h4, w4, (2 + extra) * c4)      # [up(P5) | feat2 | (feat1_patch)]
+        cat_p3 = e.tensor(n, h3, w3, 2 * c3)                # [up(P4) | feat1]
+        cat_n3 = e.tensor(n, h4, w4, (2 + extra) * c3)      # [down(P3) | P4 | (feat2_patch)]
+        cat_n4 = e.tensor(n, h5, w5, 2 * c4)                # [down(P4) | P5]
+        f = self.darknet(p + ".backbone", img, {"dark3": cat_p3.channels(c3, 2 * c3),
+                                                 "dark4": cat_p4.channels(c4, 2 * c4)})
+        feat1, feat2, feat3 = f["dark3"], f["dark4"], f["dark5"]
+        if gl:
+            self.patch_conv(p + ".Patch_conv_feat1", feat1, 2, True, out=cat_p4.channels(2 * c4, 3 * c4))
+            self.patch_conv(p + ".Patch_conv_feat2", feat2, 1, False, out=cat_n3.channels(2 * c3, 3 * c3))
+        P5 = self.cba(p + ".lateral_conv0", feat3, out=cat_n4.channels(c4, 2 * c4))
+        e.resample(P5, 2, out=cat_p4.channels(0, c4))
+        t = self.csp(p + ".C3_p4", cat_p4, False)
+        P4 = self.cba(p + ".reduce_conv1", t, out=cat_n3.channels(c3, 2 * c3))
+        e.resample(P4, 2, out=cat_p3.channels(0, c3))
+        P3 = self.csp(p + ".C3_p3", cat_p3, False)
+        if gl:
+            P3 = self.identity_conv(p + ".P3_Identity", P3)
+        self.cba(p + ".bu_conv2", P3, 2, out=cat_n3.channels(0, c3))
+        P4o = self.csp(p + ".C3_n3", cat_n3, False)
+        if gl:
+            P4o = self.identity_conv(p + ".P4_Identity", P4o)
+        self.cba(p + ".bu_conv1", P4o, 2, out=cat_n4.channels(0, c4))
+        P5o = self.csp(p + ".C3_n4", cat_n4, False)
+        if gl:
+            P5o = self.identity_conv(p + ".P5_Identity", P5o)
+        self.features = f
+        return [P3, P4o, P5o]
+
+    # ------------------------------------------------------------------ head
+    def _pred_parts(self, p: str, k: int, f: int, nc: int):
+        """One 1x1 conv over [cls_feat | reg_feat] emitting cat([reg(4), obj(1), cls(nc)])."""
+        w = torch.zeros(5 + nc, 2 * f, 1, 1)
+        b = torch.zeros(5 + nc)
+        w[0:4, f:] = self.sd["%s.reg_preds.%d.weight" % (p, k)]
+        w[4:5, f:] = self.sd["%s.obj_preds.%d.weight" % (p, k)]
+        w[5:, :f] = self.sd["%s.cls_preds.%d.weight" % (p, k)]
+        b[0:4] = self.sd["%s.reg_preds.%d.bias" % (p, k)]
+        b[4:5] = self.sd["%s.obj_preds.%d.bias" % (p, k)]
+        b[5:] = self.sd["%s.cls_preds.%d.bias" % (p, k)]
+        return w, torch.ones(5 + nc), b
+
+    def yolox_head(self, p: str, feats: Sequence[TView]) -> List[TView]:
+        """YOLOXHead.forward (base/yolox.py:46-92) -> per level fp32 [n,H,W,ceil8(5+nc)]."""
+        outs = []
+        for k, x in enumerate(feats):
+            nc = self.sd["%s.cls_preds.%d.weight" % (p, k)].shape[0]
+            f = self.conv_out_channels("%s.stems.%d" % (p, k))
+            s = self.cba("%s.stems.%d" % (p, k), x)
+            T = self.cba(["%s.cls_convs.%d.0" % (p, k), "%s.reg_convs.%d.0" % (p, k)], s)
+            U = self.e.tensor(x.n, x.h, x.w, 2 * f)
+            self.cba("%s.cls_convs.%d.1" % (p, k), T.channels(0, f), out=U.channels(0, f))
+            self.cba("%s.reg_convs.%d.1" % (p, k), T.channels(f, 2 * f), out=U.channels(f, 2 * f))
+            pk = self._pack("%s.preds.%d" % (p, k), [self._pred_parts(p, k, f, nc)], U.c)
+            outs.append(self.e.conv(U, pk, 1, 0, "none", out_dtype=F32))
+            self.num_classes = nc
+        return outs
+
+
+def build_forward(kind: str, eng: Engine, sd, img: torch.Tensor):
+    """Emit the whole raw forward of a `kind` in {'base','gl'} detector for the static input
+    tensor `img` (NCHW fp32 on the device).  Returns (list of fp32 level views, num_classes)."""
+    b = NetBuilder(eng, sd)
+    if kind not in ("base", "gl"):
+        raise ValueError("unknown detector kind %r" % kind)
+    feats = b.pafpn("backbone", img, gl=(kind == "gl"))
+    outs = b.yolox_head("head", feats)
+    return outs, b.num_classes

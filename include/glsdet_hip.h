@@ -1,0 +1,178 @@
+/* glsdet_hip.h -- C ABI of libglsdet_hip.so (MI355X / gfx950 only).
+ *
+ * Drop-in boundary for ONE path of WUTCM-Lab/GLSDet: the detection forward pass
+ * (backbone -> PAFPN / GL-fusion neck -> decoupled head -> decode -> NMS).  The reference
+ * is pure Python; the native kernels it reaches live in torch ATen/cuDNN and
+ * torchvision.  Each entry point below replaces one such call site (reference file:line
+ * given per function, paths relative to the reference root, drone/ = yolox-drone/).
+ *
+ * Conventions
+ *  - plain pointers and sizes only; every pointer is a DEVICE pointer unless it says host.
+ *  - activations are NHWC "views": base pointer + element strides for n/h/w, channels
+ *    contiguous.  A view can therefore be a quadrant, a channel slice of a concat buffer
+ *    or a row band of a larger tensor without any copy.
+ *  - dtype: GLSDET_F16 (fp16 storage, fp32 accumulate) or GLSDET_F32 (exact-f32 MFMA).
+ *  - `stream` is a hipStream_t passed as void*.  All entry points are asynchronous on
+ *    that stream, never synchronise, never allocate, and may be stream-captured.
+ *  - return value: 0 = ok, negative = GLSDET_E_* (nothing was launched); the text of
+ *    the last error of the calling thread is available from glsdet_last_error().
+ *  - every view carries the bounds of the allocation it lives in; each launch checks on
+ *    the host that the extreme addresses it can touch lie inside (a kernel is never
+ *    launched on operands that do not fit).
+ */
+#ifndef GLSDET_HIP_H
+#define GLSDET_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GLSDET_ABI_VERSION 1
+
+enum { GLSDET_F16 = 0, GLSDET_F32 = 1 };
+enum { GLSDET_ACT_NONE = 0, GLSDET_ACT_SILU = 1, GLSDET_ACT_RELU = 2, GLSDET_ACT_LRELU = 3 };
+enum {
+  GLSDET_OK = 0,
+  GLSDET_E_ARG = -1,      /* inconsistent shapes / unsupported parameter            */
+  GLSDET_E_BOUNDS = -2,   /* a view reaches outside its allocation                  */
+  GLSDET_E_ALIGN = -3,    /* pointer / stride not 16-byte compatible                */
+  GLSDET_E_HIP = -4,      /* HIP runtime error (text in glsdet_last_error)          */
+  GLSDET_E_CAPACITY = -5  /* workspace too small                                    */
+};
+
+/* NHWC view.  Strides in ELEMENTS of `dtype`; channel stride is 1. */
+typedef struct glsdet_view {
+  void*   base;            /* address of element (n=0,h=0,w=0,c=0)                    */
+  int64_t sn, sh, sw;      /* element strides                                         */
+  int32_t n, h, w, c;      /* logical extent                                          */
+  int32_t dtype;           /* GLSDET_F16 / GLSDET_F32                                 */
+  int32_t _pad;
+  void*   alloc_lo;        /* [alloc_lo, alloc_hi) = allocation the view lives in     */
+  void*   alloc_hi;
+} glsdet_view;
+
+/* ---------------------------------------------------------------------------------
+ * conv2d + folded BatchNorm + activation (+ residual add)          reference call sites:
+ *   drone/models/base/baseConv.py:15-16   act(bn(conv(x)))            (BaseConv)
+ *   drone/models/base/darknet.py:61-62    y = conv2(conv1(x)) + x     (Bottleneck add)
+ *   drone/models/base/yolox.py:31-44      predictors, Conv2d + bias
+ *   drone/models/block/non_local/Identity_Conv.py:27-84   dense kxk conv + bias
+ *   (mmdet twin: mmcv ConvModule at ufp/mmdet/models/backbones/csp_darknet.py:39-47)
+ * y[n,ho,wo,co] = act( scale[co] * sum_{r,s,ci} x[n,ho*stride-pad+r,wo*stride-pad+s,ci]
+ *                                              * w[co,r,s,ci] + bias[co] ) (+ res[n,ho,wo,co])
+ * Implicit GEMM on MFMA, NHWC, LDS-staged weight and im2col tiles, fused epilogue.
+ *  w      : packed [cout_pad][kpad] elements of x.dtype, k = (r*S + s)*x.c + ci,
+ *           kpad = round_up(R*S*x.c, 64 bytes worth of elements), cout_pad = round_up(y.c, 32),
+ *           zero filled (see glsdet_conv_weight_elems).
+ *  scale/bias : fp32 [cout_pad]  (BN folded: scale = gamma/sqrt(var+eps), bias = beta-mean*scale;
+ *           plain conv: scale = 1, bias = conv bias)
+ *  res    : optional (base == NULL for none), same dtype/extent as y.
+ *  x.c, y.c must be multiples of 8; y.dtype may be F32 while x.dtype is F16 (predictors).
+ */
+typedef struct glsdet_conv_desc {
+  glsdet_view x, y, res;
+  const void*  w;
+  const float* scale;
+  const float* bias;
+  int32_t R, S, stride, pad, act;
+  int32_t tile_hint;       /* 0 = auto; else (co_tile<<16 | px_tile)                  */
+} glsdet_conv_desc;
+
+int     glsdet_conv2d(const glsdet_conv_desc* d, void* stream);
+/* number of ELEMENTS of the packed weight buffer for (cout, R, S, cin, dtype)           */
+int64_t glsdet_conv_weight_elems(int32_t cout, int32_t R, int32_t S, int32_t cin, int32_t dtype);
+int32_t glsdet_conv_kpad(int32_t R, int32_t S, int32_t cin, int32_t dtype);
+int32_t glsdet_conv_cout_pad(int32_t cout);
+
+/* ---------------------------------------------------------------------------------
+ * Focus space-to-depth + layout change      drone/models/base/darknet.py:15-21
+ * img: NCHW fp32 [n,3,H,W] (contiguous)  ->  y: NHWC view [n,H/2,W/2,16]:
+ * channels 0..11 = (TL, BL, TR, BR) x (c0,c1,c2), 12..15 = 0.
+ */
+int glsdet_focus_pack(const float* img, int32_t n, int32_t cin, int32_t H, int32_t W,
+                      const glsdet_view* y, void* stream);
+
+/* max pool k x k, stride 1, pad k/2 (-inf padding)   drone/models/base/darknet.py:29,35 */
+int glsdet_maxpool2d(const glsdet_view* x, const glsdet_view* y, int32_t k, void* stream);
+
+/* nearest-neighbour resample by an integer factor (1 = strided copy, 2 = nn.Upsample(2))
+ * drone/models/base/yolox.py:103,181,198 ; torch.cat is realised by views, not copies.   */
+int glsdet_resample_copy(const glsdet_view* x, const glsdet_view* y, int32_t factor, void* stream);
+
+/* ---------------------------------------------------------------------------------
+ * Non-local block, dot-product form       drone/models/block/non_local/Identity_Conv.py:152-173
+ *   out = x + Wout * ( (theta^T phi / N) g^T ) + bout      (NO softmax, divide by N)
+ * `tpg` holds the three 1x1 projections [theta | phi | g] (each ci channels) of x, produced
+ * by glsdet_conv2d with concatenated weights.  Evaluated in the re-associated order
+ *   G = sum_j phi_j (x) g_j   [ci x ci],  out_i = x_i + (Wout G^T / N) theta_i + bout
+ * which is the same bilinear form at O(N ci^2) instead of O(N^2 ci).
+ *  wout : fp32 [cx][ci] row-major, bout: fp32 [cx];  gram: fp32 workspace [n][ci][ci].
+ */
+int glsdet_nonlocal(const glsdet_view* x, const glsdet_view* tpg, int32_t ci,
+                    const float* wout, const float* bout, float* gram,
+                    const glsdet_view* out, void* stream);
+
+/* ---------------------------------------------------------------------------------
+ * YOLOX decode        drone/models/core/utils_bbox.py:254-306  (mode 0, normalised cxcywh)
+ *                     ufp/mmdet/models/dense_heads/yolox_head.py:298-308 (mode 1, xyxy px)
+ * levels: fp32 views [n,H_l,W_l,>=5+nc] (channel order reg4, obj, cls..).
+ * out: fp32 [n][A][5+nc] contiguous, A = sum H_l*W_l, level-major then row-major.
+ * mode 0: sigmoid(obj,cls); cx=(x+gx)*s/in_w, cy=(y+gy)*s/in_h, w=exp()*s/in_w, h=exp()*s/in_h,
+ *         s = in_h / H_l for both axes (reference quirk, utils_bbox.py:285).
+ * mode 1: sigmoid(obj,cls); x1,y1,x2,y2 in input pixels, s_l = strides[l].
+ */
+int glsdet_yolox_decode(const glsdet_view* levels, int32_t n_levels, int32_t num_classes,
+                        int32_t in_h, int32_t in_w, const int32_t* strides /*host, may be NULL*/,
+                        int32_t mode, float* out, int64_t out_elems, void* stream);
+
+/* ---------------------------------------------------------------------------------
+ * class-max + score threshold + batched (per-class) NMS
+ *   drone/models/core/utils_bbox.py:375-419  (torchvision.ops.boxes.batched_nms)
+ *   ufp/mmdet/models/dense_heads/yolox_head.py:310-322 (mmcv.ops.batched_nms)
+ * pred: fp32 [n][A][5+nc] as produced by glsdet_yolox_decode (either mode; mode 0 boxes
+ *       are converted cxcywh->xyxy first, utils_bbox.py:380-385).
+ * keep score = obj * max_c cls_c >= conf_thres; candidates visited by descending score
+ * (ties: lower anchor index first); a candidate is dropped if an already kept one of the
+ * SAME class has IoU > nms_thres (areas without +1).
+ * dets : fp32 [n][max_det][7] = x1,y1,x2,y2,obj,cls_conf,cls_id in score order
+ * count: int32 [n] kept per image (clamped to max_det; count_raw[n] unclamped)
+ * ws   : workspace of glsdet_nms_workspace_bytes(n, A, max_cand) bytes
+ * status: int32[1], bit0 set if some image had more than max_cand candidates (results for
+ *         that image are then NOT the reference's: callers must treat it as an error).
+ */
+int64_t glsdet_nms_workspace_bytes(int32_t n, int32_t A, int32_t max_cand);
+int glsdet_nms(const float* pred, int32_t n, int32_t A, int32_t num_classes, int32_t box_mode,
+               float conf_thres, float nms_thres, int32_t max_cand, int32_t max_det,
+               float* dets, int32_t* count, int32_t* status,
+               void* ws, int64_t ws_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------
+ * Plan: a recorded sequence of the calls above, replayed without Python in the loop and
+ * capturable into one hipGraph (HIP streams + graphs instead of a tracing compiler).
+ * Recording: glsdet_plan_begin(plan) makes every following entry-point call on this
+ * thread append to the plan instead of launching; glsdet_plan_end() stops recording.
+ */
+typedef struct glsdet_plan glsdet_plan;
+glsdet_plan* glsdet_plan_create(void);
+void    glsdet_plan_destroy(glsdet_plan*);
+int     glsdet_plan_begin(glsdet_plan*);
+int     glsdet_plan_end(glsdet_plan*);
+int32_t glsdet_plan_num_ops(const glsdet_plan*);
+/* kind: 0 conv, 1 focus, 2 maxpool, 3 resample, 4 nonlocal, 5 decode, 6 nms; flops = 2*MACs */
+int     glsdet_plan_op_info(const glsdet_plan*, int32_t i, int32_t* kind, double* flops,
+                            double* bytes, char* name, int32_t name_cap);
+int     glsdet_plan_run(glsdet_plan*, void* stream);               /* eager replay        */
+int     glsdet_plan_capture(glsdet_plan*, void* stream);           /* build the hipGraph  */
+int     glsdet_plan_launch(glsdet_plan*, void* stream);            /* hipGraphLaunch      */
+/* eager replay with a hipEvent pair around every op; ms[i] accumulates milliseconds      */
+int     glsdet_plan_run_timed(glsdet_plan*, void* stream, float* ms /*host, num_ops*/);
+
+const char* glsdet_last_error(void);
+int32_t     glsdet_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GLSDET_HIP_H */

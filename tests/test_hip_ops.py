@@ -1,0 +1,220 @@
+"""GPU parity tests of the individual libglsdet_hip entry points against the CPU oracle
+(fp32 torch).  Every call goes through the C ABI (glsdet_amd._lib via Engine).
+
+Tolerances (stated per north_star: logits 1e-4 / boxes 1e-3 are met by the exact-f32
+mode; the fp16-storage mode is held to fp16 rounding of the same arithmetic):
+  f32 mode : |err| <= 2e-5 * max(1, |ref|_max)   per op
+  f16 mode : |err| <= 4e-3 * max(1, |ref|_max)   per op  (2^-11 relative rounding of
+             inputs/weights/outputs, fp32 accumulation)
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import glsdet_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+TOL = {"f32": 2e-5, "f16": 4e-3}
+
+
+@pytest.fixture(scope="module")
+def engines():
+    from glsdet_amd.engine import Engine
+    return {"f32": Engine("f32"), "f16": Engine("f16")}
+
+
+def _to_view(eng, x_nchw, pad_c=None, embed=None):
+    """Upload NCHW fp32 -> NHWC view of the engine dtype.  embed=(C_total, c0): place the
+    tensor as a channel slice of a wider buffer; a spatial border of 1 is added as well so
+    the view is genuinely strided in n, h and w."""
+    from glsdet_amd.engine import _TORCH_DT, TView
+    n, c, h, w = x_nchw.shape
+    dt = _TORCH_DT[eng.dt]
+    if embed is None:
+        v = eng.tensor(n, h, w, c)
+        t = torch.zeros(n, h, w, v.c)
+        t[..., :c] = x_nchw.permute(0, 2, 3, 1)
+        v.buf.view(dt)[: t.numel()] = t.flatten().to(dt).to(eng.device)
+        return v
+    ctot, c0 = embed
+    big = eng.tensor(n, h + 2, w + 2, ctot)
+    t = torch.full((n, h + 2, w + 2, ctot), 7.0)          # poison around the window
+    t[:, 1:-1, 1:-1, c0:c0 + c] = x_nchw.permute(0, 2, 3, 1)
+    big.buf.view(dt)[: t.numel()] = t.flatten().to(dt).to(eng.device)
+    return big.window(1, h + 1, 1, w + 1).channels(c0, c0 + c)
+
+
+def _cmp(got, want, tol, what=""):
+    got, want = got.cpu().float(), want.float()
+    assert got.shape == want.shape, (got.shape, want.shape)
+    scale = max(1.0, float(want.abs().max()))
+    err = float((got - want).abs().max())
+    assert err <= tol * scale, "%s: max abs err %.3e > %.1e * %.2f" % (what, err, tol, scale)
+
+
+CONV_CASES = [
+    # cin, cout, k, stride, act, H, W, residual, embed
+    (16, 32, 3, 1, "silu", 20, 24, False, False),
+    (16, 32, 3, 2, "relu", 20, 24, False, False),
+    (16, 32, 1, 1, "lrelu", 20, 24, False, False),
+    (16, 32, 1, 2, "none", 21, 23, False, False),
+    (32, 64, 3, 1, "silu", 33, 17, True, False),
+    (64, 128, 3, 1, "silu", 16, 16, True, True),
+    (128, 128, 3, 1, "silu", 12, 20, False, True),
+    (128, 256, 1, 1, "silu", 10, 12, False, False),
+    (256, 192, 1, 1, "none", 9, 11, False, False),
+    (24, 48, 3, 2, "silu", 16, 16, False, False),
+    (16, 16, 5, 1, "none", 20, 24, False, False),
+    (16, 16, 7, 1, "none", 20, 24, False, True),
+    (384, 128, 1, 1, "silu", 8, 8, False, False),
+    (64, 64, 3, 1, "silu", 40, 40, False, False),
+    (8, 8, 3, 1, "none", 5, 5, False, False),
+    (512, 512, 3, 1, "silu", 6, 7, False, False),
+]
+
+
+@pytest.mark.parametrize("mode", ["f32", "f16"])
+@pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: "ci%d_co%d_k%d_s%d_%s_%dx%d%s%s" % (
+    c[0], c[1], c[2], c[3], c[4], c[5], c[6], "_res" if c[7] else "", "_emb" if c[8] else ""))
+def test_conv2d(engines, mode, case):
+    cin, cout, k, stride, act, H, W, use_res, embed = case
+    eng = engines[mode]
+    g = torch.Generator().manual_seed(cin * 1000 + cout + k)
+    x = torch.randn(2, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, k, k, generator=g) / np.sqrt(cin * k * k)
+    scale = torch.rand(cout, generator=g) + 0.5
+    bias = torch.randn(cout, generator=g) * 0.3
+    pad = (k - 1) // 2
+    ref = F.conv2d(x, w, None, stride, pad) * scale[None, :, None, None] + bias[None, :, None, None]
+    ref = O._act(ref, act)
+    res = None
+    if use_res:
+        res = torch.randn(ref.shape, generator=g)
+        ref = ref + res
+    if mode == "f16":   # the kernel sees fp16-rounded operands; compare against the same
+        xr, wr = x.half().float(), w.half().float()
+        ref = O._act(F.conv2d(xr, wr, None, stride, pad) * scale[None, :, None, None] + bias[None, :, None, None], act)
+        if use_res:
+            ref = ref + res.half().float()
+    xv = _to_view(eng, x, embed=(cin + 16, 8) if embed else None)
+    rv = _to_view(eng, res) if use_res else None
+    ov = None
+    if embed:
+        big = eng.tensor(2, ref.shape[2], ref.shape[3], cout + 24)
+        ov = big.channels(16, 16 + cout)
+    pk = eng.pack_conv([(w, scale, bias)], cin)
+    out = eng.conv(xv, pk, stride, pad, act, out=ov, res=rv)
+    torch.cuda.synchronize()
+    _cmp(out.to_nchw(cout), ref, TOL[mode], "conv")
+
+
+@pytest.mark.parametrize("mode", ["f32", "f16"])
+def test_conv_fp32_output_and_fused_cout(engines, mode):
+    """two weight sets fused along Cout; fp32 output view (the predictor path)"""
+    from glsdet_amd._lib import F32
+    eng = engines[mode]
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 64, 10, 12, generator=g)
+    w1 = torch.randn(5, 64, 1, 1, generator=g) / 8
+    w2 = torch.randn(10, 64, 1, 1, generator=g) / 8
+    b1, b2 = torch.randn(5, generator=g), torch.randn(10, generator=g)
+    xr = x.half().float() if mode == "f16" else x
+    c = lambda w: (w.half().float() if mode == "f16" else w)
+    ref = torch.cat((F.conv2d(xr, c(w1), b1), F.conv2d(xr, c(w2), b2)), 1)
+    pk = eng.pack_conv([(w1, torch.ones(5), b1), (w2, torch.ones(10), b2)], 64)
+    out = eng.conv(_to_view(eng, x), pk, 1, 0, "none", out_dtype=F32)
+    torch.cuda.synchronize()
+    assert out.dtype == F32 and out.c == 16
+    _cmp(out.to_nchw(15), ref, TOL["f32"] if mode == "f32" else 1e-3, "pred conv")
+
+
+@pytest.mark.parametrize("mode", ["f32", "f16"])
+def test_focus_pack(engines, mode):
+    eng = engines[mode]
+    x = O.synth_input((2, 3, 32, 40), 3)
+    tl, bl, tr, br = x[..., ::2, ::2], x[..., 1::2, ::2], x[..., ::2, 1::2], x[..., 1::2, 1::2]
+    ref = torch.cat((tl, bl, tr, br), 1)
+    out = eng.focus_pack(x.cuda())
+    torch.cuda.synchronize()
+    assert out.c == 16
+    _cmp(out.to_nchw(12), ref if mode == "f32" else ref.half().float(), 1e-7, "focus")
+    assert float(out.to_nchw()[:, 12:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("mode", ["f32", "f16"])
+@pytest.mark.parametrize("k", [5, 9, 13])
+def test_maxpool(engines, mode, k):
+    eng = engines[mode]
+    x = O.synth_input((2, 32, 20, 24), k)
+    xr = x.half().float() if mode == "f16" else x
+    out = eng.maxpool(_to_view(eng, x, embed=(64, 16)), k)
+    torch.cuda.synchronize()
+    _cmp(out.to_nchw(), F.max_pool2d(xr, k, 1, k // 2), 0.0, "maxpool")
+
+
+@pytest.mark.parametrize("mode", ["f32", "f16"])
+def test_maxpool_chain_equals_big_kernel(engines, mode):
+    eng = engines[mode]
+    x = O.synth_input((1, 8, 11, 7), 1)
+    xr = x.half().float() if mode == "f16" else x
+    a = eng.maxpool(_to_view(eng, x), 5)
+    b = eng.maxpool(a, 5)
+    c = eng.maxpool(b, 5)
+    torch.cuda.synchronize()
+    _cmp(b.to_nchw(), F.max_pool2d(xr, 9, 1, 4), 0.0, "5o5=9")
+    _cmp(c.to_nchw(), F.max_pool2d(xr, 13, 1, 6), 0.0, "5o5o5=13")
+
+
+@pytest.mark.parametrize("mode", ["f32", "f16"])
+@pytest.mark.parametrize("factor", [1, 2])
+def test_resample(engines, mode, factor):
+    eng = engines[mode]
+    x = O.synth_input((2, 24, 9, 11), 2)
+    xr = x.half().float() if mode == "f16" else x
+    big = eng.tensor(2, 9 * factor, 11 * factor, 64)
+    out = eng.resample(_to_view(eng, x, embed=(40, 8)), factor, out=big.channels(24, 48))
+    torch.cuda.synchronize()
+    ref = F.interpolate(xr, scale_factor=factor, mode="nearest") if factor > 1 else xr
+    _cmp(out.to_nchw(), ref, 0.0, "resample")
+    assert float(big.to_nchw()[:, :24].abs().max()) == 0.0 and float(big.to_nchw()[:, 48:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("mode", ["f32", "f16"])
+@pytest.mark.parametrize("shape,ci", [((2, 16, 10, 12), 16), ((2, 32, 5, 7), 16), ((1, 64, 25, 42), 64)])
+def test_nonlocal(engines, mode, shape, ci):
+    from glsdet_amd.nets import NetBuilder
+    eng = engines[mode]
+    cx = shape[1]
+    shapes = {"m.g.weight": (ci, cx, 1, 1), "m.g.bias": (ci,), "m.theta.weight": (ci, cx, 1, 1),
+              "m.theta.bias": (ci,), "m.phi.weight": (ci, cx, 1, 1), "m.phi.bias": (ci,),
+              "m.conv_out.weight": (cx, ci, 1, 1), "m.conv_out.bias": (cx,)}
+    sd = O.synth_state_dict(shapes, 3)
+    x = O.synth_input(shape, 4)
+    ref = O.non_local_block(sd, "m", x)
+    b = NetBuilder(eng, sd)
+    xv = _to_view(eng, x)
+    out = b.nonlocal_block("m", xv)
+    torch.cuda.synchronize()
+    _cmp(out.to_nchw(), ref, 1e-4 if mode == "f32" else 2e-2, "nonlocal")
+
+
+def test_errors_are_reported_not_launched(engines):
+    """bad operands -> negative return code -> GlsdetError (mirrors the reference's
+    assertion / exception style, e.g. yolox_pafpn.py:125)"""
+    from glsdet_amd._lib import GlsdetError
+    eng = engines["f16"]
+    x = eng.tensor(1, 8, 8, 16)
+    w = torch.randn(16, 16, 3, 3)
+    pk = eng.pack_conv([(w, torch.ones(16), torch.zeros(16))], 16)
+    bad_out = eng.tensor(1, 7, 8, 16)
+    with pytest.raises(GlsdetError):
+        eng.conv(x, pk, 1, 1, "silu", out=bad_out)
+    with pytest.raises(GlsdetError):
+        eng.maxpool(x, 4)
+    # a view that leaves its allocation must be refused on the host
+    from glsdet_amd.engine import TView
+    evil = TView(x.buf, 0, 1, 8, 8, 16, 8 * 8 * 16, 8 * 16 * 2, 16, x.dtype)
+    with pytest.raises(GlsdetError):
+        eng.maxpool(evil, 3)
