@@ -57,8 +57,10 @@ struct MMA<float> {
   }
 };
 
+// SiLU: the exact-f32 instantiation uses the accurate expf, the fp16 one the native exp
+template <typename T>
 __device__ __forceinline__ float apply_act(float v, int act) {
-  if (act == GLSDET_ACT_SILU) return v / (1.0f + __expf(-v));
+  if (act == GLSDET_ACT_SILU) return v / (1.0f + (sizeof(T) == 4 ? expf(-v) : __expf(-v)));
   if (act == GLSDET_ACT_RELU) return fmaxf(v, 0.0f);
   if (act == GLSDET_ACT_LRELU) return v > 0.0f ? v : 0.1f * v;
   return v;
@@ -259,7 +261,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
         const int px_l = wpx * WT_PX + j * 32 + l31;
         float v[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = apply_act(acc[i][j][4 * g + e] * sc[e] + bi[e], a.act);
+        for (int e = 0; e < 4; ++e) v[e] = apply_act<T>(acc[i][j][4 * g + e] * sc[e] + bi[e], a.act);
         store4(smem + px_l * ORS + co_l * (int)sizeof(TO), v, (TO*)nullptr);
       }
     }

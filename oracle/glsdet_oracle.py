@@ -398,12 +398,17 @@ def synth_tensor(key: str, shape: Tuple[int, ...], seed: int) -> np.ndarray:
     if leaf == "running_mean":
         return (0.1 * rng.standard_normal(shape)).astype(np.float32)
     if leaf == "weight" and len(shape) == 1:            # BN gamma
-        return rng.uniform(0.8, 1.6, shape).astype(np.float32)
+        return rng.uniform(0.7, 1.3, shape).astype(np.float32)
     if leaf == "bias":
         return (0.2 * rng.standard_normal(shape)).astype(np.float32)
     if leaf == "weight":
         fan_in = int(np.prod(shape[1:]))
-        return (rng.standard_normal(shape) * math.sqrt(1.0 / fan_in)).astype(np.float32)
+        w = rng.standard_normal(shape) * math.sqrt(1.0 / fan_in)
+        if len(shape) == 4 and fan_in > 1:
+            # zero-mean filters: the (always positive) mean of SiLU activations is not
+            # passed on, which keeps random-weight nets from amplifying a DC component
+            w = w - w.mean(axis=(1, 2, 3), keepdims=True)
+        return w.astype(np.float32)
     raise KeyError(key)
 
 
