@@ -1,0 +1,46 @@
+"""Deterministic synthetic weights / inputs (input DATA for tests and bench; no arithmetic
+of the detection path lives here).  Shared by the golden generator, the oracle tests, the
+GPU tests and bench.py so that a state_dict never has to be stored."""
+import math
+from typing import Dict, Tuple
+
+import numpy as np
+import torch
+
+
+def synth_tensor(key: str, shape: Tuple[int, ...], seed: int) -> np.ndarray:
+    """Deterministic parameter filler shared by the golden generator, the oracle tests and
+    the product tests/bench: every tensor depends only on (key, shape, seed), so a
+    state_dict never has to be stored.  BN stats/affine and every bias are perturbed
+    (default init yields near-constant logits)."""
+    import zlib
+    rng = np.random.default_rng([seed, zlib.crc32(key.encode())])
+    leaf = key.rsplit(".", 1)[-1]
+    if leaf == "num_batches_tracked":
+        return np.zeros(shape, np.int64)
+    if leaf == "running_var":
+        return rng.uniform(0.5, 1.5, shape).astype(np.float32)
+    if leaf == "running_mean":
+        return (0.1 * rng.standard_normal(shape)).astype(np.float32)
+    if leaf == "weight" and len(shape) == 1:            # BN gamma
+        return rng.uniform(0.7, 1.3, shape).astype(np.float32)
+    if leaf == "bias":
+        return (0.2 * rng.standard_normal(shape)).astype(np.float32)
+    if leaf == "weight":
+        fan_in = int(np.prod(shape[1:]))
+        w = rng.standard_normal(shape) * math.sqrt(1.0 / fan_in)
+        if len(shape) == 4 and fan_in > 1:
+            # zero-mean filters: the (always positive) mean of SiLU activations is not
+            # passed on, which keeps random-weight nets from amplifying a DC component
+            w = w - w.mean(axis=(1, 2, 3), keepdims=True)
+        return w.astype(np.float32)
+    raise KeyError(key)
+
+
+def synth_state_dict(shapes: Dict[str, Tuple[int, ...]], seed: int) -> Dict[str, torch.Tensor]:
+    return {k: torch.from_numpy(synth_tensor(k, tuple(s), seed)) for k, s in shapes.items()}
+
+
+def synth_input(shape: Tuple[int, ...], seed: int) -> torch.Tensor:
+    rng = np.random.default_rng([seed, 0x1234])
+    return torch.from_numpy(rng.standard_normal(shape).astype(np.float32))
