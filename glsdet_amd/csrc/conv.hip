@@ -15,78 +15,9 @@
 //        identically for A and B, so the dot product is unchanged) -- exact f32.
 // Epilogue: scale/bias/activation in fp32 on the accumulator, tile transposed through LDS,
 // written (and the residual read) as full 16-byte channel chunks per pixel.
-#include "common.h"
+#include "conv_common.h"
 
 namespace glsdet {
-
-struct ConvArgs {
-  const unsigned char* x;   // bytes
-  const unsigned char* w;
-  const float* scale;
-  const float* bias;
-  unsigned char* y;
-  const unsigned char* res;
-  long x_sn, x_sh, x_sw;    // element strides
-  long y_sn, y_sh, y_sw;
-  long r_sn, r_sh, r_sw;
-  int N, H, W, Cin;
-  int Ho, Wo, Cout, cout_pad;
-  int R, S, stride, pad, act;
-  int kreal, kpad;          // elements
-  int M;                    // N*Ho*Wo
-  int n_co_tiles, n_px_tiles;
-};
-
-template <typename T>
-struct MMA;
-template <>
-struct MMA<f16> {
-  static __device__ __forceinline__ void run(const u32x4& a, const u32x4& b, f32x16& c) {
-    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a),
-                                               __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
-  }
-};
-template <>
-struct MMA<float> {
-  static __device__ __forceinline__ void run(const u32x4& a, const u32x4& b, f32x16& c) {
-    const f32x4 af = __builtin_bit_cast(f32x4, a), bf = __builtin_bit_cast(f32x4, b);
-    c = __builtin_amdgcn_mfma_f32_32x32x2f32(af[0], bf[0], c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_32x32x2f32(af[1], bf[1], c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_32x32x2f32(af[2], bf[2], c, 0, 0, 0);
-    c = __builtin_amdgcn_mfma_f32_32x32x2f32(af[3], bf[3], c, 0, 0, 0);
-  }
-};
-
-// SiLU: the exact-f32 instantiation uses the accurate expf, the fp16 one the native exp
-template <typename T>
-__device__ __forceinline__ float apply_act(float v, int act) {
-  if (act == GLSDET_ACT_SILU) return v / (1.0f + (sizeof(T) == 4 ? expf(-v) : __expf(-v)));
-  if (act == GLSDET_ACT_RELU) return fmaxf(v, 0.0f);
-  if (act == GLSDET_ACT_LRELU) return v > 0.0f ? v : 0.1f * v;
-  return v;
-}
-
-// pack 4 fp32 -> 4 TO, stored at p (8 B for f16, 16 B for f32)
-__device__ __forceinline__ void store4(unsigned char* p, const float (&v)[4], f16*) {
-  f16x4 h = {(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
-  *reinterpret_cast<f16x4*>(p) = h;
-}
-__device__ __forceinline__ void store4(unsigned char* p, const float (&v)[4], float*) {
-  f32x4 h = {v[0], v[1], v[2], v[3]};
-  *reinterpret_cast<f32x4*>(p) = h;
-}
-// 16-byte chunk (+)= residual chunk, in fp32
-__device__ __forceinline__ u32x4 add_chunk(u32x4 a, u32x4 b, f16*) {
-  f16x8 x = __builtin_bit_cast(f16x8, a), y = __builtin_bit_cast(f16x8, b);
-#pragma unroll
-  for (int i = 0; i < 8; ++i) x[i] = (f16)((float)x[i] + (float)y[i]);
-  return __builtin_bit_cast(u32x4, x);
-}
-__device__ __forceinline__ u32x4 add_chunk(u32x4 a, u32x4 b, float*) {
-  f32x4 x = __builtin_bit_cast(f32x4, a), y = __builtin_bit_cast(f32x4, b);
-  x += y;
-  return __builtin_bit_cast(u32x4, x);
-}
 
 template <int CO_T, int PX_T, int KB, typename TO>
 constexpr int conv_lds_bytes() {
@@ -398,15 +329,17 @@ extern "C" int glsdet_conv2d(const glsdet_conv_desc* d, void* stream) {
   a.M = (int)M;
   a.n_co_tiles = a.n_px_tiles = 0;
 
-  int co_t, px_t, kb;
-  pick_tile(a, dtype_size(x.dtype), d->tile_hint, &co_t, &px_t, &kb);
   const int xdt = x.dtype, ydt = y.dtype;
-
   OpRecord op;
   op.kind = 0;
   op.flops = 2.0 * (double)M * y.c * a.kreal;
   op.bytes = (double)x.n * x.h * x.w * x.c * dtype_size(xdt) + (double)M * y.c * dtype_size(ydt) * (has_res ? 2 : 1) +
              (double)a.cout_pad * a.kpad * dtype_size(xdt);
+  // tile_hint: 0 auto, 1 force the generic kernel, 2 force the halo kernel, else co<<16|px
+  if (conv_halo_try(a, xdt, ydt, d->tile_hint, &op) == 0) return submit(std::move(op), stream);
+
+  int co_t, px_t, kb;
+  pick_tile(a, dtype_size(x.dtype), d->tile_hint > 2 ? d->tile_hint : 0, &co_t, &px_t, &kb);
   char nm[96];
   snprintf(nm, sizeof nm, "conv_igemm<%s,%s,%dx%d,kb%d> %dx%d s%d cin%d cout%d", xdt ? "f32" : "f16",
            ydt ? "f32" : "f16", co_t, px_t, kb, d->R, d->S, d->stride, x.c, y.c);

@@ -1,0 +1,81 @@
+// Shared by the convolution kernels (conv.hip: generic implicit GEMM; conv_halo.hip:
+// stride-1 kxk with the input patch staged once per channel chunk).
+#pragma once
+#include "common.h"
+
+namespace glsdet {
+
+struct ConvArgs {
+  const unsigned char* x;   // bytes
+  const unsigned char* w;
+  const float* scale;
+  const float* bias;
+  unsigned char* y;
+  const unsigned char* res;
+  long x_sn, x_sh, x_sw;    // element strides
+  long y_sn, y_sh, y_sw;
+  long r_sn, r_sh, r_sw;
+  int N, H, W, Cin;
+  int Ho, Wo, Cout, cout_pad;
+  int R, S, stride, pad, act;
+  int kreal, kpad;          // elements
+  int M;                    // N*Ho*Wo
+  int n_co_tiles, n_px_tiles;
+};
+
+template <typename T>
+struct MMA;
+template <>
+struct MMA<f16> {
+  static __device__ __forceinline__ void run(const u32x4& a, const u32x4& b, f32x16& c) {
+    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a),
+                                               __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  }
+};
+template <>
+struct MMA<float> {
+  static __device__ __forceinline__ void run(const u32x4& a, const u32x4& b, f32x16& c) {
+    const f32x4 af = __builtin_bit_cast(f32x4, a), bf = __builtin_bit_cast(f32x4, b);
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(af[0], bf[0], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(af[1], bf[1], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(af[2], bf[2], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(af[3], bf[3], c, 0, 0, 0);
+  }
+};
+
+// SiLU: the exact-f32 instantiation uses the accurate expf, the fp16 one the native exp
+template <typename T>
+__device__ __forceinline__ float apply_act(float v, int act) {
+  if (act == GLSDET_ACT_SILU) return v / (1.0f + (sizeof(T) == 4 ? expf(-v) : __expf(-v)));
+  if (act == GLSDET_ACT_RELU) return fmaxf(v, 0.0f);
+  if (act == GLSDET_ACT_LRELU) return v > 0.0f ? v : 0.1f * v;
+  return v;
+}
+
+// pack 4 fp32 -> 4 TO, stored at p (8 B for f16, 16 B for f32)
+__device__ __forceinline__ void store4(unsigned char* p, const float (&v)[4], f16*) {
+  f16x4 h = {(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
+  *reinterpret_cast<f16x4*>(p) = h;
+}
+__device__ __forceinline__ void store4(unsigned char* p, const float (&v)[4], float*) {
+  f32x4 h = {v[0], v[1], v[2], v[3]};
+  *reinterpret_cast<f32x4*>(p) = h;
+}
+// 16-byte chunk (+)= residual chunk, in fp32
+__device__ __forceinline__ u32x4 add_chunk(u32x4 a, u32x4 b, f16*) {
+  f16x8 x = __builtin_bit_cast(f16x8, a), y = __builtin_bit_cast(f16x8, b);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) x[i] = (f16)((float)x[i] + (float)y[i]);
+  return __builtin_bit_cast(u32x4, x);
+}
+__device__ __forceinline__ u32x4 add_chunk(u32x4 a, u32x4 b, float*) {
+  f32x4 x = __builtin_bit_cast(f32x4, a), y = __builtin_bit_cast(f32x4, b);
+  x += y;
+  return __builtin_bit_cast(u32x4, x);
+}
+
+
+// host-side dispatch of the halo kernel (conv_halo.hip); returns 1 if it does not apply
+int conv_halo_try(const ConvArgs& a, int xdt, int ydt, int hint, OpRecord* op);
+
+}  // namespace glsdet

@@ -1,0 +1,266 @@
+// Stride-1 k x k convolution (k = 3, 5, 7) with the input PATCH staged once per channel
+// chunk instead of once per tap.
+//
+// The generic implicit-GEMM kernel (conv.hip) re-stages the im2col tile for every filter
+// tap: for a k x k filter every input pixel travels L2 -> registers -> LDS k*k times and the
+// LDS write port, not the MFMA pipe, bounds the loop.  Here a workgroup owns a TH x TW block
+// of output pixels of one image; for each 128-byte channel chunk it stages the
+// (TH+k-1) x (TW+k-1) input patch ONCE (zero filled outside the image) and then walks the
+// k*k taps: the B fragment of a tap is the same LDS image read at a constant offset
+// (r*PW + s) rows further on.  Only the 128 x 128-byte weight tile of the tap is staged per
+// step (double buffered, next tap's loads in flight under the MFMAs).
+//   LDS writes per MFMA drop by ~(1 + 1/(k*k)) / 2, global->LDS input traffic by ~k*k.
+// GEMM orientation, fragment layout, epilogue: identical to conv.hip.
+#include "conv_common.h"
+
+namespace glsdet {
+
+template <int KS, int TH, int TW>
+struct HaloGeom {
+  static constexpr int PH = TH + KS - 1, PW = TW + KS - 1;
+  static constexpr int NP = (PH * PW * 8 + 255) / 256;     // 16-B chunks per thread, one patch
+};
+
+template <typename T, typename TO, int CO_T, int WCO, int KS, int TH, int TW>
+__global__ __launch_bounds__(256) void conv_halo_kernel(const ConvArgs a, const int tiles_x, const int tiles_y) {
+  constexpr int KB = 128, RS = KB + 16;
+  constexpr int VEC = 16 / (int)sizeof(T);
+  constexpr int KE = KB / (int)sizeof(T);          // channels per chunk
+  constexpr int PX_T = TH * TW;
+  constexpr int PH = HaloGeom<KS, TH, TW>::PH, PW = HaloGeom<KS, TH, TW>::PW;
+  constexpr int NP = HaloGeom<KS, TH, TW>::NP;
+  constexpr int NA = (CO_T * 8 + 255) / 256;
+  constexpr int WPX = 4 / WCO;
+  constexpr int WT_CO = CO_T / WCO, WT_PX = PX_T / WPX;
+  constexpr int TM = WT_CO / 32, TN = WT_PX / 32;
+  constexpr int A_BYTES = CO_T * RS;
+  constexpr int PATCH_OFF = 2 * A_BYTES;
+  static_assert(PX_T == 128 && TM >= 1 && TN >= 1, "tile shape");
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+  // tile order: cout tile fastest, then x, y, image; XCD-contiguous like conv.hip
+  int tile;
+  {
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, local = bid >> 3;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+  }
+  const int co0 = (tile % a.n_co_tiles) * CO_T;
+  int rest = tile / a.n_co_tiles;
+  const int tx0 = (rest % tiles_x) * TW;
+  rest /= tiles_x;
+  const int ty0 = (rest % tiles_y) * TH;
+  const int img = rest / tiles_y;
+
+  const int kc = tid & 7, row0 = tid >> 3;         // 8 chunks per 128-B row, 32 rows per pass
+  const unsigned char* wp[NA];
+  bool wok[NA];
+#pragma unroll
+  for (int i = 0; i < NA; ++i) {
+    const int row = row0 + i * 32;
+    wok[i] = row < CO_T && (co0 + row) < a.cout_pad;
+    wp[i] = a.w + ((long)(co0 + row) * a.kpad + kc * VEC) * (long)sizeof(T);
+  }
+  // patch chunk -> input address (without the channel-chunk offset) and validity
+  long poff[NP];
+  bool pvalid[NP];
+  const int pad = KS / 2;
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    const int q = tid + i * 256;
+    const int pp = q >> 3;
+    const int py = pp / PW, px = pp - py * PW;
+    const int hi = ty0 - pad + py, wi = tx0 - pad + px;
+    pvalid[i] = pp < PH * PW && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
+    poff[i] = (long)img * a.x_sn + (long)hi * a.x_sh + (long)wi * a.x_sw + kc * VEC;
+  }
+
+  u32x4 ra[NA], rp[NP];
+  const u32x4 zero4 = {0u, 0u, 0u, 0u};
+  const int nchunks = a.Cin / KE;
+  const int ntaps = KS * KS;
+  const int nsteps = nchunks * ntaps;
+
+  auto load_a = [&](int step) __attribute__((always_inline)) {
+    const int cc = step / ntaps, tap = step - cc * ntaps;
+    const long kbyte = ((long)tap * a.Cin + (long)cc * KE) * (long)sizeof(T);
+#pragma unroll
+    for (int i = 0; i < NA; ++i) ra[i] = wok[i] ? *reinterpret_cast<const u32x4*>(wp[i] + kbyte) : zero4;
+  };
+  auto store_a = [&](int buf) __attribute__((always_inline)) {
+    unsigned char* sa = smem + buf * A_BYTES + kc * 16;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      const int row = row0 + i * 32;
+      if (row < CO_T) *reinterpret_cast<u32x4*>(sa + row * RS) = ra[i];
+    }
+  };
+  auto load_patch = [&](int cc) __attribute__((always_inline)) {
+    const long coff = (long)cc * KE;
+#pragma unroll
+    for (int i = 0; i < NP; ++i)
+      rp[i] = pvalid[i] ? *reinterpret_cast<const u32x4*>(a.x + (poff[i] + coff) * (long)sizeof(T)) : zero4;
+  };
+  auto store_patch = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const int q = tid + i * 256;
+      if (q < PH * PW * 8) *reinterpret_cast<u32x4*>(smem + PATCH_OFF + (q >> 3) * RS + (q & 7) * 16) = rp[i];
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+  const int wco = wave % WCO, wpx = wave / WCO;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int a_off = (wco * WT_CO + l31) * RS + lh * 16;
+  int b_off[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int pix = wpx * WT_PX + j * 32 + l31;
+    const int oy = pix / TW, ox = pix - oy * TW;
+    b_off[j] = PATCH_OFF + (oy * PW + ox) * RS + lh * 16;
+  }
+
+  load_patch(0);
+  load_a(0);
+  store_patch();
+  store_a(0);
+  __syncthreads();
+
+  int tap = 0, cc = 0, tr = 0, ts = 0;             // tap = tr*KS + ts
+  for (int t = 0; t < nsteps; ++t) {
+    const int cur = t & 1;
+    const bool last_tap = tap == ntaps - 1;
+    const bool more = t + 1 < nsteps;
+    if (more) load_a(t + 1);
+    if (last_tap && more) load_patch(cc + 1);
+    const unsigned char* sA = smem + cur * A_BYTES;
+    const int tap_off = (tr * PW + ts) * RS;
+#pragma unroll
+    for (int kk = 0; kk < KB / 32; ++kk) {
+      u32x4 af[TM], bf[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const u32x4*>(sA + a_off + i * 32 * RS + kk * 32);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const u32x4*>(smem + b_off[j] + tap_off + kk * 32);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) MMA<T>::run(af[i], bf[j], acc[i][j]);
+    }
+    if (more) store_a(cur ^ 1);
+    if (last_tap && more) {
+      __syncthreads();                              // every wave is done with the old patch
+      store_patch();
+    }
+    __syncthreads();
+    if (++ts == KS) { ts = 0; ++tr; }
+    if (++tap == ntaps) { tap = 0; tr = 0; ts = 0; ++cc; }
+  }
+
+  // ---- epilogue (as conv.hip; tile-local pixel -> (oy, ox))
+  constexpr int ORS = CO_T * (int)sizeof(TO) + 16;
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int co_l = wco * WT_CO + i * 32 + 8 * g + 4 * lh;
+      f32x4 sc = {0.f, 0.f, 0.f, 0.f}, bi = {0.f, 0.f, 0.f, 0.f};
+      if (co0 + co_l < a.cout_pad) {
+        sc = *reinterpret_cast<const f32x4*>(a.scale + co0 + co_l);
+        bi = *reinterpret_cast<const f32x4*>(a.bias + co0 + co_l);
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int px_l = wpx * WT_PX + j * 32 + l31;
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = apply_act<T>(acc[i][j][4 * g + e] * sc[e] + bi[e], a.act);
+        store4(smem + px_l * ORS + co_l * (int)sizeof(TO), v, (TO*)nullptr);
+      }
+    }
+  }
+  __syncthreads();
+  constexpr int VO = 16 / (int)sizeof(TO);
+  constexpr int OCPR = CO_T / VO;
+  for (int q = tid; q < PX_T * OCPR; q += 256) {
+    const int px_l = q / OCPR, cq = q - px_l * OCPR;
+    const int oy = px_l / TW, ox = px_l - oy * TW;
+    const int ho = ty0 + oy, wo = tx0 + ox, co = co0 + cq * VO;
+    if (ho < a.Ho && wo < a.Wo && co < a.Cout) {
+      u32x4 v = *reinterpret_cast<const u32x4*>(smem + px_l * ORS + cq * 16);
+      if (a.res) {
+        const long ro = (long)img * a.r_sn + (long)ho * a.r_sh + (long)wo * a.r_sw + co;
+        v = add_chunk(v, *reinterpret_cast<const u32x4*>(a.res + ro * (long)sizeof(TO)), (TO*)nullptr);
+      }
+      const long yo = (long)img * a.y_sn + (long)ho * a.y_sh + (long)wo * a.y_sw + co;
+      *reinterpret_cast<u32x4*>(a.y + yo * (long)sizeof(TO)) = v;
+    }
+  }
+}
+
+template <typename T, typename TO, int CO_T, int WCO, int KS, int TH, int TW>
+static int launch_halo(const ConvArgs& a, hipStream_t st) {
+  constexpr int PH = TH + KS - 1, PW = TW + KS - 1;
+  constexpr int stage = 2 * CO_T * 144 + PH * PW * 144;
+  constexpr int epi = TH * TW * (CO_T * (int)sizeof(TO) + 16);
+  constexpr int lds = stage > epi ? stage : epi;
+  auto kern = conv_halo_kernel<T, TO, CO_T, WCO, KS, TH, TW>;
+  static bool attr_set = false;
+  if (!attr_set && lds > 64 * 1024) {
+    GLS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    attr_set = true;
+  }
+  ConvArgs b = a;
+  b.n_co_tiles = (a.Cout + CO_T - 1) / CO_T;
+  const int tiles_x = (a.Wo + TW - 1) / TW, tiles_y = (a.Ho + TH - 1) / TH;
+  const long grid = (long)b.n_co_tiles * tiles_x * tiles_y * a.N;
+  if (grid <= 0 || grid > 0x7fffffffL) GLS_FAIL(GLSDET_E_ARG, "conv2d(halo): grid %ld out of range", grid);
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, st, b, tiles_x, tiles_y);
+  GLS_HIP(hipGetLastError());
+  return 0;
+}
+
+template <typename T, typename TO, int CO_T, int WCO>
+static int halo_by_ks(const ConvArgs& a, hipStream_t st) {
+  switch (a.R) {
+    case 3: return launch_halo<T, TO, CO_T, WCO, 3, 8, 16>(a, st);
+    case 5: return launch_halo<T, TO, CO_T, WCO, 5, 8, 16>(a, st);
+    case 7: return launch_halo<T, TO, CO_T, WCO, 7, 8, 16>(a, st);
+  }
+  GLS_FAIL(GLSDET_E_ARG, "conv2d(halo): unsupported kernel size %d", a.R);
+}
+
+// Returns 1 when the halo kernel does not apply (caller falls back to the generic kernel),
+// 0 when `op` was filled in.
+int conv_halo_try(const ConvArgs& a, int xdt, int ydt, int hint, OpRecord* op) {
+  if (hint == 1) return 1;                                   // hint 1 = force the generic kernel
+  if (a.stride != 1 || a.R != a.S || (a.R != 3 && a.R != 5 && a.R != 7) || a.pad != a.R / 2) return 1;
+  const int es = dtype_size(xdt);
+  if ((a.Cin * es) % 128) return 1;
+  if (xdt != ydt) return 1;
+  // wasted MFMA work on partial tiles: prefer the flat-pixel kernel when it is large
+  const long tiles = (long)((a.Ho + 7) / 8) * ((a.Wo + 15) / 16);
+  const double waste = (double)tiles * 128.0 / ((double)a.Ho * a.Wo);
+  if (hint != 2 && waste > 1.30) return 1;                   // hint 2 = force the halo kernel
+  const int co_t = a.cout_pad <= 64 ? 64 : 128;
+  char nm[96];
+  snprintf(nm, sizeof nm, "conv_halo<%s,%dx8x16> %dx%d s1 cin%d cout%d", xdt ? "f32" : "f16", co_t, a.R, a.S, a.Cin, a.Cout);
+  op->name = nm;
+  op->launch = [a, co_t, xdt](hipStream_t st) -> int {
+    if (xdt == GLSDET_F16) return co_t == 128 ? halo_by_ks<f16, f16, 128, 2>(a, st) : halo_by_ks<f16, f16, 64, 2>(a, st);
+    return co_t == 128 ? halo_by_ks<float, float, 128, 2>(a, st) : halo_by_ks<float, float, 64, 2>(a, st);
+  };
+  return 0;
+}
+
+}  // namespace glsdet

@@ -89,26 +89,29 @@ __global__ __launch_bounds__(256) void resample_kernel(const unsigned char* x, l
 }
 
 // ---------------------------------------------------------------- non-local block
-// G[b][c1][c2] = sum_j phi[b,j,c1] * g[b,j,c2]          (16x16 output block per workgroup)
+// Gp[z][b][c1][c2] = sum_{j in slice z} phi[b,j,c1] * g[b,j,c2]   (16x16 block per workgroup;
+// the position range is split over blockIdx.z for parallelism, partial sums are added in a
+// fixed order by nl_fold_kernel -> deterministic)
 template <typename T>
 __global__ __launch_bounds__(256) void nl_gram_kernel(const unsigned char* tpg, long sn, long sh, long sw, int H, int W,
-                                                      int ci, float* G) {
+                                                      int ci, int jchunk, float* Gp) {
   __shared__ float ph[64][17], gg[64][17];
   const int nb = (ci + 15) / 16;
   const int c1_0 = (blockIdx.x / nb) * 16, c2_0 = (blockIdx.x % nb) * 16;
-  const int b = blockIdx.y;
+  const int b = blockIdx.y, z = blockIdx.z;
   const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
   const int N = H * W;
+  const int jbeg = z * jchunk, jend = min(N, jbeg + jchunk);
   const T* base = reinterpret_cast<const T*>(tpg) + b * sn;
   float acc = 0.f;
-  for (int j0 = 0; j0 < N; j0 += 64) {
+  for (int j0 = jbeg; j0 < jend; j0 += 64) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int idx = threadIdx.x + e * 256;
       const int jj = idx >> 4, cc = idx & 15;
       const int j = j0 + jj;
       float vp = 0.f, vg = 0.f;
-      if (j < N) {
+      if (j < jend) {
         const T* px = base + (j / W) * sh + (j % W) * sw;
         if (c1_0 + cc < ci) vp = (float)px[ci + c1_0 + cc];
         if (c2_0 + cc < ci) vg = (float)px[2 * ci + c2_0 + cc];
@@ -121,20 +124,29 @@ __global__ __launch_bounds__(256) void nl_gram_kernel(const unsigned char* tpg, 
     for (int jj = 0; jj < 64; ++jj) acc += ph[jj][ty] * gg[jj][tx];
     __syncthreads();
   }
-  if (c1_0 + ty < ci && c2_0 + tx < ci) G[((long)b * ci + c1_0 + ty) * ci + c2_0 + tx] = acc;
+  if (c1_0 + ty < ci && c2_0 + tx < ci)
+    Gp[(((long)z * gridDim.y + b) * ci + c1_0 + ty) * ci + c2_0 + tx] = acc;
 }
 
-// P[b][co][c1] = (1/N) sum_c2 Wout[co][c2] * G[b][c1][c2]
-__global__ __launch_bounds__(256) void nl_fold_kernel(const float* __restrict__ G, const float* __restrict__ wout,
-                                                      int ci, int cx, float invN, float* P) {
-  extern __shared__ float wrow[];
-  const int co = blockIdx.x, b = blockIdx.y;
-  for (int c = threadIdx.x; c < ci; c += blockDim.x) wrow[c] = wout[(long)co * ci + c];
+// P[b][co][c1] = (1/N) sum_c2 Wout[co][c2] * (sum_z Gp[z][b][c1][c2]);  one workgroup per image,
+// summed Gram matrix in LDS (row stride ci+1).
+__global__ __launch_bounds__(256) void nl_fold_kernel(const float* __restrict__ Gp, int nsplit, int nimg,
+                                                      const float* __restrict__ wout, int ci, int cx, float invN,
+                                                      float* P) {
+  extern __shared__ float gs[];   // [ci][ci+1]
+  const int b = blockIdx.x, ld = ci + 1;
+  for (int e = threadIdx.x; e < ci * ci; e += 256) {
+    float a = 0.f;
+    for (int z = 0; z < nsplit; ++z) a += Gp[((long)z * nimg + b) * ci * ci + e];
+    gs[(e / ci) * ld + (e % ci)] = a;
+  }
   __syncthreads();
-  for (int c1 = threadIdx.x; c1 < ci; c1 += blockDim.x) {
-    const float* g = G + ((long)b * ci + c1) * ci;
+  for (int e = threadIdx.x; e < cx * ci; e += 256) {
+    const int co = e / ci, c1 = e - co * ci;
+    const float* w = wout + (long)co * ci;
+    const float* g = gs + c1 * ld;
     float acc = 0.f;
-    for (int c2 = 0; c2 < ci; ++c2) acc += wrow[c2] * g[c2];
+    for (int c2 = 0; c2 < ci; ++c2) acc += w[c2] * g[c2];
     P[((long)b * cx + co) * ci + c1] = acc * invN;
   }
 }
@@ -280,7 +292,7 @@ extern "C" int glsdet_nonlocal(const glsdet_view* x, const glsdet_view* tpg, int
   if (tpg->n != x->n || tpg->h != x->h || tpg->w != x->w || ci < 1 || tpg->c < 3 * ci)
     GLS_FAIL(GLSDET_E_ARG, "nonlocal: theta|phi|g view must be [n,h,w,>=3*ci]");
   const int cx = x->c;
-  if ((long)64 * (ci + 1) * 4 > 150 * 1024) GLS_FAIL(GLSDET_E_ARG, "nonlocal: ci=%d too large for the LDS tile", ci);
+  if ((long)ci * (ci + 1) * 4 > 150 * 1024) GLS_FAIL(GLSDET_E_ARG, "nonlocal: ci=%d too large for the LDS tile", ci);
   const glsdet_view vx = *x, vt = *tpg, vo = *out;
   const int N = vx.h * vx.w;
   OpRecord op;
@@ -289,19 +301,23 @@ extern "C" int glsdet_nonlocal(const glsdet_view* x, const glsdet_view* tpg, int
   op.flops = 2.0 * 2.0 * (double)vx.n * N * (double)N * ci;
   op.bytes = (double)vx.n * N * (3.0 * ci + 2.0 * cx) * dtype_size(vx.dtype);
   op.name = "nonlocal(gram+fold+apply)";
-  float* P = gram + (long)vx.n * ci * ci;
+  const int nsplit = N >= 1024 ? 8 : (N >= 256 ? 4 : 1);
+  const int jchunk = (((N + nsplit - 1) / nsplit) + 63) / 64 * 64;
+  float* P = gram + (long)vx.n * 8 * ci * ci;
   op.launch = [=](hipStream_t st) -> int {
     const int nb = (ci + 15) / 16;
-    const dim3 g1(nb * nb, vx.n), g2(cx, vx.n), g3((N + 63) / 64, vx.n);
+    const dim3 g1(nb * nb, vx.n, nsplit), g2(vx.n), g3((N + 63) / 64, vx.n);
+    const size_t lds2 = (size_t)ci * (ci + 1) * 4;
+    if (lds2 > 64 * 1024) GLS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(nl_fold_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
     const size_t lds3 = (size_t)64 * (ci + 1) * 4;
     if (vx.dtype == GLSDET_F16) {
-      hipLaunchKernelGGL(nl_gram_kernel<f16>, g1, dim3(256), 0, st, (const unsigned char*)vt.base, vt.sn, vt.sh, vt.sw, vt.h, vt.w, ci, gram);
-      hipLaunchKernelGGL(nl_fold_kernel, g2, dim3(256), ci * sizeof(float), st, gram, wout, ci, cx, 1.0f / (float)N, P);
+      hipLaunchKernelGGL(nl_gram_kernel<f16>, g1, dim3(256), 0, st, (const unsigned char*)vt.base, vt.sn, vt.sh, vt.sw, vt.h, vt.w, ci, jchunk, gram);
+      hipLaunchKernelGGL(nl_fold_kernel, g2, dim3(256), lds2, st, gram, nsplit, vx.n, wout, ci, cx, 1.0f / (float)N, P);
       if (lds3 > 64 * 1024) GLS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(nl_apply_kernel<f16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3));
       hipLaunchKernelGGL(nl_apply_kernel<f16>, g3, dim3(256), lds3, st, (const unsigned char*)vx.base, vx.sn, vx.sh, vx.sw, (const unsigned char*)vt.base, vt.sn, vt.sh, vt.sw, (unsigned char*)vo.base, vo.sn, vo.sh, vo.sw, vx.h, vx.w, ci, cx, P, bout);
     } else {
-      hipLaunchKernelGGL(nl_gram_kernel<float>, g1, dim3(256), 0, st, (const unsigned char*)vt.base, vt.sn, vt.sh, vt.sw, vt.h, vt.w, ci, gram);
-      hipLaunchKernelGGL(nl_fold_kernel, g2, dim3(256), ci * sizeof(float), st, gram, wout, ci, cx, 1.0f / (float)N, P);
+      hipLaunchKernelGGL(nl_gram_kernel<float>, g1, dim3(256), 0, st, (const unsigned char*)vt.base, vt.sn, vt.sh, vt.sw, vt.h, vt.w, ci, jchunk, gram);
+      hipLaunchKernelGGL(nl_fold_kernel, g2, dim3(256), lds2, st, gram, nsplit, vx.n, wout, ci, cx, 1.0f / (float)N, P);
       if (lds3 > 64 * 1024) GLS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(nl_apply_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3));
       hipLaunchKernelGGL(nl_apply_kernel<float>, g3, dim3(256), lds3, st, (const unsigned char*)vx.base, vx.sn, vx.sh, vx.sw, (const unsigned char*)vt.base, vt.sn, vt.sh, vt.sw, (unsigned char*)vo.base, vo.sn, vo.sh, vo.sw, vx.h, vx.w, ci, cx, P, bout);
     }

@@ -61,7 +61,7 @@ struct NmsWs {
   int* canchor;        // [n][max_cand]
   float4* sbox;        // [n][max_cand]  sorted by score desc
   float4* sext;        // [n][max_cand]
-  unsigned long long* mask;  // [n][max_cand][nw]
+  unsigned long long* mask;  // [n][nw][max_cand]  (column-block major)
 };
 
 // utils_bbox.py:380-385 (cxcywh->xyxy), :398 class max, :403 threshold
@@ -140,76 +140,81 @@ __global__ __launch_bounds__(256) void nms_rank_kernel(int max_cand, NmsWs ws) {
   }
 }
 
-// mask[i][cb] bit t : candidate j = cb*64+t (j > i) has the class of i and IoU(i,j) > thr
-// torchvision nms: inter / (area_i + area_j - inter) > thr, areas without +1.
+// maskT[cb][i] bit t : candidate j = cb*64+t (j > i) has the class of i and IoU(i,j) > thr
+// (torchvision nms: inter / (area_i + area_j - inter) > thr, areas without +1).
+// Stored column-block major so that the scan reads 64 consecutive rows of one column block
+// as one coalesced 512-byte wave load.  The grid is fixed; each 64-thread block walks the
+// (row block, column block) pairs of the ACTUAL candidate count (known only on the device).
 __global__ __launch_bounds__(64) void nms_mask_kernel(int max_cand, int nw, float thr, NmsWs ws) {
-  const int b = blockIdx.z;
+  const int b = blockIdx.y;
   const int n = min(ws.cnt[b], max_cand);
-  const int rb = blockIdx.y, cb = blockIdx.x;
-  if (rb * 64 >= n || cb * 64 >= n || cb < rb) return;
+  const int nb = (n + 63) >> 6;
   __shared__ float4 cbx[64];
   __shared__ float ccls[64];
   const long base = (long)b * max_cand;
   const int t = threadIdx.x;
-  const int j = cb * 64 + t;
-  if (j < n) {
-    cbx[t] = ws.sbox[base + j];
-    ccls[t] = ws.sext[base + j].z;
+  for (int p = blockIdx.x; p < nb * nb; p += gridDim.x) {
+    const int rb = p / nb, cb = p - rb * nb;
+    if (cb < rb) continue;                       // block-uniform
+    const int j = cb * 64 + t;
+    __syncthreads();
+    if (j < n) {
+      cbx[t] = ws.sbox[base + j];
+      ccls[t] = ws.sext[base + j].z;
+    }
+    __syncthreads();
+    const int i = rb * 64 + t;
+    if (i < n) {
+      const float4 a = ws.sbox[base + i];
+      const float acls = ws.sext[base + i].z;
+      const float aarea = (a.z - a.x) * (a.w - a.y);
+      unsigned long long bits = 0;
+      const int lim = min(64, n - cb * 64);
+      for (int k = 0; k < lim; ++k) {
+        const int jj = cb * 64 + k;
+        if (jj <= i || ccls[k] != acls) continue;
+        const float4 c = cbx[k];
+        const float w = fmaxf(0.f, fminf(a.z, c.z) - fmaxf(a.x, c.x));
+        const float h = fmaxf(0.f, fminf(a.w, c.w) - fmaxf(a.y, c.y));
+        const float inter = w * h;
+        const float iou = inter / (aarea + (c.z - c.x) * (c.w - c.y) - inter);
+        if (iou > thr) bits |= 1ull << k;
+      }
+      ws.mask[((long)b * nw + cb) * max_cand + i] = bits;
+    }
   }
-  __syncthreads();
-  const int i = rb * 64 + t;
-  if (i >= n) return;
-  const float4 a = ws.sbox[base + i];
-  const float acls = ws.sext[base + i].z;
-  const float aarea = (a.z - a.x) * (a.w - a.y);
-  unsigned long long bits = 0;
-  const int lim = min(64, n - cb * 64);
-  for (int k = 0; k < lim; ++k) {
-    const int jj = cb * 64 + k;
-    if (jj <= i || ccls[k] != acls) continue;
-    const float4 c = cbx[k];
-    const float w = fmaxf(0.f, fminf(a.z, c.z) - fmaxf(a.x, c.x));
-    const float h = fmaxf(0.f, fminf(a.w, c.w) - fmaxf(a.y, c.y));
-    const float inter = w * h;
-    const float iou = inter / (aarea + (c.z - c.x) * (c.w - c.y) - inter);
-    if (iou > thr) bits |= 1ull << k;
-  }
-  ws.mask[(base + i) * nw + cb] = bits;
 }
 
-// Greedy scan, one workgroup per image.  Wave 0 resolves one 64-candidate word at a time
-// from the word's diagonal block held in registers (no memory latency on the serial
-// chain); every thread then ORs the rows of the newly kept candidates into the removed
-// words it owns (independent loads).
-#define GLS_NMS_WPT 2   // words per thread -> 256*2*64 = 32768 candidates max
+__device__ __forceinline__ unsigned long long wave_or(unsigned long long v) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v |= __shfl_xor(v, o, 64);
+  return v;
+}
+
+// Greedy scan, one 256-thread workgroup per image, removed-bits in LDS.  Per 64-candidate
+// word: wave 0 resolves the word serially from its diagonal block held in registers
+// (shuffles only, no memory latency on the dependent chain), then all four waves OR the
+// rows of the newly kept candidates into the later words (coalesced, independent loads).
+#define GLS_NMS_MAXW 512    // 512 * 64 = 32768 candidates max
 __global__ __launch_bounds__(256) void nms_scan_kernel(int max_cand, int nw, int max_det, NmsWs ws, float* dets,
                                                        int* count) {
-  __shared__ unsigned long long s_removed_cur, s_kept;
+  __shared__ unsigned long long s_removed[GLS_NMS_MAXW];
+  __shared__ unsigned long long s_kept;
   __shared__ int s_base;
   const int b = blockIdx.x;
   const int n = min(ws.cnt[b], max_cand);
   const long base = (long)b * max_cand;
-  const int tid = threadIdx.x;
-  unsigned long long removed[GLS_NMS_WPT];
-#pragma unroll
-  for (int s = 0; s < GLS_NMS_WPT; ++s) removed[s] = 0ull;
-  if (tid == 0) s_base = 0;
-  __syncthreads();
+  const unsigned long long* maskT = ws.mask + (long)b * nw * max_cand;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int words = (n + 63) >> 6;
+  for (int w = tid; w < words; w += 256) s_removed[w] = 0ull;
+  if (tid == 0) s_base = 0;
   for (int wi = 0; wi < words; ++wi) {
-    // owner of word wi publishes its removed bits
-    if ((wi & 255) == tid) {
-      unsigned long long v = 0;
-#pragma unroll
-      for (int s = 0; s < GLS_NMS_WPT; ++s)
-        if ((wi >> 8) == s) v = removed[s];
-      s_removed_cur = v;
-    }
     __syncthreads();
-    if (tid < 64) {
-      const int i = wi * 64 + tid;
-      const unsigned long long diag = (i < n) ? ws.mask[(base + i) * nw + wi] : 0ull;
-      unsigned long long cur = s_removed_cur;
+    if (wave == 0) {
+      const int i = wi * 64 + lane;
+      const unsigned long long diag = (i < n) ? maskT[(long)wi * max_cand + i] : 0ull;
+      unsigned long long cur = s_removed[wi];
       unsigned long long kept = 0;
       const int lim = min(64, n - wi * 64);
       for (int bit = 0; bit < lim; ++bit) {
@@ -219,10 +224,9 @@ __global__ __launch_bounds__(256) void nms_scan_kernel(int max_cand, int nw, int
           cur |= row;
         }
       }
-      // write the kept candidates of this word in score order
       const int pos0 = s_base;
-      if (i < n && ((kept >> tid) & 1ull)) {
-        const int pos = pos0 + __popcll(kept & ((1ull << tid) - 1ull));
+      if (i < n && ((kept >> lane) & 1ull)) {
+        const int pos = pos0 + __popcll(kept & ((1ull << lane) - 1ull));
         if (pos < max_det) {
           const float4 bx = ws.sbox[base + i];
           const float4 ex = ws.sext[base + i];
@@ -230,30 +234,31 @@ __global__ __launch_bounds__(256) void nms_scan_kernel(int max_cand, int nw, int
           d[0] = bx.x; d[1] = bx.y; d[2] = bx.z; d[3] = bx.w; d[4] = ex.x; d[5] = ex.y; d[6] = ex.z;
         }
       }
-      if (tid == 0) {
+      if (lane == 0) {
         s_kept = kept;
         s_base = pos0 + __popcll(kept);
       }
     }
     __syncthreads();
     const unsigned long long kept = s_kept;
-    // OR rows of kept candidates into the later words this thread owns
+    const int i = wi * 64 + lane;
+    const bool mine = i < n && ((kept >> lane) & 1ull);
+    for (int w0 = wi + 1 + wave; w0 < words; w0 += 16) {
+      unsigned long long v[4];
 #pragma unroll
-    for (int s = 0; s < GLS_NMS_WPT; ++s) {
-      const int w = tid + 256 * s;
-      if (w > wi && w < words) {
-        unsigned long long acc = removed[s];
-        unsigned long long k = kept;
-        while (k) {
-          const int bit = __ffsll((long long)k) - 1;
-          k &= k - 1;
-          acc |= ws.mask[(base + wi * 64 + bit) * nw + w];
-        }
-        removed[s] = acc;
+      for (int u = 0; u < 4; ++u) {
+        const int w = w0 + 4 * u;
+        v[u] = (mine && w < words) ? maskT[(long)w * max_cand + i] : 0ull;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int w = w0 + 4 * u;
+        const unsigned long long r = wave_or(v[u]);
+        if (lane == 0 && w < words) s_removed[w] |= r;     // word w is touched by this wave only
       }
     }
-    __syncthreads();
   }
+  __syncthreads();
   if (tid == 0) count[b] = min(s_base, max_det), count[gridDim.x + b] = s_base;
 }
 
@@ -338,7 +343,7 @@ extern "C" int glsdet_nms(const float* pred, int32_t n, int32_t A, int32_t num_c
                           int32_t* count, int32_t* status, void* wsp, int64_t ws_bytes, void* stream) {
   if (!pred || !dets || !count || !status || !wsp) GLS_FAIL(GLSDET_E_ARG, "nms: null argument");
   if (n < 1 || A < 1 || num_classes < 1 || max_cand < 1 || max_det < 1) GLS_FAIL(GLSDET_E_ARG, "nms: bad sizes");
-  if (max_cand > 256 * GLS_NMS_WPT * 64) GLS_FAIL(GLSDET_E_ARG, "nms: max_cand %d > %d", max_cand, 256 * GLS_NMS_WPT * 64);
+  if (max_cand > GLS_NMS_MAXW * 64) GLS_FAIL(GLSDET_E_ARG, "nms: max_cand %d > %d", max_cand, GLS_NMS_MAXW * 64);
   if ((uintptr_t)wsp & 255) GLS_FAIL(GLSDET_E_ALIGN, "nms: workspace must be 256-byte aligned");
   NmsWs ws;
   const long need = nms_layout(n, max_cand, &ws, (char*)wsp);
@@ -357,7 +362,7 @@ extern "C" int glsdet_nms(const float* pred, int32_t n, int32_t A, int32_t num_c
     hipLaunchKernelGGL(nms_filter_kernel, dim3((unsigned)g), dim3(256), 0, st, pred, n, A, num_classes, box_mode,
                        conf_thres, max_cand, ws, status);
     hipLaunchKernelGGL(nms_rank_kernel, dim3((max_cand + 255) / 256, n), dim3(256), 0, st, max_cand, ws);
-    hipLaunchKernelGGL(nms_mask_kernel, dim3(nw, nw, n), dim3(64), 0, st, max_cand, nw, nms_thres, ws);
+    hipLaunchKernelGGL(nms_mask_kernel, dim3(2048, n), dim3(64), 0, st, max_cand, nw, nms_thres, ws);
     hipLaunchKernelGGL(nms_scan_kernel, dim3(n), dim3(256), 0, st, max_cand, nw, max_det, ws, dets, count);
     GLS_HIP(hipGetLastError());
     return 0;

@@ -215,7 +215,7 @@ class Engine:
                   out: Optional[TView] = None) -> TView:
         if out is None:
             out = self.tensor(x.n, x.h, x.w, x.c, x.dtype)
-        ws = self.raw(x.n * (ci * ci + x.c * ci) * 4)
+        ws = self.raw(x.n * (8 * ci * ci + x.c * ci) * 4)   # 8 partial Gram slices + folded P
         check(self.lib.glsdet_nonlocal(C.byref(x.as_c()), C.byref(tpg.as_c()), ci, wout.data_ptr(), bout.data_ptr(),
                                        ws.data_ptr(), C.byref(out.as_c()), _stream_ptr(self.stream)), "nonlocal")
         return out

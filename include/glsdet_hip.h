@@ -108,7 +108,8 @@ int glsdet_resample_copy(const glsdet_view* x, const glsdet_view* y, int32_t fac
  * by glsdet_conv2d with concatenated weights.  Evaluated in the re-associated order
  *   G = sum_j phi_j (x) g_j   [ci x ci],  out_i = x_i + (Wout G^T / N) theta_i + bout
  * which is the same bilinear form at O(N ci^2) instead of O(N^2 ci).
- *  wout : fp32 [cx][ci] row-major, bout: fp32 [cx];  gram: fp32 workspace [n][ci][ci].
+ *  wout : fp32 [cx][ci] row-major, bout: fp32 [cx];
+ *  gram : fp32 workspace of n*(8*ci*ci + cx*ci) floats (partial Gram slices + folded matrix).
  */
 int glsdet_nonlocal(const glsdet_view* x, const glsdet_view* tpg, int32_t ci,
                     const float* wout, const float* bout, float* gram,
@@ -137,7 +138,7 @@ int glsdet_yolox_decode(const glsdet_view* levels, int32_t n_levels, int32_t num
  * (ties: lower anchor index first); a candidate is dropped if an already kept one of the
  * SAME class has IoU > nms_thres (areas without +1).
  * dets : fp32 [n][max_det][7] = x1,y1,x2,y2,obj,cls_conf,cls_id in score order
- * count: int32 [n] kept per image (clamped to max_det; count_raw[n] unclamped)
+ * count: int32 [2n]: [0,n) kept per image clamped to max_det, [n,2n) unclamped
  * ws   : workspace of glsdet_nms_workspace_bytes(n, A, max_cand) bytes
  * status: int32[1], bit0 set if some image had more than max_cand candidates (results for
  *         that image are then NOT the reference's: callers must treat it as an error).

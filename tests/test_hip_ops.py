@@ -218,3 +218,40 @@ def test_errors_are_reported_not_launched(engines):
     evil = TView(x.buf, 0, 1, 8, 8, 16, 8 * 8 * 16, 8 * 16 * 2, 16, x.dtype)
     with pytest.raises(GlsdetError):
         eng.maxpool(evil, 3)
+
+
+HALO_CASES = [
+    # cin, cout, k, H, W, residual, embed
+    (64, 128, 3, 17, 23, True, True),
+    (128, 128, 7, 20, 24, False, False),
+    (128, 64, 5, 9, 33, False, True),
+    (64, 64, 3, 8, 16, False, False),
+    (256, 192, 3, 13, 10, True, False),
+]
+
+
+@pytest.mark.parametrize("mode", ["f32", "f16"])
+@pytest.mark.parametrize("hint", [1, 2], ids=["generic", "halo"])
+@pytest.mark.parametrize("case", HALO_CASES, ids=lambda c: "ci%d_co%d_k%d_%dx%d" % c[:5])
+def test_conv_halo_and_generic_kernels_agree_with_oracle(engines, mode, hint, case):
+    """the stride-1 kxk halo kernel (hint 2) and the generic implicit GEMM (hint 1) on the
+    same problems, incl. partial tiles, strided views, residual"""
+    cin, cout, k, H, W, use_res, embed = case
+    eng = engines[mode]
+    g = torch.Generator().manual_seed(cin + cout + k + H)
+    x = torch.randn(2, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, k, k, generator=g) / np.sqrt(cin * k * k)
+    scale = torch.rand(cout, generator=g) + 0.5
+    bias = torch.randn(cout, generator=g) * 0.3
+    r = (lambda t: t.half().float()) if mode == "f16" else (lambda t: t)
+    ref = O._act(F.conv2d(r(x), r(w), None, 1, k // 2) * scale[None, :, None, None] + bias[None, :, None, None], "silu")
+    res = None
+    if use_res:
+        res = torch.randn(ref.shape, generator=g)
+        ref = ref + r(res)
+    xv = _to_view(eng, x, embed=(cin + 16, 8) if embed else None)
+    rv = _to_view(eng, res) if use_res else None
+    ov = eng.tensor(2, H, W, cout + 24).channels(16, 16 + cout) if embed else None
+    out = eng.conv(xv, eng.pack_conv([(w, scale, bias)], cin), 1, k // 2, "silu", out=ov, res=rv, tile_hint=hint)
+    torch.cuda.synchronize()
+    _cmp(out.to_nchw(cout), ref, TOL[mode], "conv halo/generic")
