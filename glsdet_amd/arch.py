@@ -1,0 +1,123 @@
+"""Architecture tables: the parameter/buffer names and shapes of the reference's detectors,
+generated from (kind, phi, num_classes) so that our modules expose EXACTLY the reference's
+state_dict (a reference checkpoint loads with `load_state_dict`, and vice versa).
+
+Sources: drone/models/base/{baseConv,darknet,yolox}.py,
+drone/models/block/non_local/{Identity_Conv,yolo_patch_nonlocal_plus}.py (key names are
+the attribute paths of those modules; order = their registration order).
+"""
+from __future__ import annotations
+
+from collections import OrderedDict
+from typing import Tuple
+
+# drone/models/base/yolox.py:240-241
+DEPTH = {"nano": 0.33, "tiny": 0.33, "s": 0.33, "m": 0.67, "l": 1.00, "x": 1.33}
+WIDTH = {"nano": 0.25, "tiny": 0.375, "s": 0.50, "m": 0.75, "l": 1.00, "x": 1.25}
+KINDS = ("base", "gl")
+
+
+class _Table(OrderedDict):
+    def conv_bn(self, p: str, cin: int, cout: int, k: int, groups: int = 1):
+        self[p + ".conv.weight"] = (cout, cin // groups, k, k)
+        self[p + ".bn.weight"] = (cout,)
+        self[p + ".bn.bias"] = (cout,)
+        self[p + ".bn.running_mean"] = (cout,)
+        self[p + ".bn.running_var"] = (cout,)
+        self[p + ".bn.num_batches_tracked"] = ()
+
+    def any_conv(self, p: str, cin: int, cout: int, k: int, depthwise: bool):
+        if depthwise:                       # DWConv: depthwise kxk then pointwise 1x1
+            self.conv_bn(p + ".dconv", cin, cin, k, groups=cin)
+            self.conv_bn(p + ".pconv", cin, cout, 1)
+        else:
+            self.conv_bn(p, cin, cout, k)
+
+    def plain(self, p: str, cin: int, cout: int, k: int):
+        self[p + ".weight"] = (cout, cin, k, k)
+        self[p + ".bias"] = (cout,)
+
+    def csp(self, p: str, cin: int, cout: int, n: int, depthwise: bool):
+        hid = int(cout * 0.5)
+        self.conv_bn(p + ".conv1", cin, hid, 1)
+        self.conv_bn(p + ".conv2", cin, hid, 1)
+        self.conv_bn(p + ".conv3", 2 * hid, cout, 1)
+        for i in range(n):
+            self.conv_bn("%s.m.%d.conv1" % (p, i), hid, hid, 1)
+            self.any_conv("%s.m.%d.conv2" % (p, i), hid, hid, 3, depthwise)
+
+    def darknet(self, p: str, dep: float, wid: float, depthwise: bool):
+        base, depth = int(wid * 64), max(round(dep * 3), 1)
+        self.conv_bn(p + ".stem.conv", 12, base, 3)
+        for i, (name, mult, n) in enumerate((("dark2", 2, depth), ("dark3", 4, depth * 3), ("dark4", 8, depth * 3))):
+            cin = base * mult // 2
+            self.any_conv("%s.%s.0" % (p, name), cin, base * mult, 3, depthwise)
+            self.csp("%s.%s.1" % (p, name), base * mult, base * mult, n, depthwise)
+        self.any_conv(p + ".dark5.0", base * 8, base * 16, 3, depthwise)
+        self.conv_bn(p + ".dark5.1.conv1", base * 16, base * 8, 1)
+        self.conv_bn(p + ".dark5.1.conv2", base * 8 * 4, base * 16, 1)
+        self.csp(p + ".dark5.2", base * 16, base * 16, depth, depthwise)
+
+    def nonlocal_block(self, p: str, cin: int, ci: int):
+        self.plain(p + ".g", cin, ci, 1)
+        self.plain(p + ".theta", cin, ci, 1)
+        self.plain(p + ".phi", cin, ci, 1)
+        self.plain(p + ".conv_out", ci, cin, 1)
+
+    def patch_conv(self, p: str, cin: int, cout: int, with_nonlocal: bool):
+        mid = int(0.5 * cin)
+        for q in ("lt", "lb", "rt", "rb"):
+            self.conv_bn("%s.feat_patchconv_%s" % (p, q), cin, mid, 3)
+        if with_nonlocal:
+            for q in ("lt", "lb", "rt", "rb"):
+                self.nonlocal_block("%s.feat_patchconv_%s_nonlocal" % (p, q), mid, mid)
+        for q in ("r", "l", "t", "b"):
+            self.conv_bn("%s.feat_patchconv_%s" % (p, q), mid, mid, 3)
+        self.plain(p + ".channel_conv", 2 * mid, cout, 1)
+
+
+def state_dict_shapes(kind: str, phi: str, num_classes: int) -> "OrderedDict[str, Tuple[int, ...]]":
+    if kind not in KINDS:
+        raise ValueError("kind must be one of %r" % (KINDS,))
+    if phi not in DEPTH:
+        raise KeyError(phi)
+    dep, wid = DEPTH[phi], WIDTH[phi]
+    dw = phi == "nano"
+    c = [int(256 * wid), int(512 * wid), int(1024 * wid)]
+    n = round(3 * dep)
+    t = _Table()
+    b = "backbone"
+    t.darknet(b + ".backbone", dep, wid, dw)
+    t.conv_bn(b + ".lateral_conv0", c[2], c[1], 1)
+    t.csp(b + ".C3_p4", (3 if kind == "gl" else 2) * c[1], c[1], n, dw)
+    t.conv_bn(b + ".reduce_conv1", c[1], c[0], 1)
+    t.csp(b + ".C3_p3", 2 * c[0], c[0], n, dw)
+    if kind == "gl":
+        t.plain(b + ".P3_Identity.conv", c[0], c[0], 7)
+    t.any_conv(b + ".bu_conv2", c[0], c[0], 3, dw)
+    t.csp(b + ".C3_n3", (3 if kind == "gl" else 2) * c[0], c[1], n, dw)
+    if kind == "gl":
+        t.plain(b + ".P4_Identity.conv", c[1], c[1], 5)
+    t.any_conv(b + ".bu_conv1", c[1], c[1], 3, dw)
+    t.csp(b + ".C3_n4", 2 * c[1], c[2], n, dw)
+    if kind == "gl":
+        t.patch_conv(b + ".Patch_conv_feat1", c[0], c[1], True)
+        t.patch_conv(b + ".Patch_conv_feat2", c[1], c[0], False)
+        t.plain(b + ".P5_Identity.conv", c[2], c[2], 3)
+    f = int(256 * wid)
+    h = "head"
+    for i in range(3):        # per level: ModuleList entries are appended level by level
+        pass
+    for name in ("cls_convs", "reg_convs"):
+        for i in range(3):
+            for j in range(2):
+                t.any_conv("%s.%s.%d.%d" % (h, name, i, j), f, f, 3, dw)
+    for i in range(3):
+        t.plain("%s.cls_preds.%d" % (h, i), f, num_classes, 1)
+    for i in range(3):
+        t.plain("%s.reg_preds.%d" % (h, i), f, 4, 1)
+    for i in range(3):
+        t.plain("%s.obj_preds.%d" % (h, i), f, 1, 1)
+    for i in range(3):
+        t.conv_bn("%s.stems.%d" % (h, i), c[i], f, 1)
+    return t

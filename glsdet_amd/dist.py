@@ -40,9 +40,10 @@ def gather_detections(dets: torch.Tensor, count: torch.Tensor, group=None) -> to
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     if world == 1:
         return packed[None]
-    out = torch.empty((world,) + tuple(packed.shape), dtype=packed.dtype, device=packed.device)
-    dist.all_gather_into_tensor(out, packed, group=group)
-    return out
+    n = packed.shape[0]
+    out = torch.empty((world * n,) + tuple(packed.shape[1:]), dtype=packed.dtype, device=packed.device)
+    dist.all_gather_into_tensor(out, packed, group=group)       # rank-major concatenation
+    return out.view((world, n) + tuple(packed.shape[1:]))
 
 
 def unpack_in_dataset_order(gathered: torch.Tensor, num_images: Optional[int] = None) -> List[np.ndarray]:
