@@ -125,6 +125,7 @@ def main():
     ap.add_argument("--max-det", type=int, default=3000)
     ap.add_argument("--nms", type=float, default=0.65)
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-autotune", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--op-table", default="", help="write the per-op timing table (tsv) here")
     args = ap.parse_args()
@@ -150,7 +151,7 @@ def main():
     gen = torch.Generator(device=dev).manual_seed(rank)
     img = torch.randn(bs, 3, H, W, generator=gen, device=dev)
     sd = calibrate_objectness(sd, kind, img, args, dev)          # setup only, not timed
-    det = HipDetector(kind, sd, dtype=args.dtype, device=dev)
+    det = HipDetector(kind, sd, dtype=args.dtype, device=dev, autotune=not args.no_autotune)
     post = dict(conf_thres=args.conf, nms_thres=args.nms, max_det=args.max_det)
     c = det.compile(bs, H, W, post, use_graph=not args.no_graph)
     c.img.copy_(img)                                             # resident in HBM before timing

@@ -260,11 +260,20 @@ static void pick_tile(const ConvArgs& a, int elem, int hint, int* co_t, int* px_
     *co_t = hint >> 16;
     *px_t = hint & 0xffff;
   } else {
-    *co_t = a.cout_pad <= 32 ? 32 : (a.cout_pad <= 64 || ((a.cout_pad % 128) == 64 && a.cout_pad < 256)) ? 64 : 128;
-    *px_t = 128;
-    // few pixels: smaller pixel tile keeps more CUs busy
-    const long tiles = (long)((a.cout_pad + *co_t - 1) / *co_t) * ((a.M + 127) / 128);
-    if (*co_t == 64 && tiles < 256) *px_t = 64;
+    // largest tile that still gives the chip >= 3 workgroups per CU; below that the layer
+    // is latency bound and more, smaller workgroups win over MFMA density
+    struct Cand { int co, px; };
+    const Cand cands[] = {{128, 128}, {64, 128}, {64, 64}, {32, 128}};
+    *co_t = 0;
+    long best_blocks = -1;
+    for (const Cand& c : cands) {
+      if (c.co > 32 && a.cout_pad <= c.co / 2) continue;             // mostly padding
+      if (c.co == 32 && a.cout_pad > 32) continue;
+      if (c.co == 128 && (a.cout_pad % 128) == 64 && a.cout_pad <= 320) continue;   // 192, 320: 64-wide tiles waste nothing
+      const long blocks = (long)((a.cout_pad + c.co - 1) / c.co) * ((a.M + c.px - 1) / c.px);
+      if (blocks >= 768) { *co_t = c.co; *px_t = c.px; break; }
+      if (blocks > best_blocks) { best_blocks = blocks; *co_t = c.co; *px_t = c.px; }
+    }
   }
   *kb = ((long)a.kreal * elem) % 128 == 0 ? 128 : 64;
 }
@@ -283,7 +292,8 @@ extern "C" int64_t glsdet_conv_weight_elems(int32_t cout, int32_t R, int32_t S, 
   return (int64_t)glsdet_conv_cout_pad(cout) * glsdet_conv_kpad(R, S, cin, dtype);
 }
 
-extern "C" int glsdet_conv2d(const glsdet_conv_desc* d, void* stream) {
+// validate the descriptor and build the op for `hint` (d->tile_hint is ignored here)
+static int build_conv_op(const glsdet_conv_desc* d, int hint, OpRecord& op) {
   if (!d) GLS_FAIL(GLSDET_E_ARG, "conv2d: null descriptor");
   const glsdet_view &x = d->x, &y = d->y;
   int rc;
@@ -330,16 +340,17 @@ extern "C" int glsdet_conv2d(const glsdet_conv_desc* d, void* stream) {
   a.n_co_tiles = a.n_px_tiles = 0;
 
   const int xdt = x.dtype, ydt = y.dtype;
-  OpRecord op;
   op.kind = 0;
   op.flops = 2.0 * (double)M * y.c * a.kreal;
   op.bytes = (double)x.n * x.h * x.w * x.c * dtype_size(xdt) + (double)M * y.c * dtype_size(ydt) * (has_res ? 2 : 1) +
              (double)a.cout_pad * a.kpad * dtype_size(xdt);
   // tile_hint: 0 auto, 1 force the generic kernel, 2 force the halo kernel, else co<<16|px
-  if (conv_halo_try(a, xdt, ydt, d->tile_hint, &op) == 0) return submit(std::move(op), stream);
+  if (conv_halo_try(a, xdt, ydt, hint, &op) == 0) return 0;
+  if (hint == 2) GLS_FAIL(GLSDET_E_ARG, "conv2d: the halo kernel does not apply to this problem");
 
   int co_t, px_t, kb;
-  pick_tile(a, dtype_size(x.dtype), d->tile_hint > 2 ? d->tile_hint : 0, &co_t, &px_t, &kb);
+  pick_tile(a, dtype_size(x.dtype), hint > 2 ? hint : 0, &co_t, &px_t, &kb);
+  if (hint > 2 && co_t > 32 && a.cout_pad <= co_t / 2) GLS_FAIL(GLSDET_E_ARG, "conv2d: tile %dx%d is mostly padding here", co_t, px_t);
   char nm[96];
   snprintf(nm, sizeof nm, "conv_igemm<%s,%s,%dx%d,kb%d> %dx%d s%d cin%d cout%d", xdt ? "f32" : "f16",
            ydt ? "f32" : "f16", co_t, px_t, kb, d->R, d->S, d->stride, x.c, y.c);
@@ -349,5 +360,50 @@ extern "C" int glsdet_conv2d(const glsdet_conv_desc* d, void* stream) {
     if (xdt == GLSDET_F16 && ydt == GLSDET_F32) return dispatch_tile<f16, float>(a, co_t, px_t, kb, st);
     return dispatch_tile<float, float>(a, co_t, px_t, kb, st);
   };
+  return 0;
+}
+
+extern "C" int glsdet_conv2d(const glsdet_conv_desc* d, void* stream) {
+  OpRecord op;
+  int rc = build_conv_op(d, d ? d->tile_hint : 0, op);
+  if (rc) return rc;
   return submit(std::move(op), stream);
+}
+
+// Measure every kernel/tile variant that applies to this exact problem on the device (its
+// real buffers; launches immediately, never recorded) and report the fastest hint.  Build-time
+// only: it synchronises.  The conv writes its real output, so callers tune before the first
+// real run (contents are overwritten by it).
+extern "C" int glsdet_conv2d_tune(const glsdet_conv_desc* d, void* stream, int32_t* best_hint, float* best_us) {
+  if (!d || !best_hint) GLS_FAIL(GLSDET_E_ARG, "conv2d_tune: null argument");
+  hipStream_t st = (hipStream_t)stream;
+  const int hints[] = {2, (128 << 16) | 128, (64 << 16) | 128, (64 << 16) | 64, (32 << 16) | 128};
+  hipEvent_t e0, e1;
+  GLS_HIP(hipEventCreate(&e0));
+  GLS_HIP(hipEventCreate(&e1));
+  float best = 1e30f;
+  int bh = 0, any = 0;
+  for (int h : hints) {
+    OpRecord op;
+    if (build_conv_op(d, h, op)) continue;             // variant does not apply
+    if ((h >> 16) == 32 && d->y.c > 32) continue;
+    int rc = op.launch(st);                             // warm (module load, attributes)
+    if (rc) continue;
+    const int reps = 5;
+    (void)hipEventRecord(e0, st);
+    for (int r = 0; r < reps && !rc; ++r) rc = op.launch(st);
+    (void)hipEventRecord(e1, st);
+    if (hipEventSynchronize(e1) != hipSuccess || rc) continue;
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    any = 1;
+    if (ms < best) { best = ms; bh = h; }
+  }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  if (!any) GLS_FAIL(GLSDET_E_ARG, "conv2d_tune: no variant applies");
+  *best_hint = bh;
+  if (best_us) *best_us = best * 1000.f / 5.f;
+  set_error("");
+  return 0;
 }

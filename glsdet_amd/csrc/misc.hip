@@ -12,6 +12,8 @@ template <> struct Vec16<float> { typedef f32x4 type; static constexpr int N = 4
 
 // ---------------------------------------------------------------- Focus space-to-depth
 // drone/models/base/darknet.py:15-21 : cat(TL, BL, TR, BR) on channels.
+// One thread per output pixel: 2*cin float2 loads (a 2x2 patch of every channel), the
+// 16-channel fp16 pixel leaves as two 16-byte stores (fp32: four).
 template <typename T>
 __global__ __launch_bounds__(256) void focus_pack_kernel(const float* __restrict__ img, int n, int cin, int H, int W,
                                                          unsigned char* y, long sn, long sh, long sw, int cy) {
@@ -22,6 +24,30 @@ __global__ __launch_bounds__(256) void focus_pack_kernel(const float* __restrict
     const int ho = (int)((p / Wo) % Ho);
     const int b = (int)(p / ((long)Wo * Ho));
     T* out = reinterpret_cast<T*>(y) + b * sn + ho * sh + wo * sw;
+    if (cin == 3 && cy == 16) {
+      float v[16];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const float* r0 = img + (((long)b * 3 + c) * H + 2 * ho) * W + 2 * wo;
+        const float2 t = *reinterpret_cast<const float2*>(r0);          // TL, TR
+        const float2 u = *reinterpret_cast<const float2*>(r0 + W);      // BL, BR
+        v[0 + c] = t.x;   // TL
+        v[3 + c] = u.x;   // BL
+        v[6 + c] = t.y;   // TR
+        v[9 + c] = u.y;   // BR
+      }
+      v[12] = v[13] = v[14] = v[15] = 0.f;
+      typedef typename Vec16<T>::type V;
+      constexpr int VN = Vec16<T>::N;
+#pragma unroll
+      for (int q = 0; q < 16 / VN; ++q) {
+        V pk;
+#pragma unroll
+        for (int e = 0; e < VN; ++e) pk[e] = (T)v[q * VN + e];
+        reinterpret_cast<V*>(out)[q] = pk;
+      }
+      continue;
+    }
     int ch = 0;
     // patch order: (dy,dx) = (0,0) TL, (1,0) BL, (0,1) TR, (1,1) BR
     for (int patch = 0; patch < 4; ++patch) {
@@ -128,21 +154,23 @@ __global__ __launch_bounds__(256) void nl_gram_kernel(const unsigned char* tpg, 
     Gp[(((long)z * gridDim.y + b) * ci + c1_0 + ty) * ci + c2_0 + tx] = acc;
 }
 
-// P[b][co][c1] = (1/N) sum_c2 Wout[co][c2] * (sum_z Gp[z][b][c1][c2]);  one workgroup per image,
-// summed Gram matrix in LDS (row stride ci+1).
+// P[b][co][c1] = (1/N) sum_c2 Wout[co][c2] * (sum_z Gp[z][b][c1][c2]).  Workgroup = (image,
+// 8 output channels); the summed Gram matrix is rebuilt in LDS (row stride ci+1) per group.
+#define GLS_FOLD_CO 8
 __global__ __launch_bounds__(256) void nl_fold_kernel(const float* __restrict__ Gp, int nsplit, int nimg,
                                                       const float* __restrict__ wout, int ci, int cx, float invN,
                                                       float* P) {
   extern __shared__ float gs[];   // [ci][ci+1]
-  const int b = blockIdx.x, ld = ci + 1;
+  const int b = blockIdx.x, co0 = blockIdx.y * GLS_FOLD_CO, ld = ci + 1;
   for (int e = threadIdx.x; e < ci * ci; e += 256) {
     float a = 0.f;
     for (int z = 0; z < nsplit; ++z) a += Gp[((long)z * nimg + b) * ci * ci + e];
     gs[(e / ci) * ld + (e % ci)] = a;
   }
   __syncthreads();
-  for (int e = threadIdx.x; e < cx * ci; e += 256) {
-    const int co = e / ci, c1 = e - co * ci;
+  for (int e = threadIdx.x; e < GLS_FOLD_CO * ci; e += 256) {
+    const int co = co0 + e / ci, c1 = e % ci;
+    if (co >= cx) continue;
     const float* w = wout + (long)co * ci;
     const float* g = gs + c1 * ld;
     float acc = 0.f;
@@ -179,7 +207,8 @@ __global__ __launch_bounds__(256) void nl_apply_kernel(const unsigned char* x, l
   const long poff_o = b * osn + (j / W) * osh + (j % W) * osw;
   const float* Pb = P + (long)b * cx * ci;
   const float* t = th + jj * ld;
-  for (int co = grp; co < cx; co += 4) {
+  const int co_beg = blockIdx.z * 16, co_end = min(cx, co_beg + 16);
+  for (int co = co_beg + grp; co < co_end; co += 4) {
     const float* pr = Pb + (long)co * ci;
     float acc = 0.f;
     for (int c = 0; c < ci; ++c) acc += t[c] * pr[c];
@@ -306,7 +335,7 @@ extern "C" int glsdet_nonlocal(const glsdet_view* x, const glsdet_view* tpg, int
   float* P = gram + (long)vx.n * 8 * ci * ci;
   op.launch = [=](hipStream_t st) -> int {
     const int nb = (ci + 15) / 16;
-    const dim3 g1(nb * nb, vx.n, nsplit), g2(vx.n), g3((N + 63) / 64, vx.n);
+    const dim3 g1(nb * nb, vx.n, nsplit), g2(vx.n, (cx + GLS_FOLD_CO - 1) / GLS_FOLD_CO), g3((N + 63) / 64, vx.n, (cx + 15) / 16);
     const size_t lds2 = (size_t)ci * (ci + 1) * 4;
     if (lds2 > 64 * 1024) GLS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(nl_fold_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
     const size_t lds3 = (size_t)64 * (ci + 1) * 4;

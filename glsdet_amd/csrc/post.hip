@@ -59,6 +59,7 @@ struct NmsWs {
   float4* cbox;        // [n][max_cand]  candidate boxes (xyxy), arrival order
   float4* cext;        // [n][max_cand]  obj, cls_conf, cls_id, score
   int* canchor;        // [n][max_cand]
+  float* cscore;       // [n][max_cand]  score again, contiguous (scalar-cache friendly)
   float4* sbox;        // [n][max_cand]  sorted by score desc
   float4* sext;        // [n][max_cand]
   unsigned long long* mask;  // [n][nw][max_cand]  (column-block major)
@@ -69,7 +70,10 @@ __global__ __launch_bounds__(256) void nms_filter_kernel(const float* __restrict
                                                          float thr, int max_cand, NmsWs ws, int* status) {
   const long total = (long)n * A;
   const int F = 5 + nc;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+  const long padded = (total + 63) / 64 * 64;     // whole waves stay in the loop (ballots below)
+  for (long i0 = (long)blockIdx.x * blockDim.x + threadIdx.x; i0 < padded; i0 += (long)gridDim.x * blockDim.x) {
+    const bool live = i0 < total;
+    const long i = live ? i0 : total - 1;
     const int b = (int)(i / A), an = (int)(i - (long)b * A);
     const float* p = pred + i * F;
     float best = p[5];
@@ -80,8 +84,22 @@ __global__ __launch_bounds__(256) void nms_filter_kernel(const float* __restrict
     }
     const float obj = p[4];
     const float score = obj * best;
-    if (score >= thr) {
-      const int slot = atomicAdd(&ws.cnt[b], 1);
+    const bool pass = live && score >= thr;
+    // one atomic per wave and image instead of one per candidate: lanes of this wave that
+    // pass and belong to the same image as the first passing lane share one fetch-add.
+    unsigned long long todo = __ballot(pass);
+    int slot = -1;
+    while (todo) {
+      const int leader = __ffsll((long long)todo) - 1;
+      const int lb = __shfl(b, leader, 64);
+      const unsigned long long grp = __ballot(pass && b == lb) & todo;
+      int base0 = 0;
+      if ((int)(threadIdx.x & 63) == leader) base0 = atomicAdd(&ws.cnt[lb], __popcll(grp));
+      base0 = __shfl(base0, leader, 64);
+      if (pass && b == lb) slot = base0 + __popcll(grp & ((1ull << (threadIdx.x & 63)) - 1ull));
+      todo &= ~grp;
+    }
+    if (pass) {
       if (slot < max_cand) {
         float4 bx;
         if (box_mode == 0) {
@@ -93,6 +111,7 @@ __global__ __launch_bounds__(256) void nms_filter_kernel(const float* __restrict
         ws.cbox[o] = bx;
         ws.cext[o] = make_float4(obj, best, (float)arg, score);
         ws.canchor[o] = an;
+        ws.cscore[o] = score;
       } else {
         atomicOr(status, 1);
       }
@@ -101,42 +120,40 @@ __global__ __launch_bounds__(256) void nms_filter_kernel(const float* __restrict
 }
 
 // rank sort: position of candidate i = #candidates that come before it in
-// (score desc, anchor asc) order.  Exact, deterministic, O(n^2) compares from LDS.
+// (score desc, anchor asc) order.  Exact and deterministic.  Workgroup = 64 candidates x 4
+// slices of the comparison range; tiles of 256 (score, anchor) pairs go through LDS and each
+// thread scans its quarter of the tile (broadcast reads), partial ranks are summed in LDS.
 __global__ __launch_bounds__(256) void nms_rank_kernel(int max_cand, NmsWs ws) {
   __shared__ float s_score[256];
   __shared__ int s_anchor[256];
+  __shared__ int s_part[256];
   const int b = blockIdx.y;
   const int n = min(ws.cnt[b], max_cand);
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (blockIdx.x * 256 >= n) return;
+  if (blockIdx.x * 64 >= n) return;
+  const int il = threadIdx.x & 63, slice = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + il;
   const long base = (long)b * max_cand;
-  float my = 0.f;
-  int mya = 0;
-  float4 bx, ex;
-  if (i < n) {
-    bx = ws.cbox[base + i];
-    ex = ws.cext[base + i];
-    my = ex.w;
-    mya = ws.canchor[base + i];
-  }
+  const float my = i < n ? ws.cscore[base + i] : 0.f;
+  const int mya = i < n ? ws.canchor[base + i] : 0;
   int rank = 0;
   for (int j0 = 0; j0 < n; j0 += 256) {
     const int j = j0 + threadIdx.x;
-    if (j < n) {
-      s_score[threadIdx.x] = ws.cext[base + j].w;
-      s_anchor[threadIdx.x] = ws.canchor[base + j];
-    }
+    s_score[threadIdx.x] = j < n ? ws.cscore[base + j] : -INFINITY;     // never ranks before anything
+    s_anchor[threadIdx.x] = j < n ? ws.canchor[base + j] : 0x7fffffff;
     __syncthreads();
-    const int lim = min(256, n - j0);
-    for (int t = 0; t < lim; ++t) {
+#pragma unroll 16
+    for (int t = slice * 64; t < slice * 64 + 64; ++t) {
       const float s = s_score[t];
       rank += (s > my) || (s == my && s_anchor[t] < mya);
     }
     __syncthreads();
   }
-  if (i < n) {
-    ws.sbox[base + rank] = bx;
-    ws.sext[base + rank] = ex;
+  s_part[threadIdx.x] = rank;
+  __syncthreads();
+  if (slice == 0 && i < n) {
+    rank = s_part[il] + s_part[64 + il] + s_part[128 + il] + s_part[192 + il];
+    ws.sbox[base + rank] = ws.cbox[base + i];
+    ws.sext[base + rank] = ws.cext[base + i];
   }
 }
 
@@ -191,75 +208,79 @@ __device__ __forceinline__ unsigned long long wave_or(unsigned long long v) {
   return v;
 }
 
-// Greedy scan, one 256-thread workgroup per image, removed-bits in LDS.  Per 64-candidate
-// word: wave 0 resolves the word serially from its diagonal block held in registers
-// (shuffles only, no memory latency on the dependent chain), then all four waves OR the
-// rows of the newly kept candidates into the later words (coalesced, independent loads).
+// Greedy NMS as a fixed point.  keep[i] = !exists j<i : keep[j] && M[j][i] has exactly one
+// solution (induction on i) and it is what the sequential scan produces.  Iterating
+//     keep'[i] = !OR_{j<i} (keep[j] & M[j][i])
+// from keep = all-ones fixes at least one more prefix element per sweep and usually
+// converges in a handful of sweeps (longest suppression chain), each sweep fully parallel:
+// wave w ORs the coalesced column block maskT[w][0 .. 64(w+1)) under the current keep bits.
+// A sweep that changes nothing proves the fixed point.  One 1024-thread workgroup / image.
 #define GLS_NMS_MAXW 512    // 512 * 64 = 32768 candidates max
-__global__ __launch_bounds__(256) void nms_scan_kernel(int max_cand, int nw, int max_det, NmsWs ws, float* dets,
-                                                       int* count) {
-  __shared__ unsigned long long s_removed[GLS_NMS_MAXW];
-  __shared__ unsigned long long s_kept;
-  __shared__ int s_base;
+__global__ __launch_bounds__(1024) void nms_scan_kernel(int max_cand, int nw, int max_det, NmsWs ws, float* dets,
+                                                        int* count) {
+  __shared__ unsigned long long s_keep[GLS_NMS_MAXW];
+  __shared__ int s_prefix[GLS_NMS_MAXW];
+  __shared__ int s_changed;
   const int b = blockIdx.x;
   const int n = min(ws.cnt[b], max_cand);
   const long base = (long)b * max_cand;
   const unsigned long long* maskT = ws.mask + (long)b * nw * max_cand;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
   const int words = (n + 63) >> 6;
-  for (int w = tid; w < words; w += 256) s_removed[w] = 0ull;
-  if (tid == 0) s_base = 0;
-  for (int wi = 0; wi < words; ++wi) {
+  for (int w = tid; w < words; w += blockDim.x) {
+    const int valid = min(64, n - w * 64);
+    s_keep[w] = valid == 64 ? ~0ull : ((1ull << valid) - 1ull);
+  }
+  __syncthreads();
+  for (int sweep = 0; sweep <= n; ++sweep) {
+    if (tid == 0) s_changed = 0;
     __syncthreads();
-    if (wave == 0) {
-      const int i = wi * 64 + lane;
-      const unsigned long long diag = (i < n) ? maskT[(long)wi * max_cand + i] : 0ull;
-      unsigned long long cur = s_removed[wi];
-      unsigned long long kept = 0;
-      const int lim = min(64, n - wi * 64);
-      for (int bit = 0; bit < lim; ++bit) {
-        const unsigned long long row = __shfl(diag, bit, 64);   // wave-uniform source lane
-        if (!((cur >> bit) & 1ull)) {
-          kept |= 1ull << bit;
-          cur |= row;
-        }
+    for (int w = wave; w < words; w += nwaves) {
+      unsigned long long acc = 0ull;
+      const int jend = min(n, (w + 1) * 64);
+      const unsigned long long* col = maskT + (long)w * max_cand;
+      for (int j = lane; j < jend; j += 64) {
+        const unsigned long long kw = s_keep[j >> 6];
+        if ((kw >> (j & 63)) & 1ull) acc |= col[j];
       }
-      const int pos0 = s_base;
-      if (i < n && ((kept >> lane) & 1ull)) {
-        const int pos = pos0 + __popcll(kept & ((1ull << lane) - 1ull));
-        if (pos < max_det) {
-          const float4 bx = ws.sbox[base + i];
-          const float4 ex = ws.sext[base + i];
-          float* d = dets + ((long)b * max_det + pos) * 7;
-          d[0] = bx.x; d[1] = bx.y; d[2] = bx.z; d[3] = bx.w; d[4] = ex.x; d[5] = ex.y; d[6] = ex.z;
-        }
-      }
+      acc = wave_or(acc);
       if (lane == 0) {
-        s_kept = kept;
-        s_base = pos0 + __popcll(kept);
+        const int valid = min(64, n - w * 64);
+        const unsigned long long all = valid == 64 ? ~0ull : ((1ull << valid) - 1ull);
+        const unsigned long long nk = all & ~acc;
+        if (nk != s_keep[w]) {
+          s_keep[w] = nk;              // in place: any mix of old/new inputs has the same fixed point
+          s_changed = 1;
+        }
       }
     }
     __syncthreads();
-    const unsigned long long kept = s_kept;
-    const int i = wi * 64 + lane;
-    const bool mine = i < n && ((kept >> lane) & 1ull);
-    for (int w0 = wi + 1 + wave; w0 < words; w0 += 16) {
-      unsigned long long v[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int w = w0 + 4 * u;
-        v[u] = (mine && w < words) ? maskT[(long)w * max_cand + i] : 0ull;
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int w = w0 + 4 * u;
-        const unsigned long long r = wave_or(v[u]);
-        if (lane == 0 && w < words) s_removed[w] |= r;     // word w is touched by this wave only
+    if (!s_changed) break;
+    __syncthreads();
+  }
+  // exclusive prefix of kept counts per word, then every candidate writes its own row
+  if (tid == 0) {
+    int run = 0;
+    for (int w = 0; w < words; ++w) {
+      s_prefix[w] = run;
+      run += __popcll(s_keep[w]);
+    }
+    count[b] = min(run, max_det);
+    count[gridDim.x + b] = run;
+  }
+  __syncthreads();
+  for (int i = tid; i < n; i += blockDim.x) {
+    const unsigned long long kw = s_keep[i >> 6];
+    if ((kw >> (i & 63)) & 1ull) {
+      const int pos = s_prefix[i >> 6] + __popcll(kw & ((1ull << (i & 63)) - 1ull));
+      if (pos < max_det) {
+        const float4 bx = ws.sbox[base + i];
+        const float4 ex = ws.sext[base + i];
+        float* d = dets + ((long)b * max_det + pos) * 7;
+        d[0] = bx.x; d[1] = bx.y; d[2] = bx.z; d[3] = bx.w; d[4] = ex.x; d[5] = ex.y; d[6] = ex.z;
       }
     }
   }
-  __syncthreads();
-  if (tid == 0) count[b] = min(s_base, max_det), count[gridDim.x + b] = s_base;
 }
 
 static inline long align_up(long v, long a) { return (v + a - 1) / a * a; }
@@ -271,6 +292,7 @@ static long nms_layout(int n, int max_cand, NmsWs* ws, char* base) {
   const long o_cbox = take((long)n * max_cand * 16);
   const long o_cext = take((long)n * max_cand * 16);
   const long o_can = take((long)n * max_cand * 4);
+  const long o_csc = take((long)n * max_cand * 4);
   const long o_sbox = take((long)n * max_cand * 16);
   const long o_sext = take((long)n * max_cand * 16);
   const long o_mask = take((long)n * max_cand * nw * 8);
@@ -279,6 +301,7 @@ static long nms_layout(int n, int max_cand, NmsWs* ws, char* base) {
     ws->cbox = (float4*)(base + o_cbox);
     ws->cext = (float4*)(base + o_cext);
     ws->canchor = (int*)(base + o_can);
+    ws->cscore = (float*)(base + o_csc);
     ws->sbox = (float4*)(base + o_sbox);
     ws->sext = (float4*)(base + o_sext);
     ws->mask = (unsigned long long*)(base + o_mask);
@@ -361,9 +384,9 @@ extern "C" int glsdet_nms(const float* pred, int32_t n, int32_t A, int32_t num_c
     if (g > 8192) g = 8192;
     hipLaunchKernelGGL(nms_filter_kernel, dim3((unsigned)g), dim3(256), 0, st, pred, n, A, num_classes, box_mode,
                        conf_thres, max_cand, ws, status);
-    hipLaunchKernelGGL(nms_rank_kernel, dim3((max_cand + 255) / 256, n), dim3(256), 0, st, max_cand, ws);
+    hipLaunchKernelGGL(nms_rank_kernel, dim3((max_cand + 63) / 64, n), dim3(256), 0, st, max_cand, ws);
     hipLaunchKernelGGL(nms_mask_kernel, dim3(2048, n), dim3(64), 0, st, max_cand, nw, nms_thres, ws);
-    hipLaunchKernelGGL(nms_scan_kernel, dim3(n), dim3(256), 0, st, max_cand, nw, max_det, ws, dets, count);
+    hipLaunchKernelGGL(nms_scan_kernel, dim3(n), dim3(1024), 0, st, max_cand, nw, max_det, ws, dets, count);
     GLS_HIP(hipGetLastError());
     return 0;
   };

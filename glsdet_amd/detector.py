@@ -20,8 +20,8 @@ class HipDetector:
     reference's key names (drone flavour).  dtype 'f16' (fp16 storage / fp32 accumulate,
     the benchmarked mode) or 'f32' (exact-f32 MFMA, the strict-parity mode)."""
 
-    def __init__(self, kind: str, state_dict, dtype: str = "f16", device: str = "cuda:0"):
-        self.kind, self.dtype, self.device = kind, dtype, device
+    def __init__(self, kind: str, state_dict, dtype: str = "f16", device: str = "cuda:0", autotune: bool = False):
+        self.kind, self.dtype, self.device, self.autotune = kind, dtype, device, autotune
         self.sd = {k: v.detach().cpu() for k, v in state_dict.items()}
         self._compiled: Dict[Tuple, _Compiled] = {}
         self.num_classes = None
@@ -34,7 +34,7 @@ class HipDetector:
             return self._compiled[key]
         if H % 32 or W % 32:
             raise ValueError("input H and W must be multiples of 32 (got %dx%d)" % (H, W))
-        eng = Engine(self.dtype, self.device)
+        eng = Engine(self.dtype, self.device, autotune=self.autotune)
         c = _Compiled()
         c.eng = eng
         c.img = torch.zeros(n, 3, H, W, dtype=torch.float32, device=eng.device)

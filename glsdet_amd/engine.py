@@ -122,7 +122,7 @@ def _stream_ptr(stream) -> int:
 class Engine:
     """Owns device buffers and packed weights; emits ops (eagerly or into a Plan)."""
 
-    def __init__(self, dtype: str = "f16", device: str = "cuda:0"):
+    def __init__(self, dtype: str = "f16", device: str = "cuda:0", autotune: bool = False):
         self.lib = _lib.load()          # raises GlsdetLibraryError when the .so is missing
         if not torch.cuda.is_available():
             raise _lib.GlsdetLibraryError("glsdet_amd needs an MI355X visible to PyTorch-ROCm (no CPU fallback)")
@@ -132,6 +132,8 @@ class Engine:
         self.stream = None              # None -> torch current stream at call time
         self._keep: List[torch.Tensor] = []
         self.alloc_bytes = 0
+        self.autotune = autotune        # measure kernel/tile variants per conv problem at build time
+        self._tuned = {}
 
     # ---- memory
     def raw(self, nbytes: int) -> torch.Tensor:
@@ -186,6 +188,15 @@ class Engine:
         d.res = res.as_c() if res is not None else View()
         d.w, d.scale, d.bias = wdev.data_ptr(), sdev.data_ptr(), bdev.data_ptr()
         d.R, d.S, d.stride, d.pad, d.act, d.tile_hint = R, S, stride, pad, ACT[act], tile_hint
+        if self.autotune and tile_hint == 0:
+            key = (x.n, x.h, x.w, x.c, x.sn, x.sh, x.sw, out.c, out.sn, out.sh, out.sw, R, S, stride, pad,
+                   res is not None, out.dtype)
+            if key not in self._tuned:
+                best, us = C.c_int32(0), C.c_float(0)
+                check(self.lib.glsdet_conv2d_tune(C.byref(d), _stream_ptr(self.stream), C.byref(best), C.byref(us)),
+                      "conv2d_tune")
+                self._tuned[key] = best.value
+            d.tile_hint = self._tuned[key]
         check(self.lib.glsdet_conv2d(C.byref(d), _stream_ptr(self.stream)), "conv2d")
         return out
 

@@ -81,6 +81,10 @@ typedef struct glsdet_conv_desc {
 } glsdet_conv_desc;
 
 int     glsdet_conv2d(const glsdet_conv_desc* d, void* stream);
+/* Build-time autotune: times every kernel / tile variant that applies to exactly this
+ * problem on the device (synchronises; never recorded into a plan) and returns the fastest
+ * tile_hint.  The output view is written with the conv result. */
+int     glsdet_conv2d_tune(const glsdet_conv_desc* d, void* stream, int32_t* best_hint, float* best_us);
 /* number of ELEMENTS of the packed weight buffer for (cout, R, S, cin, dtype)           */
 int64_t glsdet_conv_weight_elems(int32_t cout, int32_t R, int32_t S, int32_t cin, int32_t dtype);
 int32_t glsdet_conv_kpad(int32_t R, int32_t S, int32_t cin, int32_t dtype);

@@ -250,3 +250,15 @@ def test_missing_library_fails_loudly(monkeypatch):
     monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libglsdet_hip.so")
     with pytest.raises(_lib.GlsdetLibraryError):
         _lib.load()
+
+
+def test_autotuned_plan_matches_default(golden, shapes):
+    """build-time autotune only picks among equivalent kernels: same logits (bitwise for the
+    fp16 path up to accumulation order -> compare with the per-op fp16 tolerance)"""
+    from glsdet_amd.detector import HipDetector
+    meta, sd, x, outs, _ = model_case(golden, shapes, "gl_tiny_seed0")
+    a = HipDetector("gl", sd, dtype="f32").forward_raw(x.cuda())
+    det = HipDetector("gl", sd, dtype="f32", autotune=True)
+    b = det.forward_raw(x.cuda())
+    for p, q in zip(a, b):
+        assert float((p - q).abs().max()) <= 2e-4 * max(1.0, float(p.abs().max()))
