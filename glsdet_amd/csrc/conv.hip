@@ -60,17 +60,18 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
   const int row0 = tid / CPR;                    // row of chunk i is row0 + i*(256/CPR)
   constexpr int ROWS_PER_PASS = 256 / CPR;
 
-  // ---- weight tile: per-thread row pointers
-  const unsigned char* wp[NA];
-  bool wok[NA];
+  const auto xrs = gls_make_rsrc(a.x_lo, a.x_bytes);
+  const auto wrs = gls_make_rsrc(a.w, a.w_bytes);
+  // ---- weight tile: per-thread row offsets (bytes; GLS_OOB rows read as zeros)
+  unsigned wp[NA];
 #pragma unroll
   for (int i = 0; i < NA; ++i) {
     const int row = row0 + i * ROWS_PER_PASS;
-    wok[i] = row < CO_T && (co0 + row) < a.cout_pad;
-    wp[i] = a.w + ((long)(co0 + row) * a.kpad + kc * VEC) * (long)sizeof(T);
+    const bool ok = row < CO_T && (co0 + row) < a.cout_pad;
+    wp[i] = ok ? (unsigned)(((co0 + row) * a.kpad + kc * VEC) * (int)sizeof(T)) : GLS_OOB;
   }
   // ---- im2col tile: per-thread pixel coordinates
-  long boff[NB];
+  int boff[NB];                                  // element offset from the view base (may be < 0)
   int hi0[NB], wi0[NB];
   bool pok[NB];
   const int HoWo = a.Ho * a.Wo;
@@ -84,7 +85,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
     const int ho = rem / a.Wo, wo = rem - ho * a.Wo;
     hi0[i] = ho * a.stride - a.pad;
     wi0[i] = wo * a.stride - a.pad;
-    boff[i] = (long)n * a.x_sn + (long)hi0[i] * a.x_sh + (long)wi0[i] * a.x_sw;
+    boff[i] = (int)((long)n * a.x_sn + (long)hi0[i] * a.x_sh + (long)wi0[i] * a.x_sw);
   }
   // ---- k position of this thread's chunk column: (r, s, c)
   int kr, ks, kci;
@@ -97,20 +98,19 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
   }
 
   u32x4 ra[NA], rb[NB];
-  const u32x4 zero4 = {0u, 0u, 0u, 0u};
   const int nsteps = (a.kreal + KE - 1) / KE;
 
   auto gload = [&](int step) __attribute__((always_inline)) {
-    const long kbyte = (long)step * KB;
+    const unsigned kbyte = (unsigned)step * KB;
 #pragma unroll
-    for (int i = 0; i < NA; ++i) ra[i] = wok[i] ? *reinterpret_cast<const u32x4*>(wp[i] + kbyte) : zero4;
+    for (int i = 0; i < NA; ++i) ra[i] = gls_buf_load16(wrs, wp[i] + kbyte);   // GLS_OOB + small stays out of range
     const bool kval = kr < a.R;
-    const long tapoff = (long)kr * a.x_sh + (long)ks * a.x_sw + kci;
+    const int tapoff = (int)((long)kr * a.x_sh + (long)ks * a.x_sw) + kci;
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
       const int hi = hi0[i] + kr, wi = wi0[i] + ks;
       const bool ok = pok[i] && kval && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
-      rb[i] = ok ? *reinterpret_cast<const u32x4*>(a.x + (boff[i] + tapoff) * (long)sizeof(T)) : zero4;
+      rb[i] = gls_buf_load16(xrs, ok ? a.x_off + (unsigned)((boff[i] + tapoff) * (int)sizeof(T)) : GLS_OOB);
     }
     kci += KE;
     while (kci >= a.Cin) {
@@ -338,6 +338,14 @@ static int build_conv_op(const glsdet_conv_desc* d, int hint, OpRecord& op) {
   a.kpad = glsdet_conv_kpad(d->R, d->S, x.c, x.dtype);
   a.M = (int)M;
   a.n_co_tiles = a.n_px_tiles = 0;
+  const int64_t xalloc = (const char*)x.alloc_hi - (const char*)x.alloc_lo;
+  const int64_t wbytes = (int64_t)a.cout_pad * a.kpad * dtype_size(x.dtype);
+  if (xalloc >= 0x7fffffffLL || wbytes >= 0x7fffffffLL)
+    GLS_FAIL(GLSDET_E_ARG, "conv2d: operand allocation of %lld bytes exceeds the 2 GiB descriptor range", (long long)xalloc);
+  a.x_lo = (const unsigned char*)x.alloc_lo;
+  a.x_off = (unsigned)((const char*)x.base - (const char*)x.alloc_lo);
+  a.x_bytes = (unsigned)xalloc;
+  a.w_bytes = (unsigned)wbytes;
 
   const int xdt = x.dtype, ydt = y.dtype;
   op.kind = 0;
@@ -349,8 +357,8 @@ static int build_conv_op(const glsdet_conv_desc* d, int hint, OpRecord& op) {
   if (hint == 2) GLS_FAIL(GLSDET_E_ARG, "conv2d: the halo kernel does not apply to this problem");
 
   int co_t, px_t, kb;
-  pick_tile(a, dtype_size(x.dtype), hint > 2 ? hint : 0, &co_t, &px_t, &kb);
-  if (hint > 2 && co_t > 32 && a.cout_pad <= co_t / 2) GLS_FAIL(GLSDET_E_ARG, "conv2d: tile %dx%d is mostly padding here", co_t, px_t);
+  pick_tile(a, dtype_size(x.dtype), hint > 3 ? hint : 0, &co_t, &px_t, &kb);
+  if (hint > 3 && co_t > 32 && a.cout_pad <= co_t / 2) GLS_FAIL(GLSDET_E_ARG, "conv2d: tile %dx%d is mostly padding here", co_t, px_t);
   char nm[96];
   snprintf(nm, sizeof nm, "conv_igemm<%s,%s,%dx%d,kb%d> %dx%d s%d cin%d cout%d", xdt ? "f32" : "f16",
            ydt ? "f32" : "f16", co_t, px_t, kb, d->R, d->S, d->stride, x.c, y.c);

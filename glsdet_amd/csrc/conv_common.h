@@ -21,7 +21,23 @@ struct ConvArgs {
   int kreal, kpad;          // elements
   int M;                    // N*Ho*Wo
   int n_co_tiles, n_px_tiles;
+  // buffer-descriptor view of the two streamed operands (bounds-checked loads: an offset
+  // >= *_bytes returns zeros, which is how padding / tails are zero-filled branch-free)
+  const unsigned char* x_lo;  // start of the allocation x lives in
+  unsigned x_off;             // byte offset of element (0,0,0,0) from x_lo
+  unsigned x_bytes;           // size of that allocation
+  unsigned w_bytes;           // size of the packed weight buffer (from w)
 };
+
+#define GLS_OOB 0x80000000u   // any offset >= 2^31 is out of range of every descriptor we build
+typedef __attribute__((address_space(8))) void* gls_rsrc_t;
+__device__ __forceinline__ auto gls_make_rsrc(const void* base, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), (short)0, (int)bytes, 0x00020000);
+}
+template <typename R>
+__device__ __forceinline__ u32x4 gls_buf_load16(R rsrc, unsigned voff) {
+  return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)voff, 0, 0));
+}
 
 template <typename T>
 struct MMA;

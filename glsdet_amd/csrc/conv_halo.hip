@@ -15,6 +15,20 @@
 
 namespace glsdet {
 
+
+// Tile-local pixel index -> (oy, ox) for 16-pixel-wide tiles.  A 32-lane MFMA subtile covers
+// two pixel rows; the patch row pitch PW is not a multiple of 16 rows-of-144-bytes, so the
+// second row would land on the bank sets of the first (2-way conflicts on ds_read_b128).
+// Rotating the odd rows' pixel order by (-PW mod 16) makes lane m of either row hit bank
+// set m: conflict free at no LDS cost.  The epilogue decodes with the same function.
+template <int PW>
+__device__ __forceinline__ void pix_to_xy16(int pix, int& oy, int& ox) {
+  oy = pix >> 4;
+  const int m = pix & 15;
+  constexpr int ROT = (16 - (PW & 15)) & 15;
+  ox = (oy & 1) ? ((m + ROT) & 15) : m;
+}
+
 template <int KS, int TH, int TW>
 struct HaloGeom {
   static constexpr int PH = TH + KS - 1, PW = TW + KS - 1;
@@ -35,7 +49,7 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const ConvArgs a, const 
   constexpr int TM = WT_CO / 32, TN = WT_PX / 32;
   constexpr int A_BYTES = CO_T * RS;
   constexpr int PATCH_OFF = 2 * A_BYTES;
-  static_assert(PX_T == 128 && TM >= 1 && TN >= 1, "tile shape");
+  static_assert(PX_T == 128 && TW == 16 && TM >= 1 && TN >= 1, "tile shape");
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -55,17 +69,17 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const ConvArgs a, const 
   const int img = rest / tiles_y;
 
   const int kc = tid & 7, row0 = tid >> 3;         // 8 chunks per 128-B row, 32 rows per pass
-  const unsigned char* wp[NA];
-  bool wok[NA];
+  const auto xrs = gls_make_rsrc(a.x_lo, a.x_bytes);
+  const auto wrs = gls_make_rsrc(a.w, a.w_bytes);
+  unsigned wp[NA];                                  // byte offsets; GLS_OOB rows read as zeros
 #pragma unroll
   for (int i = 0; i < NA; ++i) {
     const int row = row0 + i * 32;
-    wok[i] = row < CO_T && (co0 + row) < a.cout_pad;
-    wp[i] = a.w + ((long)(co0 + row) * a.kpad + kc * VEC) * (long)sizeof(T);
+    const bool ok = row < CO_T && (co0 + row) < a.cout_pad;
+    wp[i] = ok ? (unsigned)(((co0 + row) * a.kpad + kc * VEC) * (int)sizeof(T)) : GLS_OOB;
   }
-  // patch chunk -> input address (without the channel-chunk offset) and validity
-  long poff[NP];
-  bool pvalid[NP];
+  // patch chunk -> input byte offset (without the channel-chunk offset); outside the image: GLS_OOB
+  unsigned poff[NP];
   const int pad = KS / 2;
 #pragma unroll
   for (int i = 0; i < NP; ++i) {
@@ -73,21 +87,21 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const ConvArgs a, const 
     const int pp = q >> 3;
     const int py = pp / PW, px = pp - py * PW;
     const int hi = ty0 - pad + py, wi = tx0 - pad + px;
-    pvalid[i] = pp < PH * PW && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
-    poff[i] = (long)img * a.x_sn + (long)hi * a.x_sh + (long)wi * a.x_sw + kc * VEC;
+    const bool ok = pp < PH * PW && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
+    poff[i] = ok ? a.x_off + (unsigned)(((long)img * a.x_sn + (long)hi * a.x_sh + (long)wi * a.x_sw + kc * VEC) * (long)sizeof(T))
+                 : GLS_OOB;
   }
 
   u32x4 ra[NA], rp[NP];
-  const u32x4 zero4 = {0u, 0u, 0u, 0u};
   const int nchunks = a.Cin / KE;
   const int ntaps = KS * KS;
   const int nsteps = nchunks * ntaps;
 
   auto load_a = [&](int step) __attribute__((always_inline)) {
     const int cc = step / ntaps, tap = step - cc * ntaps;
-    const long kbyte = ((long)tap * a.Cin + (long)cc * KE) * (long)sizeof(T);
+    const unsigned kbyte = (unsigned)((tap * a.Cin + cc * KE) * (int)sizeof(T));
 #pragma unroll
-    for (int i = 0; i < NA; ++i) ra[i] = wok[i] ? *reinterpret_cast<const u32x4*>(wp[i] + kbyte) : zero4;
+    for (int i = 0; i < NA; ++i) ra[i] = gls_buf_load16(wrs, wp[i] + kbyte);
   };
   auto store_a = [&](int buf) __attribute__((always_inline)) {
     unsigned char* sa = smem + buf * A_BYTES + kc * 16;
@@ -98,10 +112,9 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const ConvArgs a, const 
     }
   };
   auto load_patch = [&](int cc) __attribute__((always_inline)) {
-    const long coff = (long)cc * KE;
+    const unsigned coff = (unsigned)(cc * KE * (int)sizeof(T));
 #pragma unroll
-    for (int i = 0; i < NP; ++i)
-      rp[i] = pvalid[i] ? *reinterpret_cast<const u32x4*>(a.x + (poff[i] + coff) * (long)sizeof(T)) : zero4;
+    for (int i = 0; i < NP; ++i) rp[i] = gls_buf_load16(xrs, poff[i] + coff);
   };
   auto store_patch = [&]() __attribute__((always_inline)) {
 #pragma unroll
@@ -126,7 +139,8 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const ConvArgs a, const 
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int pix = wpx * WT_PX + j * 32 + l31;
-    const int oy = pix / TW, ox = pix - oy * TW;
+    int oy, ox;
+    pix_to_xy16<PW>(pix, oy, ox);
     b_off[j] = PATCH_OFF + (oy * PW + ox) * RS + lh * 16;
   }
 
@@ -194,7 +208,8 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const ConvArgs a, const 
   constexpr int OCPR = CO_T / VO;
   for (int q = tid; q < PX_T * OCPR; q += 256) {
     const int px_l = q / OCPR, cq = q - px_l * OCPR;
-    const int oy = px_l / TW, ox = px_l - oy * TW;
+    int oy, ox;
+    pix_to_xy16<PW>(px_l, oy, ox);
     const int ho = ty0 + oy, wo = tx0 + ox, co = co0 + cq * VO;
     if (ho < a.Ho && wo < a.Wo && co < a.Cout) {
       u32x4 v = *reinterpret_cast<const u32x4*>(smem + px_l * ORS + cq * 16);
@@ -243,7 +258,7 @@ static int halo_by_ks(const ConvArgs& a, hipStream_t st) {
 // Returns 1 when the halo kernel does not apply (caller falls back to the generic kernel),
 // 0 when `op` was filled in.
 int conv_halo_try(const ConvArgs& a, int xdt, int ydt, int hint, OpRecord* op) {
-  if (hint == 1) return 1;                                   // hint 1 = force the generic kernel
+  if (hint == 1 || hint > 3) return 1;                       // hint 1 / explicit tile = the generic kernel
   if (a.stride != 1 || a.R != a.S || (a.R != 3 && a.R != 5 && a.R != 7) || a.pad != a.R / 2) return 1;
   const int es = dtype_size(xdt);
   if ((a.Cin * es) % 128) return 1;
@@ -264,3 +279,4 @@ int conv_halo_try(const ConvArgs& a, int xdt, int ydt, int hint, OpRecord* op) {
 }
 
 }  // namespace glsdet
+

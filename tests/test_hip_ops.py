@@ -227,6 +227,7 @@ HALO_CASES = [
     (128, 64, 5, 9, 33, False, True),
     (64, 64, 3, 8, 16, False, False),
     (256, 192, 3, 13, 10, True, False),
+    (128, 256, 3, 40, 37, False, False),
 ]
 
 

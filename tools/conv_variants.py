@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""GPU micro-benchmark: every conv kernel variant (tile_hint) on the layer shapes that
+dominate the bench workload.  Prints microseconds and algorithmic TFLOP/s per variant."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+
+from glsdet_amd._lib import GlsdetError
+from glsdet_amd.engine import Engine
+
+SHAPES = [  # n, H, W, cin, cout, k, stride
+    (8, 100, 168, 128, 128, 7, 1),
+    (8, 50, 84, 256, 256, 5, 1),
+    (8, 100, 168, 128, 128, 3, 1),
+    (8, 100, 168, 128, 256, 3, 1),
+    (8, 50, 84, 128, 128, 3, 1),
+    (8, 25, 42, 512, 512, 3, 1),
+    (8, 100, 168, 64, 64, 3, 1),
+    (8, 100, 168, 128, 128, 1, 1),
+    (8, 200, 336, 64, 64, 1, 1),
+    (8, 50, 84, 256, 256, 1, 1),
+    (8, 50, 84, 768, 256, 1, 1),
+    (8, 200, 336, 64, 128, 3, 2),
+    (8, 400, 672, 16, 32, 3, 1),
+]
+HINTS = {"auto": 0, "halo": 2, "g128x128": (128 << 16) | 128, "g64x128": (64 << 16) | 128,
+         "g64x64": (64 << 16) | 64, "g32x128": (32 << 16) | 128}
+
+
+def main():
+    only = sys.argv[1:] or None
+    eng = Engine("f16")
+    for (n, H, W, cin, cout, k, s) in SHAPES:
+        x = eng.tensor(n, H, W, cin)
+        x.buf.view(torch.float16).normal_()
+        w = torch.randn(cout, cin, k, k) / (cin * k * k) ** 0.5
+        pk = eng.pack_conv([(w, torch.ones(cout), torch.zeros(cout))], cin)
+        flops = 2.0 * n * ((H + s - 1) // s) * ((W + s - 1) // s) * cout * cin * k * k
+        line = "%dx%d s%d %4d->%4d @%dx%d: " % (k, k, s, cin, cout, H, W)
+        for name, h in HINTS.items():
+            if only and name not in only:
+                continue
+            try:
+                out = eng.conv(x, pk, s, (k - 1) // 2, "silu", tile_hint=h)
+            except GlsdetError:
+                continue
+            for _ in range(3):
+                eng.conv(x, pk, s, (k - 1) // 2, "silu", out=out, tile_hint=h)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            reps = 20
+            for _ in range(reps):
+                eng.conv(x, pk, s, (k - 1) // 2, "silu", out=out, tile_hint=h)
+            e1.record()
+            torch.cuda.synchronize()
+            us = e0.elapsed_time(e1) * 1e3 / reps
+            line += "%s %.1fus %.0fTF | " % (name, us, flops / us / 1e6)
+        print(line, flush=True)
+
+
+if __name__ == "__main__":
+    main()
