@@ -204,14 +204,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
     const int px_l = q / OCPR, cc = q - px_l * OCPR;
     const int p = px0 + px_l, co = co0 + cc * VO;
     if (p < a.M && co < a.Cout) {
-      const int n = p / HoWo, rem = p - n * HoWo;
-      const int ho = rem / a.Wo, wo = rem - ho * a.Wo;
       u32x4 v = *reinterpret_cast<const u32x4*>(smem + px_l * ORS + cc * 16);
       if (a.res) {
-        const long ro = (long)n * a.r_sn + (long)ho * a.r_sh + (long)wo * a.r_sw + co;
+        const long ro = gls_pix_off(p, HoWo, a.Wo, a.r_sn, a.r_sh, a.r_sw, a.r_lin) + co;
         v = add_chunk(v, *reinterpret_cast<const u32x4*>(a.res + ro * (long)sizeof(TO)), (TO*)nullptr);
       }
-      const long yo = (long)n * a.y_sn + (long)ho * a.y_sh + (long)wo * a.y_sw + co;
+      const long yo = gls_pix_off(p, HoWo, a.Wo, a.y_sn, a.y_sh, a.y_sw, a.y_lin) + co;
       *reinterpret_cast<u32x4*>(a.y + yo * (long)sizeof(TO)) = v;
     }
   }
@@ -346,13 +344,19 @@ static int build_conv_op(const glsdet_conv_desc* d, int hint, OpRecord& op) {
   a.x_off = (unsigned)((const char*)x.base - (const char*)x.alloc_lo);
   a.x_bytes = (unsigned)xalloc;
   a.w_bytes = (unsigned)wbytes;
+  a.y_lin = (y.sh == (int64_t)Wo * y.sw && y.sn == (int64_t)Ho * y.sh) ? 1 : 0;
+  a.r_lin = (has_res && d->res.sh == (int64_t)Wo * d->res.sw && d->res.sn == (int64_t)Ho * d->res.sh) ? 1 : 0;
 
   const int xdt = x.dtype, ydt = y.dtype;
   op.kind = 0;
   op.flops = 2.0 * (double)M * y.c * a.kreal;
   op.bytes = (double)x.n * x.h * x.w * x.c * dtype_size(xdt) + (double)M * y.c * dtype_size(ydt) * (has_res ? 2 : 1) +
              (double)a.cout_pad * a.kpad * dtype_size(xdt);
-  // tile_hint: 0 auto, 1 force the generic kernel, 2 force the halo kernel, else co<<16|px
+  // tile_hint: 0 auto, 1 generic kernel, 2 halo kernel, 3 weight-stationary 1x1 kernel, else co<<16|px (generic)
+  if (hint == 3) {
+    if (conv1x1_ws_try(a, xdt, ydt, &op) == 0) return 0;
+    GLS_FAIL(GLSDET_E_ARG, "conv2d: the weight-stationary 1x1 kernel does not apply to this problem");
+  }
   if (conv_halo_try(a, xdt, ydt, hint, &op) == 0) return 0;
   if (hint == 2) GLS_FAIL(GLSDET_E_ARG, "conv2d: the halo kernel does not apply to this problem");
 
@@ -385,7 +389,7 @@ extern "C" int glsdet_conv2d(const glsdet_conv_desc* d, void* stream) {
 extern "C" int glsdet_conv2d_tune(const glsdet_conv_desc* d, void* stream, int32_t* best_hint, float* best_us) {
   if (!d || !best_hint) GLS_FAIL(GLSDET_E_ARG, "conv2d_tune: null argument");
   hipStream_t st = (hipStream_t)stream;
-  const int hints[] = {2, (128 << 16) | 128, (64 << 16) | 128, (64 << 16) | 64, (32 << 16) | 128};
+  const int hints[] = {2, 3, (128 << 16) | 128, (64 << 16) | 128, (64 << 16) | 64, (32 << 16) | 128};
   hipEvent_t e0, e1;
   GLS_HIP(hipEventCreate(&e0));
   GLS_HIP(hipEventCreate(&e1));

@@ -27,7 +27,18 @@ struct ConvArgs {
   unsigned x_off;             // byte offset of element (0,0,0,0) from x_lo
   unsigned x_bytes;           // size of that allocation
   unsigned w_bytes;           // size of the packed weight buffer (from w)
+  // 1 when offset(pixel p) == p * s_w for the view (dense NHWC or a channel slice of one):
+  // the epilogue then needs no integer division per 16-byte chunk
+  int y_lin, r_lin;
 };
+
+// element offset of flat output pixel p (+ channel) in a view
+__device__ __forceinline__ long gls_pix_off(int p, int HoWo, int Wo, long sn, long sh, long sw, int lin) {
+  if (lin) return (long)p * sw;
+  const int n = p / HoWo, rem = p - n * HoWo;
+  const int ho = rem / Wo, wo = rem - ho * Wo;
+  return (long)n * sn + (long)ho * sh + (long)wo * sw;
+}
 
 #define GLS_OOB 0x80000000u   // any offset >= 2^31 is out of range of every descriptor we build
 typedef __attribute__((address_space(8))) void* gls_rsrc_t;
@@ -62,7 +73,10 @@ struct MMA<float> {
 // SiLU: the exact-f32 instantiation uses the accurate expf, the fp16 one the native exp
 template <typename T>
 __device__ __forceinline__ float apply_act(float v, int act) {
-  if (act == GLSDET_ACT_SILU) return v / (1.0f + (sizeof(T) == 4 ? expf(-v) : __expf(-v)));
+  if (act == GLSDET_ACT_SILU) {
+    if (sizeof(T) == 4) return v / (1.0f + expf(-v));                  // exact-f32 mode: IEEE divide
+    return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v));              // fp16 mode: v_exp + v_rcp (1 ulp each)
+  }
   if (act == GLSDET_ACT_RELU) return fmaxf(v, 0.0f);
   if (act == GLSDET_ACT_LRELU) return v > 0.0f ? v : 0.1f * v;
   return v;
@@ -93,5 +107,7 @@ __device__ __forceinline__ u32x4 add_chunk(u32x4 a, u32x4 b, float*) {
 
 // host-side dispatch of the halo kernel (conv_halo.hip); returns 1 if it does not apply
 int conv_halo_try(const ConvArgs& a, int xdt, int ydt, int hint, OpRecord* op);
+// weight-stationary persistent 1x1 kernel (conv1x1.hip), tile_hint 3; returns 1 if it does not apply
+int conv1x1_ws_try(const ConvArgs& a, int xdt, int ydt, OpRecord* op);
 
 }  // namespace glsdet

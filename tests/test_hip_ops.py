@@ -256,3 +256,34 @@ def test_conv_halo_and_generic_kernels_agree_with_oracle(engines, mode, hint, ca
     out = eng.conv(xv, eng.pack_conv([(w, scale, bias)], cin), 1, k // 2, "silu", out=ov, res=rv, tile_hint=hint)
     torch.cuda.synchronize()
     _cmp(out.to_nchw(cout), ref, TOL[mode], "conv halo/generic")
+
+
+WS_CASES = [(128, 128, 20, 24, True, True), (64, 64, 33, 17, False, False), (256, 192, 9, 11, False, True),
+            (128, 256, 30, 30, True, False), (64, 192, 7, 5, False, False)]
+
+
+@pytest.mark.parametrize("mode", ["f32", "f16"])
+@pytest.mark.parametrize("case", WS_CASES, ids=lambda c: "ci%d_co%d_%dx%d" % c[:4])
+def test_conv1x1_weight_stationary(engines, mode, case):
+    """persistent weight-stationary 1x1 kernel (tile_hint 3) incl. ragged tiles, views, residual"""
+    cin, cout, H, W, use_res, embed = case
+    if mode == "f32" and cin * 4 > 512:
+        pytest.skip("resident weight tile limited to 512 bytes of K")
+    eng = engines[mode]
+    g = torch.Generator().manual_seed(cin + cout + H)
+    x = torch.randn(3, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, 1, 1, generator=g) / np.sqrt(cin)
+    scale = torch.rand(cout, generator=g) + 0.5
+    bias = torch.randn(cout, generator=g) * 0.3
+    r = (lambda t: t.half().float()) if mode == "f16" else (lambda t: t)
+    ref = O._act(F.conv2d(r(x), r(w)) * scale[None, :, None, None] + bias[None, :, None, None], "silu")
+    res = None
+    if use_res:
+        res = torch.randn(ref.shape, generator=g)
+        ref = ref + r(res)
+    xv = _to_view(eng, x, embed=(cin + 16, 8) if embed else None)
+    rv = _to_view(eng, res) if use_res else None
+    ov = eng.tensor(3, H, W, cout + 24).channels(16, 16 + cout) if embed else None
+    out = eng.conv(xv, eng.pack_conv([(w, scale, bias)], cin), 1, 0, "silu", out=ov, res=rv, tile_hint=3)
+    torch.cuda.synchronize()
+    _cmp(out.to_nchw(cout), ref, TOL[mode], "conv1x1 ws")
