@@ -59,6 +59,7 @@ _SIGS = {
     "glsdet_plan_destroy": (None, [C.c_void_p]),
     "glsdet_plan_begin": (C.c_int, [C.c_void_p]),
     "glsdet_plan_end": (C.c_int, [C.c_void_p]),
+    "glsdet_plan_set_branch": (C.c_int, [C.c_int32]),
     "glsdet_plan_num_ops": (C.c_int32, [C.c_void_p]),
     "glsdet_plan_op_info": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_double),
                                       C.POINTER(C.c_double), C.c_char_p, C.c_int32]),

@@ -43,6 +43,8 @@ inline bool same_extent(const glsdet_view& a, const glsdet_view& b) {
 // ---- plan recording -------------------------------------------------------------------
 struct OpRecord {
   int kind;                 // 0 conv, 1 focus, 2 maxpool, 3 resample, 4 nonlocal, 5 decode, 6 nms
+  int branch = 0;           // 0 = main sequence; ops of different non-zero branches between two
+                            // main ops are independent and may overlap (set by submit())
   double flops, bytes;      // algorithmic 2*MACs and min HBM bytes of this op
   std::string name;         // kernel family / tile name
   std::function<int(hipStream_t)> launch;

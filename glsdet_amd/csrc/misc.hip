@@ -155,43 +155,58 @@ __global__ __launch_bounds__(256) void nl_gram_kernel(const unsigned char* tpg, 
 }
 
 // P[b][co][c1] = (1/N) sum_c2 Wout[co][c2] * (sum_z Gp[z][b][c1][c2]).  Workgroup = (image,
-// 8 output channels); the summed Gram matrix is rebuilt in LDS (row stride ci+1) per group.
-#define GLS_FOLD_CO 8
+// 16 output channels).  The partial Gram slices are summed into LDS with all 8 slice loads
+// of an element in flight (fixed order -> deterministic); a wave then owns one output
+// channel at a time, so its weight row is wave-uniform (scalar loads) while lanes walk c1.
+#define GLS_FOLD_CO 16
 __global__ __launch_bounds__(256) void nl_fold_kernel(const float* __restrict__ Gp, int nsplit, int nimg,
                                                       const float* __restrict__ wout, int ci, int cx, float invN,
                                                       float* P) {
   extern __shared__ float gs[];   // [ci][ci+1]
   const int b = blockIdx.x, co0 = blockIdx.y * GLS_FOLD_CO, ld = ci + 1;
+  const long slice = (long)nimg * ci * ci;
   for (int e = threadIdx.x; e < ci * ci; e += 256) {
-    float a = 0.f;
-    for (int z = 0; z < nsplit; ++z) a += Gp[((long)z * nimg + b) * ci * ci + e];
-    gs[(e / ci) * ld + (e % ci)] = a;
+    const float* g = Gp + (long)b * ci * ci + e;
+    float v[8];
+#pragma unroll
+    for (int z = 0; z < 8; ++z) v[z] = z < nsplit ? g[z * slice] : 0.f;
+    float acc = v[0];
+#pragma unroll
+    for (int z = 1; z < 8; ++z) acc += v[z];
+    gs[(e / ci) * ld + (e % ci)] = acc;
   }
   __syncthreads();
-  for (int e = threadIdx.x; e < GLS_FOLD_CO * ci; e += 256) {
-    const int co = co0 + e / ci, c1 = e % ci;
-    if (co >= cx) continue;
-    const float* w = wout + (long)co * ci;
-    const float* g = gs + c1 * ld;
-    float acc = 0.f;
-    for (int c2 = 0; c2 < ci; ++c2) acc += w[c2] * g[c2];
-    P[((long)b * cx + co) * ci + c1] = acc * invN;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int col = wave; col < GLS_FOLD_CO; col += 4) {
+    const int co = co0 + col;
+    if (co >= cx) break;
+    const float* w = wout + (long)co * ci;          // wave-uniform row
+    for (int c1 = lane; c1 < ci; c1 += 64) {
+      const float* g = gs + c1 * ld;
+      float acc = 0.f;
+#pragma unroll 8
+      for (int c2 = 0; c2 < ci; ++c2) acc += w[c2] * g[c2];
+      P[((long)b * cx + co) * ci + c1] = acc * invN;
+    }
   }
 }
 
 // out[b,i,co] = x[b,i,co] + bout[co] + sum_c1 theta[b,i,c1] * P[b][co][c1]
-// workgroup = 64 pixels of one image; theta tile in LDS (row stride ci+1: lanes = pixels,
-// conflict-free); P rows are wave-uniform reads.
+// Workgroup = 64 pixels x 32 output channels of one image.  theta tile [64][ci+1] and the P
+// rows [32][ci] live in LDS; lanes are pixels (theta rows conflict-free), a wave owns 8
+// output channels (P reads are broadcasts), 4 accumulators per thread share each theta read.
+#define GLS_APPLY_CO 32
 template <typename T>
 __global__ __launch_bounds__(256) void nl_apply_kernel(const unsigned char* x, long xsn, long xsh, long xsw,
                                                        const unsigned char* tpg, long tsn, long tsh, long tsw,
                                                        unsigned char* out, long osn, long osh, long osw, int H, int W,
                                                        int ci, int cx, const float* __restrict__ P,
                                                        const float* __restrict__ bout) {
-  extern __shared__ float th[];   // [64][ci+1]
+  extern __shared__ float th[];   // [64][ci+1] theta, then [GLS_APPLY_CO][ci] P rows
   const int N = H * W;
-  const int b = blockIdx.y, j0 = blockIdx.x * 64;
+  const int b = blockIdx.y, j0 = blockIdx.x * 64, co0 = blockIdx.z * GLS_APPLY_CO;
   const int ld = ci + 1;
+  float* pr = th + 64 * ld;
   for (int idx = threadIdx.x; idx < 64 * ci; idx += 256) {
     const int jj = idx / ci, c = idx - jj * ci;
     const int j = j0 + jj;
@@ -199,21 +214,39 @@ __global__ __launch_bounds__(256) void nl_apply_kernel(const unsigned char* x, l
     if (j < N) v = (float)(reinterpret_cast<const T*>(tpg) + b * tsn + (j / W) * tsh + (j % W) * tsw)[c];
     th[jj * ld + c] = v;
   }
+  for (int idx = threadIdx.x; idx < GLS_APPLY_CO * ci; idx += 256) {
+    const int r = idx / ci, c = idx - r * ci;
+    pr[idx] = (co0 + r) < cx ? P[((long)b * cx + co0 + r) * ci + c] : 0.f;
+  }
   __syncthreads();
   const int jj = threadIdx.x & 63, grp = threadIdx.x >> 6;
   const int j = j0 + jj;
   if (j >= N) return;
   const long poff_x = b * xsn + (j / W) * xsh + (j % W) * xsw;
   const long poff_o = b * osn + (j / W) * osh + (j % W) * osw;
-  const float* Pb = P + (long)b * cx * ci;
   const float* t = th + jj * ld;
-  const int co_beg = blockIdx.z * 16, co_end = min(cx, co_beg + 16);
-  for (int co = co_beg + grp; co < co_end; co += 4) {
-    const float* pr = Pb + (long)co * ci;
-    float acc = 0.f;
-    for (int c = 0; c < ci; ++c) acc += t[c] * pr[c];
-    const float xv = (float)(reinterpret_cast<const T*>(x) + poff_x)[co];
-    (reinterpret_cast<T*>(out) + poff_o)[co] = (T)(xv + bout[co] + acc);
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    const int r0 = grp * 8 + half * 4;              // 4 consecutive output channels
+    const float* p0 = pr + r0 * ci;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll 8
+    for (int c = 0; c < ci; ++c) {
+      const float tv = t[c];
+      a0 += tv * p0[c];
+      a1 += tv * p0[ci + c];
+      a2 += tv * p0[2 * ci + c];
+      a3 += tv * p0[3 * ci + c];
+    }
+    const float acc[4] = {a0, a1, a2, a3};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int co = co0 + r0 + e;
+      if (co < cx) {
+        const float xv = (float)(reinterpret_cast<const T*>(x) + poff_x)[co];
+        (reinterpret_cast<T*>(out) + poff_o)[co] = (T)(xv + bout[co] + acc[e]);
+      }
+    }
   }
 }
 
@@ -335,10 +368,10 @@ extern "C" int glsdet_nonlocal(const glsdet_view* x, const glsdet_view* tpg, int
   float* P = gram + (long)vx.n * 8 * ci * ci;
   op.launch = [=](hipStream_t st) -> int {
     const int nb = (ci + 15) / 16;
-    const dim3 g1(nb * nb, vx.n, nsplit), g2(vx.n, (cx + GLS_FOLD_CO - 1) / GLS_FOLD_CO), g3((N + 63) / 64, vx.n, (cx + 15) / 16);
+    const dim3 g1(nb * nb, vx.n, nsplit), g2(vx.n, (cx + GLS_FOLD_CO - 1) / GLS_FOLD_CO), g3((N + 63) / 64, vx.n, (cx + GLS_APPLY_CO - 1) / GLS_APPLY_CO);
     const size_t lds2 = (size_t)ci * (ci + 1) * 4;
     if (lds2 > 64 * 1024) GLS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(nl_fold_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
-    const size_t lds3 = (size_t)64 * (ci + 1) * 4;
+    const size_t lds3 = ((size_t)64 * (ci + 1) + (size_t)GLS_APPLY_CO * ci) * 4;
     if (vx.dtype == GLSDET_F16) {
       hipLaunchKernelGGL(nl_gram_kernel<f16>, g1, dim3(256), 0, st, (const unsigned char*)vt.base, vt.sn, vt.sh, vt.sw, vt.h, vt.w, ci, jchunk, gram);
       hipLaunchKernelGGL(nl_fold_kernel, g2, dim3(256), lds2, st, gram, nsplit, vx.n, wout, ci, cx, 1.0f / (float)N, P);

@@ -9,6 +9,7 @@ namespace glsdet {
 
 static thread_local char g_err[512] = "";
 static thread_local glsdet_plan* g_recording = nullptr;
+static thread_local int g_branch = 0;
 
 void set_error(const char* fmt, ...) {
   va_list ap;
@@ -39,15 +40,58 @@ int check_view(const glsdet_view& v, const char* what, bool need16) {
 
 }  // namespace glsdet
 
+#define GLS_MAX_BRANCH 8
 struct glsdet_plan {
   std::vector<glsdet::OpRecord> ops;
   hipGraph_t graph = nullptr;
   hipGraphExec_t exec = nullptr;
+  hipStream_t side[GLS_MAX_BRANCH + 1] = {};
+  hipEvent_t ev_fork[GLS_MAX_BRANCH + 1] = {}, ev_join[GLS_MAX_BRANCH + 1] = {};
 };
+
+namespace glsdet {
+// Replay the op list on `st`; ops of side branches go to the plan's side streams, forked from
+// and joined back into `st` with events (works the same eagerly and under stream capture,
+// where it produces parallel graph branches).
+static int replay(glsdet_plan* p, hipStream_t st, bool use_branches) {
+  bool active[GLS_MAX_BRANCH + 1] = {};
+  auto join_all = [&]() -> int {
+    for (int b = 1; b <= GLS_MAX_BRANCH; ++b)
+      if (active[b]) {
+        GLS_HIP(hipEventRecord(p->ev_join[b], p->side[b]));
+        GLS_HIP(hipStreamWaitEvent(st, p->ev_join[b], 0));
+        active[b] = false;
+      }
+    return 0;
+  };
+  for (auto& o : p->ops) {
+    int rc;
+    const int b = use_branches ? o.branch : 0;
+    if (b <= 0 || b > GLS_MAX_BRANCH) {
+      if ((rc = join_all())) return rc;
+      if ((rc = o.launch(st))) return rc;
+      continue;
+    }
+    if (!p->side[b]) {
+      GLS_HIP(hipStreamCreateWithFlags(&p->side[b], hipStreamNonBlocking));
+      GLS_HIP(hipEventCreateWithFlags(&p->ev_fork[b], hipEventDisableTiming));
+      GLS_HIP(hipEventCreateWithFlags(&p->ev_join[b], hipEventDisableTiming));
+    }
+    if (!active[b]) {
+      GLS_HIP(hipEventRecord(p->ev_fork[b], st));
+      GLS_HIP(hipStreamWaitEvent(p->side[b], p->ev_fork[b], 0));
+      active[b] = true;
+    }
+    if ((rc = o.launch(p->side[b]))) return rc;
+  }
+  return join_all();
+}
+}  // namespace glsdet
 
 namespace glsdet {
 int submit(OpRecord&& op, void* stream) {
   if (g_recording) {
+    op.branch = g_branch;
     g_recording->ops.emplace_back(std::move(op));
     return 0;
   }
@@ -66,6 +110,11 @@ extern "C" void glsdet_plan_destroy(glsdet_plan* p) {
   if (g_recording == p) g_recording = nullptr;
   if (p->exec) (void)hipGraphExecDestroy(p->exec);
   if (p->graph) (void)hipGraphDestroy(p->graph);
+  for (int b = 0; b <= GLS_MAX_BRANCH; ++b) {
+    if (p->ev_fork[b]) (void)hipEventDestroy(p->ev_fork[b]);
+    if (p->ev_join[b]) (void)hipEventDestroy(p->ev_join[b]);
+    if (p->side[b]) (void)hipStreamDestroy(p->side[b]);
+  }
   delete p;
 }
 extern "C" int glsdet_plan_begin(glsdet_plan* p) {
@@ -77,6 +126,23 @@ extern "C" int glsdet_plan_begin(glsdet_plan* p) {
 extern "C" int glsdet_plan_end(glsdet_plan* p) {
   if (g_recording != p) GLS_FAIL(GLSDET_E_ARG, "plan_end: plan is not the one being recorded");
   g_recording = nullptr;
+  g_branch = 0;
+  return 0;
+}
+extern "C" int glsdet_plan_set_branch(int32_t branch) {
+  if (branch < 0 || branch > GLS_MAX_BRANCH) GLS_FAIL(GLSDET_E_ARG, "plan_set_branch: branch %d not in [0,%d]", branch, GLS_MAX_BRANCH);
+  if (g_recording && branch == 0 && g_branch != 0) {
+    // leaving a fork region: an explicit join point, so that a following region's branches
+    // start only after ALL branches of this one (there may be no main-sequence op in between)
+    OpRecord j;
+    j.kind = -1;
+    j.flops = j.bytes = 0;
+    j.name = "join";
+    j.branch = 0;
+    j.launch = [](hipStream_t) -> int { return 0; };
+    g_recording->ops.emplace_back(std::move(j));
+  }
+  g_branch = branch;
   return 0;
 }
 extern "C" int32_t glsdet_plan_num_ops(const glsdet_plan* p) { return p ? (int32_t)p->ops.size() : 0; }
@@ -95,11 +161,7 @@ extern "C" int glsdet_plan_op_info(const glsdet_plan* p, int32_t i, int32_t* kin
 }
 extern "C" int glsdet_plan_run(glsdet_plan* p, void* stream) {
   if (!p) GLS_FAIL(GLSDET_E_ARG, "plan_run: null plan");
-  for (auto& o : p->ops) {
-    int rc = o.launch((hipStream_t)stream);
-    if (rc) return rc;
-  }
-  return 0;
+  return replay(p, (hipStream_t)stream, true);
 }
 extern "C" int glsdet_plan_capture(glsdet_plan* p, void* stream) {
   if (!p) GLS_FAIL(GLSDET_E_ARG, "plan_capture: null plan");
@@ -108,11 +170,7 @@ extern "C" int glsdet_plan_capture(glsdet_plan* p, void* stream) {
   if (p->exec) { (void)hipGraphExecDestroy(p->exec); p->exec = nullptr; }
   if (p->graph) { (void)hipGraphDestroy(p->graph); p->graph = nullptr; }
   GLS_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-  int rc = 0;
-  for (auto& o : p->ops) {
-    rc = o.launch(st);
-    if (rc) break;
-  }
+  int rc = replay(p, st, true);
   hipGraph_t g = nullptr;
   hipError_t e = hipStreamEndCapture(st, &g);
   if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }

@@ -260,6 +260,11 @@ class Engine:
                                   _stream_ptr(self.stream)), "nms")
         return nb["dets"], nb["count"], nb["status"]
 
+    def branch(self, b: int):
+        """Ops emitted until the next branch(0) belong to independent branch b (1..8): quadrant
+        convs, the l/r/t/b stitch convs, the cls/reg towers.  No-op outside plan recording."""
+        check(self.lib.glsdet_plan_set_branch(b), "plan_set_branch")
+
     def new_plan(self) -> Plan:
         return Plan(self.lib)
 

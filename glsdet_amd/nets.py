@@ -142,17 +142,24 @@ class NetBuilder:
                  "lb": (x.window(hh, x.h, 0, hw), Q.window(ht, ht + hb, 0, wl)),
                  "rt": (x.window(0, hh, hw, x.w), Q.window(0, ht, wl, wl + wr)),
                  "rb": (x.window(hh, x.h, hw, x.w), Q.window(ht, ht + hb, wl, wl + wr))}
-        for name, (src, dst) in quads.items():
+        for bi, (name, (src, dst)) in enumerate(quads.items()):      # four independent branches
+            self.e.branch(bi + 1)
             self.cba("%s.feat_patchconv_%s" % (p, name), src, stride, out=dst)
             if with_nonlocal:
                 self.nonlocal_block("%s.feat_patchconv_%s_nonlocal" % (p, name), dst)
+        self.e.branch(0)
         H, W = ht + hb, wl + wr
         Z = self.e.tensor(x.n, H, W, 2 * mid)
         lr, tb = Z.channels(0, mid), Z.channels(mid, 2 * mid)
+        self.e.branch(1)
         self.cba(p + ".feat_patchconv_l", Q.window(0, H, 0, wl), out=lr.window(0, H, 0, wl))
+        self.e.branch(2)
         self.cba(p + ".feat_patchconv_r", Q.window(0, H, wl, W), out=lr.window(0, H, wl, W))
+        self.e.branch(3)
         self.cba(p + ".feat_patchconv_t", Q.window(0, ht, 0, W), out=tb.window(0, ht, 0, W))
+        self.e.branch(4)
         self.cba(p + ".feat_patchconv_b", Q.window(ht, H, 0, W), out=tb.window(ht, H, 0, W))
+        self.e.branch(0)
         if self.has(p + ".channel_conv.weight"):
             return self.plain(p + ".channel_conv", Z, out=out)
         return self.cba(p + ".channel_conv", Z, out=out)
@@ -223,8 +230,11 @@ class NetBuilder:
             s = self.cba("%s.stems.%d" % (p, k), x)
             T = self.cba(["%s.cls_convs.%d.0" % (p, k), "%s.reg_convs.%d.0" % (p, k)], s)
             U = self.e.tensor(x.n, x.h, x.w, 2 * f)
+            self.e.branch(1)
             self.cba("%s.cls_convs.%d.1" % (p, k), T.channels(0, f), out=U.channels(0, f))
+            self.e.branch(2)
             self.cba("%s.reg_convs.%d.1" % (p, k), T.channels(f, 2 * f), out=U.channels(f, 2 * f))
+            self.e.branch(0)
             pk = self._pack("%s.preds.%d" % (p, k), [self._pred_parts(p, k, f, nc)], U.c)
             outs.append(self.e.conv(U, pk, 1, 0, "none", out_dtype=F32))
             self.num_classes = nc

@@ -164,6 +164,10 @@ glsdet_plan* glsdet_plan_create(void);
 void    glsdet_plan_destroy(glsdet_plan*);
 int     glsdet_plan_begin(glsdet_plan*);
 int     glsdet_plan_end(glsdet_plan*);
+/* While recording: ops submitted under different non-zero branch ids (1..8) between two
+ * branch-0 ops are declared independent of each other; replay runs them on side streams
+ * forked from / joined into the main stream (parallel nodes of the captured hipGraph). */
+int     glsdet_plan_set_branch(int32_t branch);
 int32_t glsdet_plan_num_ops(const glsdet_plan*);
 /* kind: 0 conv, 1 focus, 2 maxpool, 3 resample, 4 nonlocal, 5 decode, 6 nms; flops = 2*MACs */
 int     glsdet_plan_op_info(const glsdet_plan*, int32_t i, int32_t* kind, double* flops,
