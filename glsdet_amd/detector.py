@@ -48,6 +48,7 @@ class HipDetector:
                 c.decoded = eng.decode(c.levels, self.num_classes, H, W, mode=post.get("mode", 0))
                 c.nmsb = eng.nms_buffers(n, A, min(post.get("max_cand", A), A), post.get("max_det", 1000))
                 eng.nms(c.decoded, self.num_classes, post.get("mode", 0), post["conf_thres"], post["nms_thres"], c.nmsb)
+        eng.save_tune_cache()
         c.graph_stream = None
         if use_graph:
             c.plan.run()                         # warm-up outside capture (lazy module load, attributes)

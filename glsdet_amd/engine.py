@@ -6,6 +6,8 @@ forward pass is a kernel of libglsdet_hip.so reached through the C ABI (``_lib``
 from __future__ import annotations
 
 import ctypes as C
+import json
+import os
 from typing import List, Optional, Sequence, Tuple
 
 import numpy as np
@@ -134,6 +136,12 @@ class Engine:
         self.alloc_bytes = 0
         self.autotune = autotune        # measure kernel/tile variants per conv problem at build time
         self._tuned = {}
+        # optional persistent tuning cache (JSON): GLSDET_TUNE_CACHE=/path/file.json
+        self._tune_cache_path = os.environ.get("GLSDET_TUNE_CACHE", "")
+        if self._tune_cache_path and os.path.exists(self._tune_cache_path):
+            with open(self._tune_cache_path) as f:
+                self._tuned = {tuple(json.loads(k)): v for k, v in json.load(f).get(dtype, {}).items()}
+        self._dtype_name = dtype
 
     # ---- memory
     def raw(self, nbytes: int) -> torch.Tensor:
@@ -196,6 +204,7 @@ class Engine:
                 check(self.lib.glsdet_conv2d_tune(C.byref(d), _stream_ptr(self.stream), C.byref(best), C.byref(us)),
                       "conv2d_tune")
                 self._tuned[key] = best.value
+                self._tune_dirty = True
             d.tile_hint = self._tuned[key]
         check(self.lib.glsdet_conv2d(C.byref(d), _stream_ptr(self.stream)), "conv2d")
         return out
@@ -264,6 +273,18 @@ class Engine:
         """Ops emitted until the next branch(0) belong to independent branch b (1..8): quadrant
         convs, the l/r/t/b stitch convs, the cls/reg towers.  No-op outside plan recording."""
         check(self.lib.glsdet_plan_set_branch(b), "plan_set_branch")
+
+    def save_tune_cache(self):
+        if not self._tune_cache_path or not getattr(self, "_tune_dirty", False):
+            return
+        data = {}
+        if os.path.exists(self._tune_cache_path):
+            with open(self._tune_cache_path) as f:
+                data = json.load(f)
+        data[self._dtype_name] = {json.dumps(list(k)): v for k, v in self._tuned.items()}
+        with open(self._tune_cache_path, "w") as f:
+            json.dump(data, f)
+        self._tune_dirty = False
 
     def new_plan(self) -> Plan:
         return Plan(self.lib)
