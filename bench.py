@@ -17,6 +17,7 @@ Prints ONE JSON line (rank 0).  Extra objects: `roofline` for the dominant kerne
 launch stream) and `cpu_baseline` (the CPU oracle, bounded sample, rank 0 at N=1 only).
 """
 import argparse
+import glob
 import json
 import os
 import sys
@@ -195,10 +196,20 @@ def main():
     conv_ms = sum(t for _, t in conv)
     all_ms = float(ms.sum())
     achieved = conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
-    roofline = {"bound": "mfma", "kernel": "conv_igemm (all tile instantiations)",
+    # HBM traffic per conv launch: PMC counters cannot be read from inside the benchmark; the
+    # newest committed rocprofv3 --pmc summary of this same command (tools/profile_round.sh ->
+    # profiles/*/traffic.json, FETCH_SIZE doubled per the gfx950 correction) is reported.
+    traffic = None
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "traffic.json")), key=os.path.getmtime)
+    if cands and args.workload == "yolox_s_glfusion_1344x800_bs8" and args.dtype == "f16":
+        with open(cands[-1]) as f:
+            traffic = round(json.load(f)["hbm_bytes_per_launch"])
+    roofline = {"bound": "mfma", "kernel": "conv family: conv_igemm + conv_halo + conv1x1_ws (all instantiations)",
                 "achieved": round(achieved, 2), "peak": PEAK_F16_TFLOPS if args.dtype == "f16" else 157.3,
                 "unit": "TFLOP/s", "frac": round(achieved / (PEAK_F16_TFLOPS if args.dtype == "f16" else 157.3), 4),
-                "traffic": None, "launches_per_step": len(conv),
+                "traffic": traffic, "traffic_unit": "HBM bytes per conv launch (rocprofv3 PMC, profiles/)",
+                "algorithmic_bytes_per_launch": round(8 * 431.8e6 / max(1, len(conv))),
+                "launches_per_step": len(conv),
                 "avg_launch_us": round(conv_ms * 1e3 / max(1, len(conv)), 2),
                 "gflop_per_launch": round(conv_flops / max(1, len(conv)) / 1e9, 3),
                 "conv_ms_per_step": round(conv_ms, 4), "all_ops_ms_per_step_eager": round(all_ms, 4),
