@@ -9,7 +9,7 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "lib", "libglsdet_hip.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 F16, F32 = 0, 1
 ACT = {"none": 0, "silu": 1, "relu": 2, "lrelu": 3}
@@ -50,7 +50,7 @@ _SIGS = {
     "glsdet_nonlocal": (C.c_int, [C.POINTER(View), C.POINTER(View), C.c_int32, C.c_void_p, C.c_void_p,
                                   C.c_void_p, C.POINTER(View), C.c_void_p]),
     "glsdet_yolox_decode": (C.c_int, [C.POINTER(View), C.c_int32, C.c_int32, C.c_int32, C.c_int32,
-                                      C.POINTER(C.c_int32), C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]),
+                                      C.POINTER(C.c_int32), C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "glsdet_nms_workspace_bytes": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
     "glsdet_nms": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_float,
                              C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,

@@ -16,6 +16,7 @@ struct DecodeArgs {
   int n_levels, nc, n, A, mode;
   float in_w, in_h;
   float* out;
+  const float* scale;   // optional [n][4] per-image divisors of (x1,y1,x2,y2) (mmdet `rescale`), mode 1
 };
 
 __device__ __forceinline__ float sigmoidf_acc(float v) { return 1.0f / (1.0f + expf(-v)); }
@@ -43,10 +44,12 @@ __global__ __launch_bounds__(256) void decode_kernel(const DecodeArgs a) {
       o[2] = w / a.in_w;
       o[3] = h / a.in_h;
     } else {
-      o[0] = cx - w / 2;
-      o[1] = cy - h / 2;
-      o[2] = cx + w / 2;
-      o[3] = cy + h / 2;
+      float x1 = cx - w / 2, y1 = cy - h / 2, x2 = cx + w / 2, y2 = cy + h / 2;
+      if (a.scale) {          // yolox_head.py:283-285  flatten_bboxes[..., :4] /= scale_factor
+        const float* sf = a.scale + 4 * b;
+        x1 /= sf[0]; y1 /= sf[1]; x2 /= sf[2]; y2 /= sf[3];
+      }
+      o[0] = x1; o[1] = y1; o[2] = x2; o[3] = y2;
     }
     for (int c = 4; c < F; ++c) o[c] = sigmoidf_acc(p[c]);
   }
@@ -315,7 +318,7 @@ using namespace glsdet;
 
 extern "C" int glsdet_yolox_decode(const glsdet_view* levels, int32_t n_levels, int32_t num_classes, int32_t in_h,
                                    int32_t in_w, const int32_t* strides, int32_t mode, float* out, int64_t out_elems,
-                                   void* stream) {
+                                   const float* scale_factors, void* stream) {
   if (!levels || !out || n_levels < 1 || n_levels > GLS_MAX_LEVELS) GLS_FAIL(GLSDET_E_ARG, "yolox_decode: bad levels");
   if (num_classes < 1 || mode < 0 || mode > 1) GLS_FAIL(GLSDET_E_ARG, "yolox_decode: bad num_classes/mode");
   DecodeArgs a = {};
@@ -339,6 +342,7 @@ extern "C" int glsdet_yolox_decode(const glsdet_view* levels, int32_t n_levels, 
   a.n_levels = n_levels; a.nc = num_classes; a.n = levels[0].n; a.A = A; a.mode = mode;
   a.in_w = (float)in_w; a.in_h = (float)in_h;
   a.out = out;
+  a.scale = mode == 1 ? scale_factors : nullptr;
   if (out_elems < (int64_t)a.n * A * (5 + num_classes)) GLS_FAIL(GLSDET_E_CAPACITY, "yolox_decode: output buffer too small");
   OpRecord op;
   op.kind = 5;

@@ -12,7 +12,7 @@ from .nets import build_forward
 
 
 class _Compiled:
-    __slots__ = ("img", "plan", "levels", "decoded", "nmsb", "eng", "post", "graph_stream")
+    __slots__ = ("img", "plan", "levels", "stems", "decoded", "nmsb", "eng", "post", "graph_stream", "scale")
 
 
 class HipDetector:
@@ -40,12 +40,16 @@ class HipDetector:
         c.img = torch.zeros(n, 3, H, W, dtype=torch.float32, device=eng.device)
         c.plan = eng.new_plan()
         c.post = post
-        c.decoded = c.nmsb = None
+        c.decoded = c.nmsb = c.scale = None
+        if post is not None and post.get("rescale"):
+            c.scale = torch.ones(n, 4, dtype=torch.float32, device=eng.device)   # per-image divisors (mmdet rescale)
         with c.plan:
-            c.levels, self.num_classes = build_forward(self.kind, eng, self.sd, c.img)
+            c.levels, self.num_classes, c.stems = build_forward(self.kind, eng, self.sd, c.img)
             if post is not None:
                 A = sum(l.h * l.w for l in c.levels)
-                c.decoded = eng.decode(c.levels, self.num_classes, H, W, mode=post.get("mode", 0))
+                c.decoded = eng.decode(c.levels, self.num_classes, H, W, mode=post.get("mode", 0),
+                                       strides=[8, 16, 32] if post.get("mode", 0) == 1 else None,
+                                       scale_factors=c.scale)
                 c.nmsb = eng.nms_buffers(n, A, min(post.get("max_cand", A), A), post.get("max_det", 1000))
                 eng.nms(c.decoded, self.num_classes, post.get("mode", 0), post["conf_thres"], post["nms_thres"], c.nmsb)
         eng.save_tune_cache()
@@ -61,7 +65,7 @@ class HipDetector:
         return c
 
     # ------------------------------------------------------------------ run
-    def run(self, c: _Compiled, img: Optional[torch.Tensor] = None, stream=None):
+    def run(self, c: _Compiled, img: Optional[torch.Tensor] = None, stream=None, scale: Optional[torch.Tensor] = None):
         """One forward (+ post-processing if compiled in).  Asynchronous; a captured plan is
         replayed on its own stream, ordered after/before the caller's current stream."""
         if c.plan.captured:
@@ -70,11 +74,15 @@ class HipDetector:
             with torch.cuda.stream(st):
                 if img is not None:
                     c.img.copy_(img, non_blocking=True)
+                if scale is not None:
+                    c.scale.copy_(scale, non_blocking=True)
                 c.plan.launch(st)
             cur.wait_stream(st)
             return
         if img is not None:
             c.img.copy_(img, non_blocking=True)
+        if scale is not None:
+            c.scale.copy_(scale, non_blocking=True)
         c.plan.run(stream)
 
     def forward_raw(self, img: torch.Tensor) -> List[torch.Tensor]:

@@ -23,14 +23,14 @@ class RawOutputs(list):
     detector = None
 
 
-class HipYoloBody(nn.Module):
-    kind = "base"
+class TableModule(nn.Module):
+    """nn.Module used purely as a parameter container: registers the tensors of a
+    {key: shape} table (reference names, reference order) and exposes them under exactly those
+    names in state_dict()/load_state_dict(); arithmetic happens elsewhere (libglsdet_hip)."""
 
-    def __init__(self, num_classes: int, phi: str, dtype: str = "f16"):
-        super().__init__()
-        self.num_classes, self.phi, self.hip_dtype = num_classes, phi, dtype
+    def _init_table(self, shapes):
         self._names = {}
-        for key, shape in state_dict_shapes(self.kind, phi, num_classes).items():
+        for key, shape in shapes.items():
             flat = key.replace(".", "__")
             self._names[flat] = key
             if key.endswith("num_batches_tracked"):
@@ -48,11 +48,14 @@ class HipYoloBody(nn.Module):
                 bound = 1.0 / fan_in ** 0.5
                 self.register_parameter(flat, nn.Parameter(torch.empty(shape).uniform_(-bound, bound),
                                                            requires_grad=False))
-        self._det = None
+        self._on_weights_changed()
+
+    def _on_weights_changed(self):
+        pass
 
     # ---- reference-named state_dict -----------------------------------------------------
     def state_dict(self, *args, destination=None, prefix="", keep_vars=False):
-        raw = super().state_dict(prefix="", keep_vars=keep_vars)
+        raw = nn.Module.state_dict(self, prefix="", keep_vars=keep_vars)
         out = destination if destination is not None else type(raw)()
         for flat, key in self._names.items():          # the reference's registration order
             out[prefix + key] = raw[flat]
@@ -71,9 +74,22 @@ class HipYoloBody(nn.Module):
         if strict and (missing or unexpected):
             raise RuntimeError("Error(s) in loading state_dict for {}: missing {} unexpected {}".format(
                 type(self).__name__, missing[:5], unexpected[:5]))
-        res = super().load_state_dict(sd, strict=False)
-        self._det = None                                         # weights changed: re-pack lazily
+        res = nn.Module.load_state_dict(self, sd, strict=False)
+        self._on_weights_changed()                                # weights changed: re-pack lazily
         return res
+
+
+class HipYoloBody(TableModule):
+    kind = "base"
+
+    def __init__(self, num_classes: int, phi: str, dtype: str = "f16"):
+        super().__init__()
+        self.num_classes, self.phi, self.hip_dtype = num_classes, phi, dtype
+        self._det = None
+        self._init_table(state_dict_shapes(self.kind, phi, num_classes))
+
+    def _on_weights_changed(self):
+        self._det = None
 
     # ---- forward ---------------------------------------------------------------------------
     def forward(self, x: torch.Tensor) -> List[torch.Tensor]:

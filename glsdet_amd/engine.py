@@ -241,7 +241,8 @@ class Engine:
         return out
 
     def decode(self, levels: Sequence[TView], num_classes: int, in_h: int, in_w: int,
-               strides: Optional[Sequence[int]] = None, mode: int = 0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+               strides: Optional[Sequence[int]] = None, mode: int = 0, out: Optional[torch.Tensor] = None,
+               scale_factors: Optional[torch.Tensor] = None) -> torch.Tensor:
         A = sum(l.h * l.w for l in levels)
         n = levels[0].n
         if out is None:
@@ -249,8 +250,12 @@ class Engine:
             self._keep.append(out)
         arr = (View * len(levels))(*[l.as_c() for l in levels])
         st = (C.c_int32 * len(levels))(*strides) if strides is not None else None
+        sf = None
+        if scale_factors is not None:
+            assert scale_factors.dtype == torch.float32 and scale_factors.is_contiguous() and scale_factors.numel() == 4 * n
+            sf = scale_factors.data_ptr()
         check(self.lib.glsdet_yolox_decode(arr, len(levels), num_classes, in_h, in_w, st, mode,
-                                           out.data_ptr(), out.numel(), _stream_ptr(self.stream)), "yolox_decode")
+                                           out.data_ptr(), out.numel(), sf, _stream_ptr(self.stream)), "yolox_decode")
         return out
 
     def nms_buffers(self, n: int, A: int, max_cand: int, max_det: int):

@@ -224,10 +224,12 @@ class NetBuilder:
     def yolox_head(self, p: str, feats: Sequence[TView]) -> List[TView]:
         """YOLOXHead.forward (base/yolox.py:46-92) -> per level fp32 [n,H,W,ceil8(5+nc)]."""
         outs = []
+        self.stems = []
         for k, x in enumerate(feats):
             nc = self.sd["%s.cls_preds.%d.weight" % (p, k)].shape[0]
             f = self.conv_out_channels("%s.stems.%d" % (p, k))
             s = self.cba("%s.stems.%d" % (p, k), x)
+            self.stems.append(s)
             T = self.cba(["%s.cls_convs.%d.0" % (p, k), "%s.reg_convs.%d.0" % (p, k)], s)
             U = self.e.tensor(x.n, x.h, x.w, 2 * f)
             self.e.branch(1)
@@ -249,4 +251,4 @@ def build_forward(kind: str, eng: Engine, sd, img: torch.Tensor):
         raise ValueError("unknown detector kind %r" % kind)
     feats = b.pafpn("backbone", img, gl=(kind == "gl"))
     outs = b.yolox_head("head", feats)
-    return outs, b.num_classes
+    return outs, b.num_classes, b.stems

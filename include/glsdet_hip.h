@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GLSDET_ABI_VERSION 1
+#define GLSDET_ABI_VERSION 2
 
 enum { GLSDET_F16 = 0, GLSDET_F32 = 1 };
 enum { GLSDET_ACT_NONE = 0, GLSDET_ACT_SILU = 1, GLSDET_ACT_RELU = 2, GLSDET_ACT_LRELU = 3 };
@@ -126,11 +126,14 @@ int glsdet_nonlocal(const glsdet_view* x, const glsdet_view* tpg, int32_t ci,
  * out: fp32 [n][A][5+nc] contiguous, A = sum H_l*W_l, level-major then row-major.
  * mode 0: sigmoid(obj,cls); cx=(x+gx)*s/in_w, cy=(y+gy)*s/in_h, w=exp()*s/in_w, h=exp()*s/in_h,
  *         s = in_h / H_l for both axes (reference quirk, utils_bbox.py:285).
- * mode 1: sigmoid(obj,cls); x1,y1,x2,y2 in input pixels, s_l = strides[l].
+ * mode 1: sigmoid(obj,cls); x1,y1,x2,y2 in input pixels, s_l = strides[l]; if scale_factors
+ *         (device fp32 [n][4], may be NULL) is given the box is divided by it per image
+ *         (mmdet `rescale=True`, yolox_head.py:283-285).
  */
 int glsdet_yolox_decode(const glsdet_view* levels, int32_t n_levels, int32_t num_classes,
                         int32_t in_h, int32_t in_w, const int32_t* strides /*host, may be NULL*/,
-                        int32_t mode, float* out, int64_t out_elems, void* stream);
+                        int32_t mode, float* out, int64_t out_elems,
+                        const float* scale_factors, void* stream);
 
 /* ---------------------------------------------------------------------------------
  * class-max + score threshold + batched (per-class) NMS

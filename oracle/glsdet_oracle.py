@@ -387,3 +387,39 @@ def non_max_suppression(prediction: Tensor, num_classes: int, input_shape, image
 # arithmetic of the path; it lives in glsdet_amd/synth.py so bench.py can build weights
 # without importing the oracle.  Re-exported here for the tests and the golden generator.
 from glsdet_amd.synth import synth_input, synth_state_dict, synth_tensor  # noqa: E402,F401
+
+
+# --------------------------------------------------------------------------- mmdet flavour
+def mmdet_yolox_get_bboxes(outs: Sequence[Tensor], num_classes: int, strides: Sequence[int], score_thr: float,
+                           iou_thr: float, scale_factors=None):
+    """YOLOXHead.get_bboxes / _bbox_decode / _bboxes_nms + bbox2result restated
+    (ufp/mmdet/models/dense_heads/yolox_head.py:249-322, core/anchor/point_generator.py with
+    offset=0, core/bbox/transforms.py:116-133).  `outs` = per level [B, 4+1+nc, H, W] in the
+    drone channel order (reg, obj, cls).  -> list[img] of list[class] of ndarray(n,5)."""
+    B = outs[0].shape[0]
+    priors, flat = [], []
+    for o, s in zip(outs, strides):
+        h, w = o.shape[-2:]
+        gy, gx = torch.meshgrid(torch.arange(h), torch.arange(w), indexing="ij")
+        priors.append(torch.stack((gx.flatten() * s, gy.flatten() * s, torch.full((h * w,), s), torch.full((h * w,), s)), 1).float())
+        flat.append(o.permute(0, 2, 3, 1).reshape(B, -1, o.shape[1]))
+    priors, flat = torch.cat(priors), torch.cat(flat, 1).float()
+    xys = flat[..., :2] * priors[:, 2:] + priors[:, :2]
+    whs = flat[..., 2:4].exp() * priors[:, 2:]
+    boxes = torch.cat((xys - whs / 2, xys + whs / 2), -1)
+    if scale_factors is not None:
+        boxes = boxes / torch.as_tensor(np.asarray(scale_factors, np.float32)).reshape(B, 1, 4)
+    obj, cls = flat[..., 4].sigmoid(), flat[..., 5:5 + num_classes].sigmoid()
+    results = []
+    for i in range(B):
+        max_scores, labels = torch.max(cls[i], 1)
+        valid = obj[i] * max_scores >= score_thr
+        b, s, l = boxes[i][valid].numpy(), (max_scores[valid] * obj[i][valid]).numpy(), labels[valid].numpy()
+        if len(l) == 0:
+            results.append([np.zeros((0, 5), np.float32) for _ in range(num_classes)])
+            continue
+        keep = batched_nms(b, s, l.astype(np.float32), iou_thr)
+        dets = np.concatenate([b[keep], s[keep][:, None]], 1).astype(np.float32)
+        lk = l[keep]
+        results.append([dets[lk == c] for c in range(num_classes)])
+    return results
