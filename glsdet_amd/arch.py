@@ -14,7 +14,7 @@ from typing import Tuple
 # drone/models/base/yolox.py:240-241
 DEPTH = {"nano": 0.33, "tiny": 0.33, "s": 0.33, "m": 0.67, "l": 1.00, "x": 1.33}
 WIDTH = {"nano": 0.25, "tiny": 0.375, "s": 0.50, "m": 0.75, "l": 1.00, "x": 1.25}
-KINDS = ("base", "gl")
+KINDS = ("base", "gl", "cross")
 
 
 class _Table(OrderedDict):
@@ -76,6 +76,31 @@ class _Table(OrderedDict):
         self.plain(p + ".channel_conv", 2 * mid, cout, 1)
 
 
+def cross_head_table(t: "_Table", h: str, num_classes: int, wid: float, dw: bool):
+    """Cross-scale decoupled head, drone/models/lsk/yolox6.py:7-67 (= new/yolox6.py)."""
+    c = [int(256 * wid), int(512 * wid), int(1024 * wid)]
+    f = int(256 * wid)
+    for i in range(3):
+        cin = f * 2 if i == 2 else f * 3
+        t.any_conv("%s.cls_convs.%d.0" % (h, i), cin, cin, 3, dw)
+        t.any_conv("%s.cls_convs.%d.1" % (h, i), cin, f, 3, dw)
+    for i in range(3):
+        for j in range(2):
+            t.any_conv("%s.reg_convs.%d.%d" % (h, i, j), f, f, 3, dw)
+    for i in range(3):
+        t.plain("%s.cls_preds.%d" % (h, i), f, num_classes, 1)
+    for i in range(3):
+        t.plain("%s.reg_preds.%d" % (h, i), f, 4, 1)
+    for i in range(3):
+        t.plain("%s.obj_preds.%d" % (h, i), f, 1, 1)
+    for i in range(3):
+        t.conv_bn("%s.stems.%d" % (h, i), c[i], f, 1)
+    t.csp(h + ".csp_feat0", int(0.5 * 256 * wid), f, round(3 * 0.75), dw)
+    for i in range(3):
+        t.any_conv("%s.up_convs.%d.0" % (h, i), f, f, 3, dw)
+        t.any_conv("%s.up_convs.%d.1" % (h, i), f, f, 3, dw)
+
+
 def state_dict_shapes(kind: str, phi: str, num_classes: int) -> "OrderedDict[str, Tuple[int, ...]]":
     if kind not in KINDS:
         raise ValueError("kind must be one of %r" % (KINDS,))
@@ -106,8 +131,9 @@ def state_dict_shapes(kind: str, phi: str, num_classes: int) -> "OrderedDict[str
         t.plain(b + ".P5_Identity.conv", c[2], c[2], 3)
     f = int(256 * wid)
     h = "head"
-    for i in range(3):        # per level: ModuleList entries are appended level by level
-        pass
+    if kind == "cross":
+        cross_head_table(t, h, num_classes, wid, dw)
+        return t
     for name in ("cls_convs", "reg_convs"):
         for i in range(3):
             for j in range(2):

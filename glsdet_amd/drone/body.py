@@ -113,3 +113,10 @@ class BaseYoloBody(HipYoloBody):
 
 class GLYoloBody(HipYoloBody):
     kind = "gl"
+
+
+class CrossYoloBody(HipYoloBody):
+    """YOLOX with the cross-scale decoupled head (drone/models/new/yolox6.py, whose import of
+    `models.decouple` is missing from the reference checkout; head text-identical to
+    drone/models/lsk/yolox6.py) on the plain CSPDarknet backbone."""
+    kind = "cross"

@@ -243,12 +243,53 @@ class NetBuilder:
         return outs
 
 
+    def cross_scale_head(self, p: str, feats: Sequence[TView]) -> List[TView]:
+        """Cross-scale decoupled head (drone/models/lsk/yolox6.py:69-153 = new/yolox6.py).
+        feats = (dark2, P3, P4, P5).  The cls tower of level k sees cat[x_k, down(finer level),
+        up(coarser level)]: the stem writes x_k straight into that concat buffer, the two
+        neighbours land in their slices (3x3 s1 + 3x3 s2 `up_convs`, nearest x2)."""
+        e = self.e
+        nc = self.sd["%s.cls_preds.0.weight" % p].shape[0]
+        f = self.conv_out_channels("%s.stems.0" % p)
+        feat0 = self.csp(p + ".csp_feat0", feats[0], False)
+        lv, cats = [], []
+        for k, x in enumerate(feats[1:]):
+            parts = 3 if k < 2 else 2
+            cat = e.tensor(x.n, x.h, x.w, parts * f)
+            cats.append(cat)
+            lv.append(self.cba("%s.stems.%d" % (p, k), x, out=cat.channels(0, f)))
+        self.stems = lv
+        outs = []
+        for k in range(3):
+            finer = feat0 if k == 0 else lv[k - 1]
+            e.branch(1)
+            t = self.cba("%s.up_convs.%d.0" % (p, k), finer)
+            self.cba("%s.up_convs.%d.1" % (p, k), t, 2, out=cats[k].channels(f, 2 * f))
+            if k < 2:
+                e.branch(2)
+                e.resample(lv[k + 1], 2, out=cats[k].channels(2 * f, 3 * f))
+            e.branch(3)
+            r = self.cba("%s.reg_convs.%d.0" % (p, k), lv[k])
+            U = e.tensor(lv[k].n, lv[k].h, lv[k].w, 2 * f)
+            self.cba("%s.reg_convs.%d.1" % (p, k), r, out=U.channels(f, 2 * f))
+            e.branch(0)
+            c = self.cba("%s.cls_convs.%d.0" % (p, k), cats[k])
+            self.cba("%s.cls_convs.%d.1" % (p, k), c, out=U.channels(0, f))
+            pk = self._pack("%s.preds.%d" % (p, k), [self._pred_parts(p, k, f, nc)], U.c)
+            outs.append(e.conv(U, pk, 1, 0, "none", out_dtype=F32))
+        self.num_classes = nc
+        return outs
+
+
 def build_forward(kind: str, eng: Engine, sd, img: torch.Tensor):
-    """Emit the whole raw forward of a `kind` in {'base','gl'} detector for the static input
+    """Emit the whole raw forward of a `kind` in {'base','gl','cross'} detector for the static input
     tensor `img` (NCHW fp32 on the device).  Returns (list of fp32 level views, num_classes)."""
     b = NetBuilder(eng, sd)
-    if kind not in ("base", "gl"):
+    if kind not in ("base", "gl", "cross"):
         raise ValueError("unknown detector kind %r" % kind)
     feats = b.pafpn("backbone", img, gl=(kind == "gl"))
-    outs = b.yolox_head("head", feats)
+    if kind == "cross":
+        outs = b.cross_scale_head("head", [b.features["dark2"]] + feats)
+    else:
+        outs = b.yolox_head("head", feats)
     return outs, b.num_classes, b.stems

@@ -119,6 +119,21 @@ def main():
     block("identity5", lambda: Identity_Conv_five(16, 16), (2, 16, 20, 24))
     block("identity7", lambda: Identity_Conv_seven(16, 16), (2, 16, 20, 24))
 
+    # ------------------------------------------------------------------ cross-scale decoupled head
+    # drone/models/lsk/yolox6.py:7-153 (text-identical to new/yolox6.py): the head class alone,
+    # fed with four synthetic pyramid features (dark2, P3, P4, P5 of a width-0.5 model).
+    from models.lsk.yolox6 import YOLOXHead as CrossHead
+    for seed in (0, 1):
+        m = CrossHead(10, 0.5)
+        shapes = fill(m, seed)
+        feats = [synth_input(sh, seed + 300 + i) for i, sh in enumerate(
+            [(2, 64, 32, 40), (2, 128, 16, 20), (2, 256, 8, 10), (2, 512, 4, 5)])]
+        ys = m(feats)
+        for i, y in enumerate(ys):
+            out["crosshead/seed%d/out%d" % (seed, i)] = y.numpy()
+        out["crosshead/seed%d/meta" % seed] = np.frombuffer(json.dumps(
+            {"shapes": shapes, "seed": seed, "feat_shapes": [list(f.shape) for f in feats]}).encode(), np.uint8)
+
     # ------------------------------------------------------------------ whole models
     shapes_all = {}
     for mname, mod in (("base", ref_base), ("gl", ref_gl)):

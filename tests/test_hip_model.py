@@ -262,3 +262,44 @@ def test_autotuned_plan_matches_default(golden, shapes):
     b = det.forward_raw(x.cuda())
     for p, q in zip(a, b):
         assert float((p - q).abs().max()) <= 2e-4 * max(1.0, float(p.abs().max()))
+
+
+@pytest.mark.parametrize("mode", ["f32", "f16"])
+@pytest.mark.parametrize("seed", [0, 1])
+def test_cross_scale_head_vs_reference_golden(engines, golden, mode, seed):
+    """A7': the cross-scale decoupled head (lsk/yolox6.py:69-153) lowered by
+    NetBuilder.cross_scale_head vs the reference head's own outputs"""
+    import json
+    from glsdet_amd.nets import NetBuilder
+    from glsdet_amd.synth import synth_input, synth_tensor
+    eng = engines[mode]
+    meta = json.loads(bytes(golden["crosshead/seed%d/meta" % seed]).decode())
+    sd = {"head." + k: torch.from_numpy(synth_tensor(k, tuple(s), seed)) for k, s in meta["shapes"].items()}
+    feats = [synth_input(tuple(sh), seed + 300 + i) for i, sh in enumerate(meta["feat_shapes"])]
+    b = NetBuilder(eng, sd)
+    outs = b.cross_scale_head("head", [_upload(eng, f) for f in feats])
+    torch.cuda.synchronize()
+    for i, o in enumerate(outs):
+        want = torch.from_numpy(golden["crosshead/seed%d/out%d" % (seed, i)])
+        got = o.to_nchw(15).cpu()
+        err = float((got - want).abs().max())
+        tol = (5e-5 if mode == "f32" else 2e-2) * max(1.0, float(want.abs().max()))
+        assert err <= tol, (i, err, tol)
+
+
+def test_cross_model_matches_oracle(shapes):
+    """whole 'cross' detector (plain CSPDarknet + PAFPN + cross-scale head) vs the oracle"""
+    from glsdet_amd.arch import state_dict_shapes
+    from glsdet_amd.detector import HipDetector
+    from glsdet_amd.synth import synth_input, synth_state_dict
+    sh = state_dict_shapes("cross", "tiny", 10)
+    sd = synth_state_dict(sh, 3)
+    for k in list(sd):      # tame the un-calibrated random net: small BN gains
+        if k.endswith("bn.weight"):
+            sd[k] = sd[k] * 0.5
+    x = synth_input((2, 3, 128, 160), 7)
+    want = O.yolox_cross_forward(sd, x)
+    got = HipDetector("cross", sd, dtype="f32").forward_raw(x.cuda())
+    for g, w in zip(got, want):
+        assert g.shape == w.shape
+        assert float((g.cpu() - w).abs().max()) <= 2e-4 * max(1.0, float(w.abs().max()))

@@ -134,3 +134,15 @@ def test_non_max_suppression_shapes(golden, shapes):
     for r in res:
         assert r is None or (r.ndim == 2 and r.shape[1] == 7)
     assert any(r is not None and len(r) > 0 for r in res)
+
+
+@pytest.mark.parametrize("seed", [0, 1])
+def test_cross_scale_head_matches_reference(golden, seed):
+    """A7': oracle.cross_scale_head vs the reference head class (lsk/yolox6.py:7-153) itself"""
+    import json
+    meta = json.loads(bytes(golden["crosshead/seed%d/meta" % seed]).decode())
+    sd = {"head." + k: torch.from_numpy(O.synth_tensor(k, tuple(s), seed)) for k, s in meta["shapes"].items()}
+    feats = [O.synth_input(tuple(sh), seed + 300 + i) for i, sh in enumerate(meta["feat_shapes"])]
+    outs = O.cross_scale_head(sd, "head", feats)
+    for i, o in enumerate(outs):
+        _close(o, torch.from_numpy(golden["crosshead/seed%d/out%d" % (seed, i)]))

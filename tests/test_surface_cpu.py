@@ -40,6 +40,8 @@ def test_drop_in_module_paths_like_the_reference_harness(shapes, monkeypatch):
     for mod in list(sys.modules):
         if mod == "models" or mod.startswith("models."):
             monkeypatch.delitem(sys.modules, mod)
+    m6 = importlib.import_module("models/new/yolox6.py"[:-3].replace("/", "."))
+    assert len(m6.YoloBody(10, "tiny").state_dict()) == 540
     for path, tag in (("models/base/yolox.py", "base_tiny"),
                       ("models/block/non_local/yolo_patch_nonlocal_plus.py", "gl_tiny")):
         m = importlib.import_module(path[:-3].replace("/", "."))
