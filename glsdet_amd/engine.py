@@ -209,6 +209,29 @@ class Engine:
         check(self.lib.glsdet_conv2d(C.byref(d), _stream_ptr(self.stream)), "conv2d")
         return out
 
+    def pack_dw(self, w: torch.Tensor, scale: torch.Tensor, bias: torch.Tensor, c_pad: int):
+        """depthwise weights [C,1,R,S] -> ([R*S][c_pad] in engine dtype, scale, bias, C, R, S)"""
+        C_, one, R, S = w.shape
+        assert one == 1 and C_ <= c_pad and c_pad % 8 == 0
+        wp = torch.zeros(R * S, c_pad, dtype=torch.float32)
+        wp[:, :C_] = w.float().reshape(C_, R * S).t()
+        sc, bi = torch.ones(c_pad), torch.zeros(c_pad)
+        sc[:C_], bi[:C_] = scale.float(), bias.float()
+        return (self.upload(wp.to(_TORCH_DT[self.dt])), self.upload(sc), self.upload(bi), C_, R, S)
+
+    def dwconv(self, x: TView, packed, stride: int, pad: int, act: str, out: Optional[TView] = None) -> TView:
+        wdev, sdev, bdev, C_, R, S = packed
+        ho = (x.h + 2 * pad - R) // stride + 1
+        wo = (x.w + 2 * pad - S) // stride + 1
+        if out is None:
+            out = self.tensor(x.n, ho, wo, x.c, x.dtype)
+        d = ConvDesc()
+        d.x, d.y, d.res = x.as_c(), out.as_c(), View()
+        d.w, d.scale, d.bias = wdev.data_ptr(), sdev.data_ptr(), bdev.data_ptr()
+        d.R, d.S, d.stride, d.pad, d.act, d.tile_hint = R, S, stride, pad, ACT[act], 0
+        check(self.lib.glsdet_dwconv2d(C.byref(d), _stream_ptr(self.stream)), "dwconv2d")
+        return out
+
     def focus_pack(self, img: torch.Tensor, out: Optional[TView] = None) -> TView:
         assert img.dtype == torch.float32 and img.is_contiguous() and img.device.type == "cuda"
         n, cin, H, W = img.shape

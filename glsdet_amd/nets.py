@@ -66,13 +66,35 @@ class NetBuilder:
         """BaseConv(s): conv (no bias) + BN + act; several prefixes = fused along Cout."""
         if isinstance(prefixes, str):
             prefixes = [prefixes]
-        for p in prefixes:
-            if self.is_depthwise(p):
-                raise NotImplementedError("depthwise (phi='nano') towers are not lowered yet: " + p)
+        if any(self.is_depthwise(p) for p in prefixes):
+            return self._dw_separable(prefixes, x, stride, act, out, res)
         parts = [self._bn_part(p) for p in prefixes]
         k = parts[0][0].shape[-1]
         pk = self._pack("+".join(prefixes), parts, x.c)
         return self.e.conv(x, pk, stride, (k - 1) // 2, act, out=out, res=res)
+
+    def _dw_separable(self, prefixes, x: TView, stride, act, out, res) -> TView:
+        """DWConv (baseConv.py:22-30): depthwise kxk (+BN+act) then pointwise 1x1 (+BN+act).
+        A list of prefixes (outputs concatenated along C) is lowered one by one."""
+        couts = [self.sd[p + ".pconv.conv.weight"].shape[0] for p in prefixes]
+        if out is None:
+            k0 = self.sd[prefixes[0] + ".dconv.conv.weight"].shape[-1]
+            ho = (x.h + 2 * ((k0 - 1) // 2) - k0) // stride + 1
+            wo = (x.w + 2 * ((k0 - 1) // 2) - k0) // stride + 1
+            out = self.e.tensor(x.n, ho, wo, sum(couts))
+        c0 = 0
+        for p, co in zip(prefixes, couts):
+            w, s, b = self._bn_part(p + ".dconv")
+            k = w.shape[-1]
+            key = (p + ".dconv", x.c)
+            if key not in self._packed:
+                self._packed[key] = self.e.pack_dw(w, s, b, x.c)
+            t = self.e.dwconv(x, self._packed[key], stride, (k - 1) // 2, act)
+            dst = out if len(prefixes) == 1 else out.channels(c0, c0 + co)
+            pk = self._pack(p + ".pconv", [self._bn_part(p + ".pconv")], t.c)
+            self.e.conv(t, pk, 1, 0, act, out=dst, res=res)
+            c0 += co
+        return out
 
     def plain(self, p: str, x: TView, pad: int = 0, out: Optional[TView] = None) -> TView:
         """nn.Conv2d with bias, no norm / activation."""
@@ -80,6 +102,8 @@ class NetBuilder:
         return self.e.conv(x, pk, 1, pad, "none", out=out)
 
     def conv_out_channels(self, p: str) -> int:
+        if self.is_depthwise(p):
+            return self.sd[p + ".pconv.conv.weight"].shape[0]
         return self.sd[p + ".conv.weight"].shape[0]
 
     # ------------------------------------------------------------------ blocks

@@ -85,6 +85,10 @@ int     glsdet_conv2d(const glsdet_conv_desc* d, void* stream);
  * problem on the device (synchronises; never recorded into a plan) and returns the fastest
  * tile_hint.  The output view is written with the conv result. */
 int     glsdet_conv2d_tune(const glsdet_conv_desc* d, void* stream, int32_t* best_hint, float* best_us);
+/* Depthwise k x k conv + folded BN + act (`dconv` of DWConv, drone/models/base/baseConv.py:22-30;
+ * mmcv DepthwiseSeparableConvModule).  Same descriptor; x.c == y.c; w = [R*S][x.c] elements of
+ * x.dtype (tap-major), scale/bias fp32 [x.c]; res must be empty. */
+int     glsdet_dwconv2d(const glsdet_conv_desc* d, void* stream);
 /* number of ELEMENTS of the packed weight buffer for (cout, R, S, cin, dtype)           */
 int64_t glsdet_conv_weight_elems(int32_t cout, int32_t R, int32_t S, int32_t cin, int32_t dtype);
 int32_t glsdet_conv_kpad(int32_t R, int32_t S, int32_t cin, int32_t dtype);

@@ -49,6 +49,8 @@ BLOCKS = {
     "baseconv_k3_s2_silu": lambda b, x: b.cba("m", x, 2, "silu"),
     "baseconv_k1_s1_lrelu": lambda b, x: b.cba("m", x, 1, "lrelu"),
     "baseconv_k3_s1_relu": lambda b, x: b.cba("m", x, 1, "relu"),
+    "dwconv_k3_s2": lambda b, x: b.cba("m", x, 2, "silu"),
+    "bottleneck_add": lambda b, x: b.cba("m.conv2", b.cba("m.conv1", x), res=x),
 }
 
 
@@ -78,7 +80,8 @@ def test_focus_stem_vs_reference_golden(engines, golden):
     assert float((out.to_nchw(want.shape[1]).cpu() - want).abs().max()) <= 5e-5 * max(1.0, float(want.abs().max()))
 
 
-MODELS = ["base_tiny_seed0", "base_tiny_seed1", "base_s_seed0", "gl_tiny_seed0", "gl_tiny_seed1", "gl_s_seed0"]
+MODELS = ["base_tiny_seed0", "base_tiny_seed1", "base_s_seed0", "gl_tiny_seed0", "gl_tiny_seed1", "gl_s_seed0",
+          "base_nano_seed0", "base_nano_seed1", "gl_nano_seed0", "gl_nano_seed1"]     # nano = depthwise towers
 
 
 def _rel(a, b):
