@@ -27,9 +27,12 @@ class HipDetector:
         self.num_classes = None
 
     # ------------------------------------------------------------------ compile
-    def compile(self, n: int, H: int, W: int, post: Optional[dict] = None, use_graph: bool = False) -> _Compiled:
-        """post: None (raw logits only) or dict(conf_thres, nms_thres, max_cand, max_det, mode)."""
-        key = (n, H, W, tuple(sorted(post.items())) if post else None, use_graph)
+    def compile(self, n: int, H: int, W: int, post: Optional[dict] = None, use_graph: bool = False,
+                instance: int = 0) -> _Compiled:
+        """post: None (raw logits only) or dict(conf_thres, nms_thres, max_cand, max_det, mode).
+        `instance` > 0 builds an independent copy (own buffers, own stream) of the same plan, so
+        consecutive batches can be in flight concurrently (see run_async)."""
+        key = (n, H, W, tuple(sorted(post.items())) if post else None, use_graph, instance)
         if key in self._compiled:
             return self._compiled[key]
         if H % 32 or W % 32:
@@ -84,6 +87,15 @@ class HipDetector:
         if scale is not None:
             c.scale.copy_(scale, non_blocking=True)
         c.plan.run(stream)
+
+    @staticmethod
+    def run_async(c: _Compiled):
+        """Replay a captured plan on ITS OWN stream without ordering it against the caller's
+        current stream: with two instances alternating, the latency-bound tail of batch i
+        (NMS, small convs) overlaps the MFMA-bound body of batch i+1.  The caller synchronises
+        (torch.cuda.synchronize() or c.graph_stream.synchronize()) before reading results."""
+        assert c.plan.captured, "run_async needs compile(..., use_graph=True)"
+        c.plan.launch(c.graph_stream)
 
     def forward_raw(self, img: torch.Tensor) -> List[torch.Tensor]:
         """Reference-shaped output: list of [B, 5+nc, H_l, W_l] fp32 logits (NCHW)."""
