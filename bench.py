@@ -69,7 +69,11 @@ def synthetic_state_dict(tag):
 def cpu_baseline(sd, kind, n, H, W, conf, nms_thr, budget_s=25.0):
     """The oracle (a port: kind='port') timed on the host cores: forward + decode + NMS."""
     from oracle import glsdet_oracle as O
-    torch.set_num_threads(max(1, min(os.cpu_count() or 1, 64)))
+    try:
+        ncpu = len(os.sched_getaffinity(0))
+    except AttributeError:
+        ncpu = os.cpu_count() or 1
+    torch.set_num_threads(max(1, min(ncpu, 64)))
     x = O.synth_input((n, 3, H, W), 100)
 
     def step():
