@@ -300,6 +300,11 @@ class Engine:
     def branch(self, b: int):
         """Ops emitted until the next branch(0) belong to independent branch b (1..8): quadrant
         convs, the l/r/t/b stitch convs, the cls/reg towers.  No-op outside plan recording."""
+        # Opt-in (GLSDET_BRANCHES=1).  Measured on MI355X: alone, forking the quadrant / tower
+        # convs into parallel graph branches gains ~2 %; with two batches in flight (bench) the
+        # fork/join nodes serialise the two graphs against each other and cost 15 % img/s.
+        if not os.environ.get("GLSDET_BRANCHES"):
+            return
         check(self.lib.glsdet_plan_set_branch(b), "plan_set_branch")
 
     def save_tune_cache(self):
