@@ -81,11 +81,16 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
     const int p = px0 + row;
     pok[i] = row < PX_T && p < a.M;
     const int pp = pok[i] ? p : 0;
-    const int n = pp / HoWo, rem = pp - n * HoWo;
-    const int ho = rem / a.Wo, wo = rem - ho * a.Wo;
-    hi0[i] = ho * a.stride - a.pad;
-    wi0[i] = wo * a.stride - a.pad;
-    boff[i] = (int)((long)n * a.x_sn + (long)hi0[i] * a.x_sh + (long)wi0[i] * a.x_sw);
+    if (a.x_lin) {              // 1x1 / stride 1 / no padding on a pixel-linear view: no division, always in range
+      hi0[i] = wi0[i] = 0;
+      boff[i] = (int)((long)pp * a.x_sw);
+    } else {
+      const int n = pp / HoWo, rem = pp - n * HoWo;
+      const int ho = rem / a.Wo, wo = rem - ho * a.Wo;
+      hi0[i] = ho * a.stride - a.pad;
+      wi0[i] = wo * a.stride - a.pad;
+      boff[i] = (int)((long)n * a.x_sn + (long)hi0[i] * a.x_sh + (long)wi0[i] * a.x_sw);
+    }
   }
   // ---- k position of this thread's chunk column: (r, s, c)
   int kr, ks, kci;
@@ -97,10 +102,13 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
     ks = tap - kr * a.S;
   }
 
-  u32x4 ra[NA], rb[NB];
+  // register ring of three K-step tiles: the loads of step t+3 are issued while step t is
+  // multiplied (a 64x64 tile's MFMA phase is ~0.1 us, one step of lookahead cannot cover an
+  // L2/HBM round trip; the small-K / small-tile layers were latency bound on it)
+  u32x4 ra0[NA], rb0[NB], ra1[NA], rb1[NB], ra2[NA], rb2[NB];
   const int nsteps = (a.kreal + KE - 1) / KE;
 
-  auto gload = [&](int step) __attribute__((always_inline)) {
+  auto gload = [&](int step, u32x4 (&ra)[NA], u32x4 (&rb)[NB]) __attribute__((always_inline)) {
     const unsigned kbyte = (unsigned)step * KB;
 #pragma unroll
     for (int i = 0; i < NA; ++i) ra[i] = gls_buf_load16(wrs, wp[i] + kbyte);   // GLS_OOB + small stays out of range
@@ -121,7 +129,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
       }
     }
   };
-  auto lstore = [&](int buf) __attribute__((always_inline)) {
+  auto lstore = [&](int buf, const u32x4 (&ra)[NA], const u32x4 (&rb)[NB]) __attribute__((always_inline)) {
     unsigned char* sa = smem + buf * STAGE + kc * 16;
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
@@ -149,13 +157,18 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
   const int a_off = (wco * WT_CO + l31) * RS + lh * 16;
   const int b_off = CO_T * RS + (wpx * WT_PX + l31) * RS + lh * 16;
 
-  gload(0);
-  lstore(0);
+  gload(0, ra0, rb0);
+  lstore(0, ra0, rb0);
+  if (nsteps > 1) gload(1, ra1, rb1);
+  if (nsteps > 2) gload(2, ra2, rb2);
   __syncthreads();
 
-  for (int t = 0; t < nsteps; ++t) {
+  // one K step: issue step t+3 into the set that held step t (already in LDS), multiply step t
+  // from LDS buffer t&1, then move step t+1 (in flight for two steps) into the other buffer
+  auto kstep = [&](int t, u32x4 (&fa)[NA], u32x4 (&fb)[NB], const u32x4 (&na)[NA], const u32x4 (&nb)[NB])
+      __attribute__((always_inline)) {
     const int cur = t & 1;
-    if (t + 1 < nsteps) gload(t + 1);
+    if (t + 3 < nsteps) gload(t + 3, fa, fb);
     const unsigned char* sbuf = smem + cur * STAGE;
 #pragma unroll
     for (int kk = 0; kk < KB / 32; ++kk) {
@@ -171,8 +184,13 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) MMA<T>::run(af[i], bf[j], acc[i][j]);
     }
-    if (t + 1 < nsteps) lstore(cur ^ 1);
+    if (t + 1 < nsteps) lstore(cur ^ 1, na, nb);
     __syncthreads();
+  };
+  for (int t = 0; t < nsteps; t += 3) {
+    kstep(t, ra0, rb0, ra1, rb1);
+    if (t + 1 < nsteps) kstep(t + 1, ra1, rb1, ra2, rb2);
+    if (t + 2 < nsteps) kstep(t + 2, ra2, rb2, ra0, rb0);
   }
 
   // ---- epilogue: fp32 scale/bias/act, transpose through LDS, 16-B channel chunks out
@@ -256,7 +274,7 @@ static int dispatch_tile(const ConvArgs& a, int co_t, int px_t, int kb, hipStrea
 static void pick_tile(const ConvArgs& a, int elem, int hint, int* co_t, int* px_t, int* kb) {
   if (hint) {
     *co_t = hint >> 16;
-    *px_t = hint & 0xffff;
+    *px_t = hint & 0x7fff;
   } else {
     // largest tile that still gives the chip >= 3 workgroups per CU; below that the layer
     // is latency bound and more, smaller workgroups win over MFMA density
@@ -274,6 +292,7 @@ static void pick_tile(const ConvArgs& a, int elem, int hint, int* co_t, int* px_
     }
   }
   *kb = ((long)a.kreal * elem) % 128 == 0 ? 128 : 64;
+  if (hint & 0x8000) *kb = 64;      // explicit 64-byte K steps: half the LDS / registers -> more workgroups per CU
 }
 
 }  // namespace glsdet
@@ -344,6 +363,8 @@ static int build_conv_op(const glsdet_conv_desc* d, int hint, OpRecord& op) {
   a.x_off = (unsigned)((const char*)x.base - (const char*)x.alloc_lo);
   a.x_bytes = (unsigned)xalloc;
   a.w_bytes = (unsigned)wbytes;
+  a.x_lin = (d->R == 1 && d->S == 1 && d->stride == 1 && d->pad == 0 && x.sh == (int64_t)x.w * x.sw &&
+             x.sn == (int64_t)x.h * x.sh) ? 1 : 0;
   a.y_lin = (y.sh == (int64_t)Wo * y.sw && y.sn == (int64_t)Ho * y.sh) ? 1 : 0;
   a.r_lin = (has_res && d->res.sh == (int64_t)Wo * d->res.sw && d->res.sn == (int64_t)Ho * d->res.sh) ? 1 : 0;
 
@@ -389,7 +410,8 @@ extern "C" int glsdet_conv2d(const glsdet_conv_desc* d, void* stream) {
 extern "C" int glsdet_conv2d_tune(const glsdet_conv_desc* d, void* stream, int32_t* best_hint, float* best_us) {
   if (!d || !best_hint) GLS_FAIL(GLSDET_E_ARG, "conv2d_tune: null argument");
   hipStream_t st = (hipStream_t)stream;
-  const int hints[] = {2, 3, (128 << 16) | 128, (64 << 16) | 128, (64 << 16) | 64, (32 << 16) | 128};
+  const int hints[] = {2, 3, (128 << 16) | 128, (64 << 16) | 128, (64 << 16) | 64, (32 << 16) | 128,
+                       (64 << 16) | 64 | 0x8000, (64 << 16) | 128 | 0x8000, (128 << 16) | 128 | 0x8000};
   hipEvent_t e0, e1;
   GLS_HIP(hipEventCreate(&e0));
   GLS_HIP(hipEventCreate(&e1));

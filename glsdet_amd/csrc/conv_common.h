@@ -30,6 +30,7 @@ struct ConvArgs {
   // 1 when offset(pixel p) == p * s_w for the view (dense NHWC or a channel slice of one):
   // the epilogue then needs no integer division per 16-byte chunk
   int y_lin, r_lin;
+  int x_lin;                  // 1x1 / s1 / p0 conv on a pixel-linear input view
 };
 
 // element offset of flat output pixel p (+ channel) in a view

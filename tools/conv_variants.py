@@ -27,7 +27,7 @@ SHAPES = [  # n, H, W, cin, cout, k, stride
     (8, 400, 672, 16, 32, 3, 1),
 ]
 HINTS = {"auto": 0, "halo": 2, "ws1x1": 3, "g128x128": (128 << 16) | 128, "g64x128": (64 << 16) | 128,
-         "g64x64": (64 << 16) | 64, "g32x128": (32 << 16) | 128}
+         "g64x64": (64 << 16) | 64, "g64x64k64": (64 << 16) | 64 | 0x8000, "g64x128k64": (64 << 16) | 128 | 0x8000, "g32x128": (32 << 16) | 128}
 
 
 def main():
