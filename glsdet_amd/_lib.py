@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(HERE, "lib", "libglsdet_hip.so")
 ABI_VERSION = 2
 
 F16, F32 = 0, 1
-ACT = {"none": 0, "silu": 1, "relu": 2, "lrelu": 3}
+ACT = {"none": 0, "silu": 1, "relu": 2, "lrelu": 3, "gelu": 4, "sigmoid": 5}
 
 
 class GlsdetLibraryError(RuntimeError):
@@ -46,6 +46,7 @@ _SIGS = {
     "glsdet_conv_cout_pad": (C.c_int32, [C.c_int32]),
     "glsdet_focus_pack": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                     C.POINTER(View), C.c_void_p]),
+    "glsdet_channel_maxmean": (C.c_int, [C.POINTER(View), C.POINTER(View), C.c_void_p]),
     "glsdet_maxpool2d": (C.c_int, [C.POINTER(View), C.POINTER(View), C.c_int32, C.c_void_p]),
     "glsdet_resample_copy": (C.c_int, [C.POINTER(View), C.POINTER(View), C.c_int32, C.c_void_p]),
     "glsdet_nonlocal": (C.c_int, [C.POINTER(View), C.POINTER(View), C.c_int32, C.c_void_p, C.c_void_p,

@@ -46,7 +46,16 @@ class _Table(OrderedDict):
             self.conv_bn("%s.m.%d.conv1" % (p, i), hid, hid, 1)
             self.any_conv("%s.m.%d.conv2" % (p, i), hid, hid, 3, depthwise)
 
-    def darknet(self, p: str, dep: float, wid: float, depthwise: bool):
+    def attention(self, p: str, d: int):
+        """Attention (drone/models/new/Non_local_family.py:254-263), gating unit channel_scale=1."""
+        self.plain(p + ".proj_1", d, d, 1)
+        g = p + ".spatial_gating_unit"
+        for q in ("lt", "lb", "rt", "rb"):
+            self.nonlocal_block("%s.feat_patchconv_%s_nonlocal" % (g, q), d, d)
+        self.conv_bn(g + ".channel_conv", d, d, 3)
+        self.plain(p + ".proj_2", d, d, 1)
+
+    def darknet(self, p: str, dep: float, wid: float, depthwise: bool, attention: bool = False):
         base, depth = int(wid * 64), max(round(dep * 3), 1)
         self.conv_bn(p + ".stem.conv", 12, base, 3)
         for i, (name, mult, n) in enumerate((("dark2", 2, depth), ("dark3", 4, depth * 3), ("dark4", 8, depth * 3))):
@@ -57,6 +66,9 @@ class _Table(OrderedDict):
         self.conv_bn(p + ".dark5.1.conv1", base * 16, base * 8, 1)
         self.conv_bn(p + ".dark5.1.conv2", base * 8 * 4, base * 16, 1)
         self.csp(p + ".dark5.2", base * 16, base * 16, depth, depthwise)
+        if attention:                       # drone/models/new/darknet_att.py:161-164
+            for i, mult in enumerate((2, 4, 8, 16)):
+                self.attention("%s.lsk%d" % (p, i + 2), base * mult)
 
     def nonlocal_block(self, p: str, cin: int, ci: int):
         self.plain(p + ".g", cin, ci, 1)
@@ -101,7 +113,10 @@ def cross_head_table(t: "_Table", h: str, num_classes: int, wid: float, dw: bool
         t.any_conv("%s.up_convs.%d.1" % (h, i), f, f, 3, dw)
 
 
-def state_dict_shapes(kind: str, phi: str, num_classes: int) -> "OrderedDict[str, Tuple[int, ...]]":
+def state_dict_shapes(kind: str, phi: str, num_classes: int,
+                      attention_backbone: bool = False) -> "OrderedDict[str, Tuple[int, ...]]":
+    """attention_backbone=True: the backbone is new/darknet_att.py's CSPDarknet (an Attention
+    block after each stage) instead of base/darknet.py's."""
     if kind not in KINDS:
         raise ValueError("kind must be one of %r" % (KINDS,))
     if phi not in DEPTH:
@@ -112,7 +127,7 @@ def state_dict_shapes(kind: str, phi: str, num_classes: int) -> "OrderedDict[str
     n = round(3 * dep)
     t = _Table()
     b = "backbone"
-    t.darknet(b + ".backbone", dep, wid, dw)
+    t.darknet(b + ".backbone", dep, wid, dw, attention_backbone)
     t.conv_bn(b + ".lateral_conv0", c[2], c[1], 1)
     t.csp(b + ".C3_p4", (3 if kind == "gl" else 2) * c[1], c[1], n, dw)
     t.conv_bn(b + ".reduce_conv1", c[1], c[0], 1)

@@ -328,7 +328,7 @@ static int build_conv_op(const glsdet_conv_desc* d, int hint, OpRecord& op) {
   if (!d->w || !d->scale || !d->bias) GLS_FAIL(GLSDET_E_ARG, "conv2d: null weight/scale/bias");
   if (((uintptr_t)d->w | (uintptr_t)d->scale | (uintptr_t)d->bias) & 15)
     GLS_FAIL(GLSDET_E_ALIGN, "conv2d: weight/scale/bias must be 16-byte aligned");
-  if (d->act < 0 || d->act > 3) GLS_FAIL(GLSDET_E_ARG, "conv2d: bad act %d", d->act);
+  if (d->act < 0 || d->act > 5) GLS_FAIL(GLSDET_E_ARG, "conv2d: bad act %d", d->act);
   const bool has_res = d->res.base != nullptr;
   if (has_res) {
     if ((rc = check_view(d->res, "conv2d.res"))) return rc;

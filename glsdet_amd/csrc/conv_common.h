@@ -79,6 +79,8 @@ __device__ __forceinline__ float apply_act(float v, int act) {
     return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v));              // fp16 mode: v_exp + v_rcp (1 ulp each)
   }
   if (act == GLSDET_ACT_RELU) return fmaxf(v, 0.0f);
+  if (act == GLSDET_ACT_GELU) return 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
+  if (act == GLSDET_ACT_SIGMOID) return 1.0f / (1.0f + expf(-v));
   if (act == GLSDET_ACT_LRELU) return v > 0.0f ? v : 0.1f * v;
   return v;
 }

@@ -94,6 +94,57 @@ __global__ __launch_bounds__(256) void maxpool_kernel(const unsigned char* x, lo
   }
 }
 
+// ---------------------------------------------------------------- channel max / mean
+// SpatialAttention (Non_local_family.py:429-432).  One wave per pixel: lanes stride the
+// channel chunks (16 B each), max and sum reduced across the wave with shuffles.
+template <typename T>
+__global__ __launch_bounds__(256) void channel_maxmean_kernel(const unsigned char* x, long xsn, long xsh, long xsw,
+                                                              unsigned char* y, long ysn, long ysh, long ysw, int n,
+                                                              int H, int W, int C) {
+  typedef typename Vec16<T>::type V;
+  constexpr int VN = Vec16<T>::N;
+  const int lane = threadIdx.x & 63;
+  const long wave = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const long nwaves = ((long)gridDim.x * blockDim.x) >> 6;
+  const long total = (long)n * H * W;
+  for (long p = wave; p < total; p += nwaves) {
+    const int w = (int)(p % W);
+    const int h = (int)((p / W) % H);
+    const int b = (int)(p / ((long)W * H));
+    const unsigned char* px = x + (b * xsn + h * xsh + w * xsw) * (long)sizeof(T);
+    float mx = -INFINITY, sm = 0.f;
+    for (int c = lane * VN; c < C; c += 64 * VN) {
+      const V v = *reinterpret_cast<const V*>(px + c * (long)sizeof(T));
+#pragma unroll
+      for (int e = 0; e < VN; ++e) {
+        const float f = (float)v[e];
+        mx = fmaxf(mx, f);
+        sm += f;
+      }
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+      mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+      sm += __shfl_xor(sm, o, 64);
+    }
+    if (lane == 0) {
+      V out;
+#pragma unroll
+      for (int e = 0; e < VN; ++e) out[e] = (T)0.f;
+      out[0] = (T)mx;
+      out[1] = (T)(sm / (float)C);
+      T* o = reinterpret_cast<T*>(y) + b * ysn + h * ysh + w * ysw;
+      *reinterpret_cast<V*>(o) = out;
+      if (VN == 4) {
+        V z;
+#pragma unroll
+        for (int e = 0; e < VN; ++e) z[e] = (T)0.f;
+        *reinterpret_cast<V*>(o + 4) = z;
+      }
+    }
+  }
+}
+
 // ---------------------------------------------------------------- nearest resample / copy
 template <typename T>
 __global__ __launch_bounds__(256) void resample_kernel(const unsigned char* x, long xsn, long xsh, long xsw,
@@ -155,97 +206,113 @@ __global__ __launch_bounds__(256) void nl_gram_kernel(const unsigned char* tpg, 
 }
 
 // P[b][co][c1] = (1/N) sum_c2 Wout[co][c2] * (sum_z Gp[z][b][c1][c2]).  Workgroup = (image,
-// 16 output channels).  The partial Gram slices are summed into LDS with all 8 slice loads
-// of an element in flight (fixed order -> deterministic); a wave then owns one output
-// channel at a time, so its weight row is wave-uniform (scalar loads) while lanes walk c1.
+// 16 output channels, 64 rows c1).  The Gram rows are walked in c2 chunks of kc (<= 128)
+// columns: the partial slices of a chunk are summed into LDS with all 8 slice loads of an
+// element in flight (fixed order -> deterministic); a wave owns 4 output channels, so its
+// weight rows are wave-uniform (scalar loads) while lanes are the c1 rows (stride kc+1,
+// conflict-free).  Any ci works: LDS holds one chunk, never the whole Gram.
 #define GLS_FOLD_CO 16
+#define GLS_NL_KC 128
 __global__ __launch_bounds__(256) void nl_fold_kernel(const float* __restrict__ Gp, int nsplit, int nimg,
                                                       const float* __restrict__ wout, int ci, int cx, float invN,
-                                                      float* P) {
-  extern __shared__ float gs[];   // [ci][ci+1]
-  const int b = blockIdx.x, co0 = blockIdx.y * GLS_FOLD_CO, ld = ci + 1;
+                                                      float* P, int kc) {
+  extern __shared__ float gs[];   // [64][kc+1]
+  const int b = blockIdx.x, co0 = blockIdx.y * GLS_FOLD_CO, c1_0 = blockIdx.z * 64, ld = kc + 1;
   const long slice = (long)nimg * ci * ci;
-  for (int e = threadIdx.x; e < ci * ci; e += 256) {
-    const float* g = Gp + (long)b * ci * ci + e;
-    float v[8];
-#pragma unroll
-    for (int z = 0; z < 8; ++z) v[z] = z < nsplit ? g[z * slice] : 0.f;
-    float acc = v[0];
-#pragma unroll
-    for (int z = 1; z < 8; ++z) acc += v[z];
-    gs[(e / ci) * ld + (e % ci)] = acc;
-  }
-  __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int col = wave; col < GLS_FOLD_CO; col += 4) {
-    const int co = co0 + col;
-    if (co >= cx) break;
-    const float* w = wout + (long)co * ci;          // wave-uniform row
-    for (int c1 = lane; c1 < ci; c1 += 64) {
-      const float* g = gs + c1 * ld;
-      float acc = 0.f;
+  const float* w[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) w[q] = wout + (long)min(co0 + wave * 4 + q, cx - 1) * ci;   // wave-uniform rows
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int c2_0 = 0; c2_0 < ci; c2_0 += kc) {
+    const int kn = min(kc, ci - c2_0);
+    for (int e = threadIdx.x; e < 64 * kc; e += 256) {
+      const int r = e / kc, c = e - r * kc;
+      float a = 0.f;
+      if (c1_0 + r < ci && c < kn) {
+        const float* g = Gp + ((long)b * ci + c1_0 + r) * ci + c2_0 + c;
+        float v[8];
+#pragma unroll
+        for (int z = 0; z < 8; ++z) v[z] = z < nsplit ? g[z * slice] : 0.f;
+        a = v[0];
+#pragma unroll
+        for (int z = 1; z < 8; ++z) a += v[z];
+      }
+      gs[r * ld + c] = a;
+    }
+    __syncthreads();
+    const float* g = gs + lane * ld;
 #pragma unroll 8
-      for (int c2 = 0; c2 < ci; ++c2) acc += w[c2] * g[c2];
-      P[((long)b * cx + co) * ci + c1] = acc * invN;
+    for (int c = 0; c < kn; ++c) {
+      const float gv = g[c];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) acc[q] += w[q][c2_0 + c] * gv;
+    }
+    __syncthreads();
+  }
+  const int c1 = c1_0 + lane;
+  if (c1 < ci) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int co = co0 + wave * 4 + q;
+      if (co < cx) P[((long)b * cx + co) * ci + c1] = acc[q] * invN;
     }
   }
 }
 
 // out[b,i,co] = x[b,i,co] + bout[co] + sum_c1 theta[b,i,c1] * P[b][co][c1]
-// Workgroup = 64 pixels x 32 output channels of one image.  theta tile [64][ci+1] and the P
-// rows [32][ci] live in LDS; lanes are pixels (theta rows conflict-free), a wave owns 8
-// output channels (P reads are broadcasts), 4 accumulators per thread share each theta read.
+// Workgroup = 64 pixels x 32 output channels of one image.  c1 is walked in chunks of kc:
+// a theta tile [64][kc+1] and the P rows [32][kc] live in LDS; lanes are pixels (theta rows
+// conflict-free), a wave owns 8 output channels (P reads are broadcasts), whose 8
+// accumulators share each theta read and persist across the chunks.
 #define GLS_APPLY_CO 32
 template <typename T>
 __global__ __launch_bounds__(256) void nl_apply_kernel(const unsigned char* x, long xsn, long xsh, long xsw,
                                                        const unsigned char* tpg, long tsn, long tsh, long tsw,
                                                        unsigned char* out, long osn, long osh, long osw, int H, int W,
                                                        int ci, int cx, const float* __restrict__ P,
-                                                       const float* __restrict__ bout) {
-  extern __shared__ float th[];   // [64][ci+1] theta, then [GLS_APPLY_CO][ci] P rows
+                                                       const float* __restrict__ bout, int kc) {
+  extern __shared__ float th[];   // [64][kc+1] theta, then [GLS_APPLY_CO][kc] P rows
   const int N = H * W;
   const int b = blockIdx.y, j0 = blockIdx.x * 64, co0 = blockIdx.z * GLS_APPLY_CO;
-  const int ld = ci + 1;
+  const int ld = kc + 1;
   float* pr = th + 64 * ld;
-  for (int idx = threadIdx.x; idx < 64 * ci; idx += 256) {
-    const int jj = idx / ci, c = idx - jj * ci;
-    const int j = j0 + jj;
-    float v = 0.f;
-    if (j < N) v = (float)(reinterpret_cast<const T*>(tpg) + b * tsn + (j / W) * tsh + (j % W) * tsw)[c];
-    th[jj * ld + c] = v;
-  }
-  for (int idx = threadIdx.x; idx < GLS_APPLY_CO * ci; idx += 256) {
-    const int r = idx / ci, c = idx - r * ci;
-    pr[idx] = (co0 + r) < cx ? P[((long)b * cx + co0 + r) * ci + c] : 0.f;
-  }
-  __syncthreads();
   const int jj = threadIdx.x & 63, grp = threadIdx.x >> 6;
   const int j = j0 + jj;
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int c0 = 0; c0 < ci; c0 += kc) {
+    const int kn = min(kc, ci - c0);
+    for (int idx = threadIdx.x; idx < 64 * kn; idx += 256) {
+      const int r = idx / kn, c = idx - r * kn;
+      const int jr = j0 + r;
+      float v = 0.f;
+      if (jr < N) v = (float)(reinterpret_cast<const T*>(tpg) + b * tsn + (jr / W) * tsh + (jr % W) * tsw)[c0 + c];
+      th[r * ld + c] = v;
+    }
+    for (int idx = threadIdx.x; idx < GLS_APPLY_CO * kn; idx += 256) {
+      const int r = idx / kn, c = idx - r * kn;
+      pr[r * kc + c] = (co0 + r) < cx ? P[((long)b * cx + co0 + r) * ci + c0 + c] : 0.f;
+    }
+    __syncthreads();
+    const float* t = th + jj * ld;
+    const float* p0 = pr + grp * 8 * kc;
+#pragma unroll 4
+    for (int c = 0; c < kn; ++c) {
+      const float tv = t[c];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) acc[q] += tv * p0[q * kc + c];
+    }
+    __syncthreads();
+  }
   if (j >= N) return;
   const long poff_x = b * xsn + (j / W) * xsh + (j % W) * xsw;
   const long poff_o = b * osn + (j / W) * osh + (j % W) * osw;
-  const float* t = th + jj * ld;
 #pragma unroll
-  for (int half = 0; half < 2; ++half) {
-    const int r0 = grp * 8 + half * 4;              // 4 consecutive output channels
-    const float* p0 = pr + r0 * ci;
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-#pragma unroll 8
-    for (int c = 0; c < ci; ++c) {
-      const float tv = t[c];
-      a0 += tv * p0[c];
-      a1 += tv * p0[ci + c];
-      a2 += tv * p0[2 * ci + c];
-      a3 += tv * p0[3 * ci + c];
-    }
-    const float acc[4] = {a0, a1, a2, a3};
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int co = co0 + r0 + e;
-      if (co < cx) {
-        const float xv = (float)(reinterpret_cast<const T*>(x) + poff_x)[co];
-        (reinterpret_cast<T*>(out) + poff_o)[co] = (T)(xv + bout[co] + acc[e]);
-      }
+  for (int q = 0; q < 8; ++q) {
+    const int co = co0 + grp * 8 + q;
+    if (co < cx) {
+      const float xv = (float)(reinterpret_cast<const T*>(x) + poff_x)[co];
+      (reinterpret_cast<T*>(out) + poff_o)[co] = (T)(xv + bout[co] + acc[q]);
     }
   }
 }
@@ -314,6 +381,31 @@ extern "C" int glsdet_maxpool2d(const glsdet_view* x, const glsdet_view* y, int3
   return submit(std::move(op), stream);
 }
 
+extern "C" int glsdet_channel_maxmean(const glsdet_view* x, const glsdet_view* y, void* stream) {
+  if (!x || !y) GLS_FAIL(GLSDET_E_ARG, "channel_maxmean: null argument");
+  int rc;
+  if ((rc = check_view(*x, "channel_maxmean.x"))) return rc;
+  if ((rc = check_view(*y, "channel_maxmean.y"))) return rc;
+  if (x->dtype != y->dtype || y->n != x->n || y->h != x->h || y->w != x->w || y->c != 8 || x->c % 8)
+    GLS_FAIL(GLSDET_E_ARG, "channel_maxmean: y must be [n,h,w,8] of x's dtype, x.c a multiple of 8");
+  const glsdet_view a = *x, b = *y;
+  OpRecord op;
+  op.kind = 2;
+  op.flops = 0;
+  op.bytes = (double)a.n * a.h * a.w * (a.c + 8) * dtype_size(a.dtype);
+  op.name = "channel_maxmean";
+  op.launch = [=](hipStream_t st) -> int {
+    const unsigned g = grid_for((long)a.n * a.h * a.w * 64);
+    if (a.dtype == GLSDET_F16)
+      hipLaunchKernelGGL(channel_maxmean_kernel<f16>, dim3(g), dim3(256), 0, st, (const unsigned char*)a.base, a.sn, a.sh, a.sw, (unsigned char*)b.base, b.sn, b.sh, b.sw, a.n, a.h, a.w, a.c);
+    else
+      hipLaunchKernelGGL(channel_maxmean_kernel<float>, dim3(g), dim3(256), 0, st, (const unsigned char*)a.base, a.sn, a.sh, a.sw, (unsigned char*)b.base, b.sn, b.sh, b.sw, a.n, a.h, a.w, a.c);
+    GLS_HIP(hipGetLastError());
+    return 0;
+  };
+  return submit(std::move(op), stream);
+}
+
 extern "C" int glsdet_resample_copy(const glsdet_view* x, const glsdet_view* y, int32_t factor, void* stream) {
   if (!x || !y) GLS_FAIL(GLSDET_E_ARG, "resample_copy: null argument");
   int rc;
@@ -354,7 +446,6 @@ extern "C" int glsdet_nonlocal(const glsdet_view* x, const glsdet_view* tpg, int
   if (tpg->n != x->n || tpg->h != x->h || tpg->w != x->w || ci < 1 || tpg->c < 3 * ci)
     GLS_FAIL(GLSDET_E_ARG, "nonlocal: theta|phi|g view must be [n,h,w,>=3*ci]");
   const int cx = x->c;
-  if ((long)ci * (ci + 1) * 4 > 150 * 1024) GLS_FAIL(GLSDET_E_ARG, "nonlocal: ci=%d too large for the LDS tile", ci);
   const glsdet_view vx = *x, vt = *tpg, vo = *out;
   const int N = vx.h * vx.w;
   OpRecord op;
@@ -368,20 +459,19 @@ extern "C" int glsdet_nonlocal(const glsdet_view* x, const glsdet_view* tpg, int
   float* P = gram + (long)vx.n * 8 * ci * ci;
   op.launch = [=](hipStream_t st) -> int {
     const int nb = (ci + 15) / 16;
-    const dim3 g1(nb * nb, vx.n, nsplit), g2(vx.n, (cx + GLS_FOLD_CO - 1) / GLS_FOLD_CO), g3((N + 63) / 64, vx.n, (cx + GLS_APPLY_CO - 1) / GLS_APPLY_CO);
-    const size_t lds2 = (size_t)ci * (ci + 1) * 4;
-    if (lds2 > 64 * 1024) GLS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(nl_fold_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
-    const size_t lds3 = ((size_t)64 * (ci + 1) + (size_t)GLS_APPLY_CO * ci) * 4;
+    const int kc = ci < GLS_NL_KC ? ci : GLS_NL_KC;
+    const dim3 g1(nb * nb, vx.n, nsplit), g2(vx.n, (cx + GLS_FOLD_CO - 1) / GLS_FOLD_CO, (ci + 63) / 64),
+        g3((N + 63) / 64, vx.n, (cx + GLS_APPLY_CO - 1) / GLS_APPLY_CO);
+    const size_t lds2 = (size_t)64 * (kc + 1) * 4;
+    const size_t lds3 = ((size_t)64 * (kc + 1) + (size_t)GLS_APPLY_CO * kc) * 4;
     if (vx.dtype == GLSDET_F16) {
       hipLaunchKernelGGL(nl_gram_kernel<f16>, g1, dim3(256), 0, st, (const unsigned char*)vt.base, vt.sn, vt.sh, vt.sw, vt.h, vt.w, ci, jchunk, gram);
-      hipLaunchKernelGGL(nl_fold_kernel, g2, dim3(256), lds2, st, gram, nsplit, vx.n, wout, ci, cx, 1.0f / (float)N, P);
-      if (lds3 > 64 * 1024) GLS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(nl_apply_kernel<f16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3));
-      hipLaunchKernelGGL(nl_apply_kernel<f16>, g3, dim3(256), lds3, st, (const unsigned char*)vx.base, vx.sn, vx.sh, vx.sw, (const unsigned char*)vt.base, vt.sn, vt.sh, vt.sw, (unsigned char*)vo.base, vo.sn, vo.sh, vo.sw, vx.h, vx.w, ci, cx, P, bout);
+      hipLaunchKernelGGL(nl_fold_kernel, g2, dim3(256), lds2, st, gram, nsplit, vx.n, wout, ci, cx, 1.0f / (float)N, P, kc);
+      hipLaunchKernelGGL(nl_apply_kernel<f16>, g3, dim3(256), lds3, st, (const unsigned char*)vx.base, vx.sn, vx.sh, vx.sw, (const unsigned char*)vt.base, vt.sn, vt.sh, vt.sw, (unsigned char*)vo.base, vo.sn, vo.sh, vo.sw, vx.h, vx.w, ci, cx, P, bout, kc);
     } else {
       hipLaunchKernelGGL(nl_gram_kernel<float>, g1, dim3(256), 0, st, (const unsigned char*)vt.base, vt.sn, vt.sh, vt.sw, vt.h, vt.w, ci, jchunk, gram);
-      hipLaunchKernelGGL(nl_fold_kernel, g2, dim3(256), lds2, st, gram, nsplit, vx.n, wout, ci, cx, 1.0f / (float)N, P);
-      if (lds3 > 64 * 1024) GLS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(nl_apply_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3));
-      hipLaunchKernelGGL(nl_apply_kernel<float>, g3, dim3(256), lds3, st, (const unsigned char*)vx.base, vx.sn, vx.sh, vx.sw, (const unsigned char*)vt.base, vt.sn, vt.sh, vt.sw, (unsigned char*)vo.base, vo.sn, vo.sh, vo.sw, vx.h, vx.w, ci, cx, P, bout);
+      hipLaunchKernelGGL(nl_fold_kernel, g2, dim3(256), lds2, st, gram, nsplit, vx.n, wout, ci, cx, 1.0f / (float)N, P, kc);
+      hipLaunchKernelGGL(nl_apply_kernel<float>, g3, dim3(256), lds3, st, (const unsigned char*)vx.base, vx.sn, vx.sh, vx.sw, (const unsigned char*)vt.base, vt.sn, vt.sh, vt.sw, (unsigned char*)vo.base, vo.sn, vo.sh, vo.sw, vx.h, vx.w, ci, cx, P, bout, kc);
     }
     GLS_HIP(hipGetLastError());
     return 0;

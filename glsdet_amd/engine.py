@@ -241,6 +241,13 @@ class Engine:
                                          _stream_ptr(self.stream)), "focus_pack")
         return out
 
+    def channel_maxmean(self, x: TView, out: Optional[TView] = None) -> TView:
+        if out is None:
+            out = self.tensor(x.n, x.h, x.w, 8, x.dtype)
+        check(self.lib.glsdet_channel_maxmean(C.byref(x.as_c()), C.byref(out.as_c()), _stream_ptr(self.stream)),
+              "channel_maxmean")
+        return out
+
     def maxpool(self, x: TView, k: int, out: Optional[TView] = None) -> TView:
         if out is None:
             out = self.tensor(x.n, x.h, x.w, x.c, x.dtype)

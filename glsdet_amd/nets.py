@@ -96,10 +96,11 @@ class NetBuilder:
             c0 += co
         return out
 
-    def plain(self, p: str, x: TView, pad: int = 0, out: Optional[TView] = None) -> TView:
-        """nn.Conv2d with bias, no norm / activation."""
+    def plain(self, p: str, x: TView, pad: int = 0, out: Optional[TView] = None, act: str = "none",
+              res: Optional[TView] = None) -> TView:
+        """nn.Conv2d with bias, no norm; activation / residual add only where the caller fuses one."""
         pk = self._pack(p, [self._plain_part(p)], x.c)
-        return self.e.conv(x, pk, 1, pad, "none", out=out)
+        return self.e.conv(x, pk, 1, pad, act, out=out, res=res)
 
     def conv_out_channels(self, p: str) -> int:
         if self.is_depthwise(p):
@@ -132,13 +133,22 @@ class NetBuilder:
         f = {}
         x = self.e.focus_pack(img)
         x = self.cba(p + ".stem.conv", x)
-        for name in ("dark2", "dark3", "dark4"):
+        att = lambda i: self.has("%s.lsk%d.proj_1.weight" % (p, i))     # new/darknet_att.py:161-201
+        for i, name in enumerate(("dark2", "dark3", "dark4")):
             x = self.cba("%s.%s.0" % (p, name), x, 2)
-            x = self.csp("%s.%s.1" % (p, name), x, True, out=homes.get(name))
+            if att(i + 2):
+                x = self.csp("%s.%s.1" % (p, name), x, True)
+                x = self.attention("%s.lsk%d" % (p, i + 2), x, out=homes.get(name))
+            else:
+                x = self.csp("%s.%s.1" % (p, name), x, True, out=homes.get(name))
             f[name] = x
         x = self.cba(p + ".dark5.0", x, 2)
         x = self.spp(p + ".dark5.1", x)
-        x = self.csp(p + ".dark5.2", x, False, out=homes.get("dark5"))
+        if att(5):
+            x = self.csp(p + ".dark5.2", x, False)
+            x = self.attention(p + ".lsk5", x, out=homes.get("dark5"))
+        else:
+            x = self.csp(p + ".dark5.2", x, False, out=homes.get("dark5"))
         f["dark5"] = x
         return f
 
@@ -187,6 +197,32 @@ class NetBuilder:
         if self.has(p + ".channel_conv.weight"):
             return self.plain(p + ".channel_conv", Z, out=out)
         return self.cba(p + ".channel_conv", Z, out=out)
+
+    def patch_conv_nonlocal_new(self, p: str, x: TView, out: Optional[TView] = None) -> TView:
+        """Patch_Conv_NonLocal_new (new/Non_local_family.py:208-252).  The four quadrant
+        non-local blocks run IN PLACE on windows of x (x is consumed), so the re-stitch is free."""
+        hh, hw = x.h // 2, x.w // 2
+        for bi, (name, win) in enumerate((("lt", x.window(0, hh, 0, hw)), ("lb", x.window(hh, x.h, 0, hw)),
+                                          ("rt", x.window(0, hh, hw, x.w)), ("rb", x.window(hh, x.h, hw, x.w)))):
+            self.e.branch(bi + 1)
+            self.nonlocal_block("%s.feat_patchconv_%s_nonlocal" % (p, name), win)
+        self.e.branch(0)
+        if self.has(p + ".channel_conv.weight"):
+            return self.plain(p + ".channel_conv", x, out=out)
+        return self.cba(p + ".channel_conv", x, out=out)
+
+    def attention(self, p: str, x: TView, out: Optional[TView] = None) -> TView:
+        """Attention (new/Non_local_family.py:254-272): proj_1 + exact GELU fused in one 1x1
+        GEMM epilogue, gating unit, proj_2 with the shortcut add fused as the residual."""
+        t = self.plain(p + ".proj_1", x, act="gelu")
+        t = self.patch_conv_nonlocal_new(p + ".spatial_gating_unit", t)
+        return self.plain(p + ".proj_2", t, out=out, res=x)
+
+    def spatial_attention(self, p: str, x: TView) -> TView:
+        """SpatialAttention (new/Non_local_family.py:423-436) -> [n,h,w,8] view, channel 0 valid."""
+        k = self.sd[p + ".conv.weight"].shape[-1]
+        mm = self.e.channel_maxmean(x)
+        return self.plain(p + ".conv", mm, pad=k // 2, act="sigmoid")
 
     def identity_conv(self, p: str, x: TView, out: Optional[TView] = None) -> TView:
         k = self.sd[p + ".conv.weight"].shape[-1]

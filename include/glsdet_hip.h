@@ -32,7 +32,8 @@ extern "C" {
 #define GLSDET_ABI_VERSION 2
 
 enum { GLSDET_F16 = 0, GLSDET_F32 = 1 };
-enum { GLSDET_ACT_NONE = 0, GLSDET_ACT_SILU = 1, GLSDET_ACT_RELU = 2, GLSDET_ACT_LRELU = 3 };
+enum { GLSDET_ACT_NONE = 0, GLSDET_ACT_SILU = 1, GLSDET_ACT_RELU = 2, GLSDET_ACT_LRELU = 3,
+       GLSDET_ACT_GELU = 4 /* exact erf form, nn.GELU() */, GLSDET_ACT_SIGMOID = 5 };
 enum {
   GLSDET_OK = 0,
   GLSDET_E_ARG = -1,      /* inconsistent shapes / unsupported parameter            */
@@ -104,6 +105,11 @@ int glsdet_focus_pack(const float* img, int32_t n, int32_t cin, int32_t H, int32
 
 /* max pool k x k, stride 1, pad k/2 (-inf padding)   drone/models/base/darknet.py:29,35 */
 int glsdet_maxpool2d(const glsdet_view* x, const glsdet_view* y, int32_t k, void* stream);
+
+/* SpatialAttention front half (drone/models/new/Non_local_family.py:429-432): per pixel the max
+ * and the mean over channels.  y: view [n,h,w,8] of x.dtype, channel 0 = max, 1 = mean, 2..7 = 0
+ * (the 7x7 2->1 conv + sigmoid that follows is a glsdet_conv2d with GLSDET_ACT_SIGMOID).     */
+int glsdet_channel_maxmean(const glsdet_view* x, const glsdet_view* y, void* stream);
 
 /* nearest-neighbour resample by an integer factor (1 = strided copy, 2 = nn.Upsample(2))
  * drone/models/base/yolox.py:103,181,198 ; torch.cat is realised by views, not copies.   */

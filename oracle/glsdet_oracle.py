@@ -115,13 +115,17 @@ def csp_darknet(sd: SD, p: str, x: Tensor) -> Dict[str, Tensor]:
     out = {}
     x = focus(sd, p + ".stem", x)
     out["stem"] = x
-    for name in ("dark2", "dark3", "dark4"):
+    att = lambda i, t: attention(sd, "{}.lsk{}".format(p, i), t) \
+        if "{}.lsk{}.proj_1.weight".format(p, i) in sd else t       # new/darknet_att.py:176-201
+    for i, name in enumerate(("dark2", "dark3", "dark4")):
         x = any_conv(sd, "{}.{}.0".format(p, name), x, 2)
         x = csp_layer(sd, "{}.{}.1".format(p, name), x, True)
+        x = att(i + 2, x)
         out[name] = x
     x = any_conv(sd, p + ".dark5.0", x, 2)
     x = spp_bottleneck(sd, p + ".dark5.1", x)
     x = csp_layer(sd, p + ".dark5.2", x, False)
+    x = att(5, x)
     out["dark5"] = x
     return out
 
@@ -186,6 +190,42 @@ def patch_conv(sd: SD, p: str, x: Tensor, stride: int, nonlocal_: bool) -> Tenso
     if p + ".channel_conv.weight" in sd:           # channel_cat == 'linear'
         return plain_conv(sd, p + ".channel_conv", both)
     return base_conv(sd, p + ".channel_conv", both)
+
+
+def patch_conv_nonlocal_new(sd: SD, p: str, x: Tensor) -> Tensor:
+    """Patch_Conv_NonLocal_new (drone/models/new/Non_local_family.py:208-252): a non-local block
+    on each floor-split quadrant AT the input resolution, re-stitch, then channel_conv
+    (BaseConv 3x3 for channel_cat='non_linear', Conv2d 1x1+bias for 'linear')."""
+    lt, lb, rt, rb = _quadrants(x)
+    q = {name: non_local_block(sd, "{}.feat_patchconv_{}_nonlocal".format(p, name), t)
+         for name, t in (("lt", lt), ("lb", lb), ("rt", rt), ("rb", rb))}
+    top = torch.cat((q["lt"], q["rt"]), 3)
+    bot = torch.cat((q["lb"], q["rb"]), 3)
+    both = torch.cat((top, bot), 2)
+    if p + ".channel_conv.weight" in sd:
+        return plain_conv(sd, p + ".channel_conv", both)
+    return base_conv(sd, p + ".channel_conv", both)
+
+
+def attention(sd: SD, p: str, x: Tensor) -> Tensor:
+    """Attention (Non_local_family.py:254-272): proj_1 1x1 -> exact GELU -> quadrant non-local
+    gating unit -> proj_2 1x1 -> + shortcut."""
+    y = F.gelu(plain_conv(sd, p + ".proj_1", x))
+    y = patch_conv_nonlocal_new(sd, p + ".spatial_gating_unit", y)
+    return plain_conv(sd, p + ".proj_2", y) + x
+
+
+def spatial_attention(sd: SD, p: str, x: Tensor) -> Tensor:
+    """SpatialAttention (Non_local_family.py:423-436): sigmoid(conv7x7([max_c x, mean_c x]))."""
+    k = sd[p + ".conv.weight"].shape[-1]
+    r = torch.cat((x.max(1, keepdim=True)[0], x.mean(1, keepdim=True)), 1)
+    return torch.sigmoid(plain_conv(sd, p + ".conv", r, 1, k // 2))
+
+
+def csp_darknet_att(sd: SD, p: str, x: Tensor) -> Dict[str, Tensor]:
+    """drone/models/new/darknet_att.py:120-203: CSPDarknet with an Attention block (lsk2..lsk5)
+    after every stage.  csp_darknet() below applies them when the keys are present."""
+    return csp_darknet(sd, p, x)
 
 
 def identity_conv(sd: SD, p: str, x: Tensor) -> Tensor:

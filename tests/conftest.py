@@ -19,6 +19,12 @@ def golden():
 
 
 @pytest.fixture(scope="session")
+def att_golden():
+    import numpy as np
+    return np.load(os.path.join(ROOT, "tests", "golden", "attention_golden.npz"))
+
+
+@pytest.fixture(scope="session")
 def shapes():
     import json
     with open(os.path.join(ROOT, "tests", "golden", "shapes.json")) as f:

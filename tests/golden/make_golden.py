@@ -68,6 +68,29 @@ def calibrate_bn(net, x, seed):
             if k.endswith("running_mean") or k.endswith("running_var")}
 
 
+def attention_cases(block):
+    """SURVEY section 8a row A6': the other GL attention variants the tree holds
+    (drone/models/new/Non_local_family.py, new/darknet_att.py)."""
+    from models.new.Non_local_family import Attention, Patch_Conv_NonLocal_new, SpatialAttention
+    from models.new.darknet_att import CSPDarknet as AttDarknet
+    block("att_pcnl_new_nonlinear", lambda: Patch_Conv_NonLocal_new(32, 32, channel_scale=1), (2, 32, 20, 24))
+    block("att_pcnl_new_linear", lambda: Patch_Conv_NonLocal_new(32, 48, channel_scale=1, channel_cat="linear"),
+          (2, 32, 21, 27))
+    block("att_attention_c32", lambda: Attention(32), (2, 32, 20, 24))
+    block("att_attention_c48_odd", lambda: Attention(48), (1, 48, 17, 23))
+    block("att_spatial_attention", lambda: SpatialAttention(7), (2, 32, 20, 24))
+
+    class Outs(torch.nn.Module):            # dict -> tuple so that block() can store it
+        def __init__(self):
+            super().__init__()
+            self.backbone = AttDarknet(0.33, 0.375, out_features=("dark2", "dark3", "dark4", "dark5"))
+
+        def forward(self, x):
+            f = self.backbone(x)
+            return torch.cat([f[k].flatten(1) for k in ("dark2", "dark3", "dark4", "dark5")], 1)
+    block("att_darknet_tiny", Outs, (1, 3, 128, 160), calibrate=True)
+
+
 def main():
     from models.base import yolox as ref_base
     from models.base.baseConv import BaseConv, DWConv
@@ -90,10 +113,13 @@ def main():
     out = {}
 
     # ------------------------------------------------------------------ blocks
-    def block(tag, ctor, in_shape, seed=0):
+    def block(tag, ctor, in_shape, seed=0, calibrate=False):
         m = ctor()
         shapes = fill(m, seed)
         x = synth_input(in_shape, seed + 100)
+        if calibrate:
+            for k, v in calibrate_bn(m, x, seed).items():
+                out["block/%s/bn/%s" % (tag, k)] = v
         y = m(x)
         out["block/%s/y" % tag] = y.numpy()
         out["block/%s/meta" % tag] = np.frombuffer(json.dumps(
@@ -169,6 +195,9 @@ def main():
             xy.copy(), wh.copy(), [640, 640], np.array([540, 1024]), lb)
     out["correct_boxes/xy"], out["correct_boxes/wh"] = xy, wh
 
+    attention_cases(block)
+    att = {k: out.pop(k) for k in list(out) if k.startswith("block/att_") or k.startswith("attnet/")}
+    np.savez_compressed(os.path.join(HERE, "attention_golden.npz"), **att)
     np.savez_compressed(os.path.join(HERE, "drone_golden.npz"), **out)
     with open(os.path.join(HERE, "shapes.json"), "w") as f:
         json.dump(shapes_all, f, separators=(",", ":"))

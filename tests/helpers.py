@@ -16,6 +16,10 @@ def block_case(golden, tag):
     meta = meta_of(golden, "block/%s/meta" % tag)
     sd = {"m." + k: torch.from_numpy(O.synth_tensor(k, tuple(s), meta["seed"]))
           for k, s in meta["shapes"].items()}
+    pre = "block/%s/bn/" % tag                 # calibrated BN statistics, where the case stores them
+    for k in golden.files:
+        if k.startswith(pre):
+            sd["m." + k[len(pre):]] = torch.from_numpy(golden[k])
     x = O.synth_input(tuple(meta["in_shape"]), meta["seed"] + 100)
     return sd, x, torch.from_numpy(golden["block/%s/y" % tag])
 

@@ -1,0 +1,142 @@
+"""SURVEY section 8a row A6': the GL attention variants of drone/models/new/Non_local_family.py
+(Patch_Conv_NonLocal_new, Attention, SpatialAttention) and the attention backbone
+new/darknet_att.py.  Goldens come from the reference classes themselves
+(tests/golden/make_golden.py::attention_cases -> attention_golden.npz).
+
+CPU part: the oracle restatement against those goldens.  GPU part: the HIP lowering
+(NetBuilder.attention / patch_conv_nonlocal_new / spatial_attention / darknet with lsk*)
+against the same goldens, through the C ABI.  Tolerances as in test_hip_model.py:
+f32 5e-5 * max(1,|ref|) per block, f16 2e-2 * max(1,|ref|)."""
+import pytest
+import torch
+
+from oracle import glsdet_oracle as O
+from tests.helpers import block_case
+
+
+def _dark(sd, x):
+    f = O.csp_darknet_att(sd, "m.backbone", x)
+    return torch.cat([f[k].flatten(1) for k in ("dark2", "dark3", "dark4", "dark5")], 1)
+
+
+ORACLE = {
+    "att_pcnl_new_nonlinear": lambda sd, x: O.patch_conv_nonlocal_new(sd, "m", x),
+    "att_pcnl_new_linear": lambda sd, x: O.patch_conv_nonlocal_new(sd, "m", x),
+    "att_attention_c32": lambda sd, x: O.attention(sd, "m", x),
+    "att_attention_c48_odd": lambda sd, x: O.attention(sd, "m", x),
+    "att_spatial_attention": lambda sd, x: O.spatial_attention(sd, "m", x),
+    "att_darknet_tiny": _dark,
+}
+
+
+def _err(a, b):
+    return float((a - b).abs().max()) / max(1.0, float(b.abs().max()))
+
+
+@pytest.mark.parametrize("tag", sorted(ORACLE))
+def test_oracle_matches_reference(att_golden, tag):
+    sd, x, want = block_case(att_golden, tag)
+    got = ORACLE[tag](sd, x)
+    assert got.shape == want.shape
+    assert _err(got, want) <= 5e-5
+
+
+def test_every_attention_golden_is_covered(att_golden):
+    assert {k.split("/")[1] for k in att_golden.files if k.startswith("block/")} == set(ORACLE)
+
+
+# ----------------------------------------------------------------------------------- HIP
+@pytest.fixture(scope="module")
+def engines():
+    from glsdet_amd.engine import Engine
+    return {"f32": Engine("f32"), "f16": Engine("f16")}
+
+
+def _hip_dark(b, eng, x):
+    f = b.darknet("m.backbone", x.cuda(), {})
+    return torch.cat([f[k].to_nchw(f[k].c).flatten(1) for k in ("dark2", "dark3", "dark4", "dark5")], 1)
+
+
+HIP = {
+    "att_pcnl_new_nonlinear": lambda b, x: b.patch_conv_nonlocal_new("m", x),
+    "att_pcnl_new_linear": lambda b, x: b.patch_conv_nonlocal_new("m", x),
+    "att_attention_c32": lambda b, x: b.attention("m", x),
+    "att_attention_c48_odd": lambda b, x: b.attention("m", x),
+    "att_spatial_attention": lambda b, x: b.spatial_attention("m", x),
+}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["f32", "f16"])
+@pytest.mark.parametrize("tag", sorted(HIP))
+def test_hip_block_vs_reference_golden(engines, att_golden, mode, tag):
+    from glsdet_amd.nets import NetBuilder
+    from tests.test_hip_ops import _to_view
+    eng = engines[mode]
+    sd, x, want = block_case(att_golden, tag)
+    out = HIP[tag](NetBuilder(eng, sd), _to_view(eng, x))
+    torch.cuda.synchronize()
+    got = out.to_nchw(want.shape[1]).cpu()
+    tol = 5e-5 if mode == "f32" else 2e-2
+    assert _err(got, want) <= tol, "%s/%s: %.3e" % (tag, mode, _err(got, want))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["f32", "f16"])
+def test_hip_attention_backbone_vs_reference_golden(engines, att_golden, mode):
+    """new/darknet_att.py CSPDarknet (Attention after every stage), all four stage outputs."""
+    from glsdet_amd.nets import NetBuilder
+    eng = engines[mode]
+    sd, x, want = block_case(att_golden, "att_darknet_tiny")
+    got = _hip_dark(NetBuilder(eng, sd), eng, x).cpu()
+    torch.cuda.synchronize()
+    assert got.shape == want.shape
+    sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
+    noise = _err(want, _dark(sd64, x.double()).float())      # the reference's own fp32 rounding noise
+    tol = max(1e-4, 2 * noise) if mode == "f32" else 5e-2
+    print("att backbone %s: err %.3e (reference-vs-fp64 %.3e)" % (mode, _err(got, want), noise))
+    assert _err(got, want) <= tol
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["f32", "f16"])
+@pytest.mark.parametrize("c", [8, 64, 200])
+def test_channel_maxmean(engines, mode, c):
+    from tests.test_hip_ops import _to_view
+    eng = engines[mode]
+    x = O.synth_input((2, c, 9, 11), c)
+    xr = x.half().float() if mode == "f16" else x
+    out = eng.channel_maxmean(_to_view(eng, x, embed=(c + 16, 8)))
+    torch.cuda.synchronize()
+    got = out.to_nchw(8).cpu()
+    assert float((got[:, 0] - xr.max(1)[0]).abs().max()) == 0.0
+    assert float((got[:, 1] - xr.mean(1)).abs().max()) <= (1e-6 if mode == "f32" else 2e-3)
+    assert float(got[:, 2:].abs().max()) == 0.0
+
+
+def test_arch_table_equals_the_reference_attention_backbone(att_golden):
+    """glsdet_amd.arch with attention_backbone=True lists new/darknet_att.py's state_dict
+    (names, shapes, registration order) -- taken from the golden's recorded reference shapes."""
+    from glsdet_amd.arch import state_dict_shapes
+    from tests.helpers import meta_of
+    ref = meta_of(att_golden, "block/att_darknet_tiny/meta")["shapes"]
+    ours = [(k[len("backbone."):], list(v)) for k, v in state_dict_shapes("base", "tiny", 10, True).items()
+            if k.startswith("backbone.backbone.")]
+    assert ours == [(k, list(v)) for k, v in ref.items()]
+
+
+@pytest.mark.gpu
+def test_detector_with_attention_backbone_vs_oracle():
+    """A whole detector whose backbone is the attention CSPDarknet (the lsk* keys switch it on)."""
+    from glsdet_amd.arch import state_dict_shapes
+    from glsdet_amd.detector import HipDetector
+    sd = O.synth_state_dict(state_dict_shapes("base", "tiny", 10, True), 2)
+    x = O.synth_input((1, 3, 96, 128), 5)
+    want = O.FORWARDS["base"](sd, x)
+    got = [g.cpu() for g in HipDetector("base", sd, dtype="f32").forward_raw(x.cuda())]
+    truth = [o.float() for o in O.FORWARDS["base"](
+        {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}, x.double())]
+    noise = max(_err(w, t) for w, t in zip(want, truth))
+    for g, w in zip(got, want):
+        assert g.shape == w.shape
+        assert _err(g, w) <= max(1e-4, 2 * noise), (_err(g, w), noise)

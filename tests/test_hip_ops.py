@@ -182,7 +182,8 @@ def test_resample(engines, mode, factor):
 
 
 @pytest.mark.parametrize("mode", ["f32", "f16"])
-@pytest.mark.parametrize("shape,ci", [((2, 16, 10, 12), 16), ((2, 32, 5, 7), 16), ((1, 64, 25, 42), 64)])
+@pytest.mark.parametrize("shape,ci", [((2, 16, 10, 12), 16), ((2, 32, 5, 7), 16), ((1, 64, 25, 42), 64),
+                                      ((1, 384, 6, 9), 384), ((2, 200, 7, 5), 136), ((1, 72, 9, 9), 264)])
 def test_nonlocal(engines, mode, shape, ci):
     from glsdet_amd.nets import NetBuilder
     eng = engines[mode]
