@@ -9,7 +9,7 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "lib", "libglsdet_hip.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 F16, F32 = 0, 1
 ACT = {"none": 0, "silu": 1, "relu": 2, "lrelu": 3, "gelu": 4, "sigmoid": 5}
@@ -57,6 +57,19 @@ _SIGS = {
     "glsdet_nms": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_float,
                              C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                              C.c_int64, C.c_void_p]),
+    "glsdet_nchw_pack": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(View), C.c_void_p]),
+    "glsdet_pool2d": (C.c_int, [C.POINTER(View), C.POINTER(View), C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "glsdet_upsample_add": (C.c_int, [C.POINTER(View), C.POINTER(View), C.c_void_p]),
+    "glsdet_groupnorm_workspace_bytes": (C.c_int64, [C.c_int32, C.c_int32]),
+    "glsdet_groupnorm": (C.c_int, [C.POINTER(View), C.POINTER(View), C.c_int32, C.c_void_p, C.c_void_p, C.c_float,
+                                   C.c_int32, C.c_void_p, C.c_void_p]),
+    "glsdet_proxy_scores": (C.c_int, [C.POINTER(View), C.POINTER(View), C.POINTER(C.c_int32), C.c_int32, C.c_float,
+                                      C.POINTER(View), C.c_void_p]),
+    "glsdet_gfl_workspace_bytes": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+    "glsdet_gfl_detect": (C.c_int, [C.POINTER(View), C.POINTER(View), C.c_int32, C.POINTER(C.c_int32), C.c_int32,
+                                    C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_float, C.c_int32,
+                                    C.c_float, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                    C.c_int64, C.c_void_p]),
     "glsdet_plan_create": (C.c_void_p, []),
     "glsdet_plan_destroy": (None, [C.c_void_p]),
     "glsdet_plan_begin": (C.c_int, [C.c_void_p]),

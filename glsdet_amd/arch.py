@@ -162,3 +162,103 @@ def state_dict_shapes(kind: str, phi: str, num_classes: int,
     for i in range(3):
         t.conv_bn("%s.stems.%d" % (h, i), c[i], f, 1)
     return t
+
+
+# ------------------------------------------------------------------------------------------
+# ResNet + FPN + GFLHead / MPHead (mmdet key names)
+RESNET_STAGE_BLOCKS = {50: (3, 4, 6, 3), 101: (3, 4, 23, 3)}       # ufp/mmdet/models/backbones/resnet.py:363-369
+
+
+def _bn(t: "_Table", p: str, c: int):
+    t[p + ".weight"] = (c,)
+    t[p + ".bias"] = (c,)
+    t[p + ".running_mean"] = (c,)
+    t[p + ".running_var"] = (c,)
+    t[p + ".num_batches_tracked"] = ()
+
+
+def resnet_table(t: "_Table", p: str, depth: int = 50, base: int = 64):
+    """torchvision-style names, resnet.py:571-598 (stem) and res_layer.py (stages)."""
+    t[p + ".conv1.weight"] = (base, 3, 7, 7)
+    _bn(t, p + ".bn1", base)
+    inplanes = base
+    for i, nblocks in enumerate(RESNET_STAGE_BLOCKS[depth]):
+        planes = base * 2 ** i
+        for j in range(nblocks):
+            q = "%s.layer%d.%d" % (p, i + 1, j)
+            t[q + ".conv1.weight"] = (planes, inplanes, 1, 1)
+            _bn(t, q + ".bn1", planes)
+            t[q + ".conv2.weight"] = (planes, planes, 3, 3)
+            _bn(t, q + ".bn2", planes)
+            t[q + ".conv3.weight"] = (planes * 4, planes, 1, 1)
+            _bn(t, q + ".bn3", planes * 4)
+            if j == 0:                      # stride != 1 or inplanes != planes*4 (res_layer.py:40)
+                t[q + ".downsample.0.weight"] = (planes * 4, inplanes, 1, 1)
+                _bn(t, q + ".downsample.1", planes * 4)
+            inplanes = planes * 4
+
+
+def fpn_table(t: "_Table", p: str, in_channels, out_channels: int, start_level: int, num_outs: int, add_extra_convs):
+    """fpn.py:105-148: all lateral convs, then all fpn convs (incl. the extra stride-2 ones)."""
+    n_lat = len(in_channels) - start_level
+    for i in range(n_lat):
+        t.plain("%s.lateral_convs.%d.conv" % (p, i), in_channels[i + start_level], out_channels, 1)
+    for i in range(n_lat):
+        t.plain("%s.fpn_convs.%d.conv" % (p, i), out_channels, out_channels, 3)
+    if add_extra_convs:
+        mode = "on_input" if add_extra_convs is True else add_extra_convs
+        for i in range(num_outs - n_lat):
+            cin = in_channels[-1] if (i == 0 and mode == "on_input") else out_channels
+            t.plain("%s.fpn_convs.%d.conv" % (p, n_lat + i), cin, out_channels, 3)
+
+
+def _gn_tower(t: "_Table", p: str, cin: int, feat: int, stacked: int):
+    for name in ("cls_convs", "reg_convs"):
+        for i in range(stacked):
+            q = "%s.%s.%d" % (p, name, i)
+            t[q + ".conv.weight"] = (feat, cin if i == 0 else feat, 3, 3)
+            t[q + ".gn.weight"] = (feat,)
+            t[q + ".gn.bias"] = (feat,)
+
+
+def gfl_head_table(t: "_Table", p: str, num_classes: int, in_channels: int = 256, feat: int = 256, stacked: int = 4,
+                   reg_max: int = 16, n_levels: int = 5):
+    """gfl_head.py:128-152 (+ Integral buffer :32-33)."""
+    _gn_tower(t, p, in_channels, feat, stacked)
+    t.plain(p + ".gfl_cls", feat, num_classes, 3)
+    t.plain(p + ".gfl_reg", feat, 4 * (reg_max + 1), 3)
+    for l in range(n_levels):
+        t["%s.scales.%d.scale" % (p, l)] = ()
+    t[p + ".integral.project"] = (reg_max + 1,)
+
+
+def mp_head_table(t: "_Table", p: str, proxies_list, in_channels: int = 256, feat: int = 256, stacked: int = 4,
+                  reg_max: int = 16, n_levels: int = 5, num_words: int = 200):
+    """mp_head.py:42-91: own parameter/buffers first, then the child modules."""
+    nc = len(proxies_list)
+    t[p + ".proxies"] = (sum(proxies_list), feat)
+    t[p + "._embedding"] = (nc + 1, num_words, feat)
+    t[p + "._pos_embedding_ptr"] = (nc + 1,)
+    t[p + "._proxies_prob"] = (sum(proxies_list),)
+    _gn_tower(t, p, in_channels, feat, stacked)
+    t.plain(p + ".gfl_cls_conv", feat, feat, 3)
+    t.plain(p + ".gfl_reg", feat, 4 * (reg_max + 1), 3)
+    for l in range(n_levels):
+        t["%s.scales.%d.scale" % (p, l)] = ()
+    t[p + ".integral.project"] = (reg_max + 1,)
+
+
+def resdet_state_dict_shapes(kind: str, num_classes: int = 10, depth: int = 50, start_level: int = 1,
+                             num_outs: int = 5, add_extra_convs="on_output", stacked: int = 4, reg_max: int = 16,
+                             proxies_list=(2, 3, 2, 5, 4, 8, 8, 4, 3, 3)) -> "OrderedDict[str, Tuple[int, ...]]":
+    """kind 'gfl': GFL r50-FPN (SingleStageDetector: backbone / neck / bbox_head); 'mpdet': MPDet."""
+    if kind not in ("gfl", "mpdet"):
+        raise ValueError("kind must be 'gfl' or 'mpdet'")
+    t = _Table()
+    resnet_table(t, "backbone", depth)
+    fpn_table(t, "neck", [256, 512, 1024, 2048], 256, start_level, num_outs, add_extra_convs)
+    if kind == "gfl":
+        gfl_head_table(t, "bbox_head", num_classes, 256, 256, stacked, reg_max, num_outs)
+    else:
+        mp_head_table(t, "bbox_head", proxies_list, 256, 256, stacked, reg_max, num_outs)
+    return t

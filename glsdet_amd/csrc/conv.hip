@@ -225,7 +225,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
       u32x4 v = *reinterpret_cast<const u32x4*>(smem + px_l * ORS + cc * 16);
       if (a.res) {
         const long ro = gls_pix_off(p, HoWo, a.Wo, a.r_sn, a.r_sh, a.r_sw, a.r_lin) + co;
-        v = add_chunk(v, *reinterpret_cast<const u32x4*>(a.res + ro * (long)sizeof(TO)), (TO*)nullptr);
+        v = add_chunk(v, *reinterpret_cast<const u32x4*>(a.res + ro * (long)sizeof(TO)), (TO*)nullptr, a.act_post);
       }
       const long yo = gls_pix_off(p, HoWo, a.Wo, a.y_sn, a.y_sh, a.y_sw, a.y_lin) + co;
       *reinterpret_cast<u32x4*>(a.y + yo * (long)sizeof(TO)) = v;
@@ -328,7 +328,7 @@ static int build_conv_op(const glsdet_conv_desc* d, int hint, OpRecord& op) {
   if (!d->w || !d->scale || !d->bias) GLS_FAIL(GLSDET_E_ARG, "conv2d: null weight/scale/bias");
   if (((uintptr_t)d->w | (uintptr_t)d->scale | (uintptr_t)d->bias) & 15)
     GLS_FAIL(GLSDET_E_ALIGN, "conv2d: weight/scale/bias must be 16-byte aligned");
-  if (d->act < 0 || d->act > 5) GLS_FAIL(GLSDET_E_ARG, "conv2d: bad act %d", d->act);
+  if (d->act < 0 || (d->act & 0xff) > 5 || (d->act & ~0x1ff)) GLS_FAIL(GLSDET_E_ARG, "conv2d: bad act %d", d->act);
   const bool has_res = d->res.base != nullptr;
   if (has_res) {
     if ((rc = check_view(d->res, "conv2d.res"))) return rc;
@@ -350,7 +350,10 @@ static int build_conv_op(const glsdet_conv_desc* d, int hint, OpRecord& op) {
   a.r_sn = d->res.sn; a.r_sh = d->res.sh; a.r_sw = d->res.sw;
   a.N = x.n; a.H = x.h; a.W = x.w; a.Cin = x.c;
   a.Ho = Ho; a.Wo = Wo; a.Cout = y.c; a.cout_pad = glsdet_conv_cout_pad(y.c);
-  a.R = d->R; a.S = d->S; a.stride = d->stride; a.pad = d->pad; a.act = d->act;
+  a.R = d->R; a.S = d->S; a.stride = d->stride; a.pad = d->pad;
+  a.act = d->act & 0xff;
+  a.act_post = 0;
+  if ((d->act & GLSDET_ACT_RES_FIRST) && has_res) { a.act_post = a.act; a.act = GLSDET_ACT_NONE; }
   a.kreal = d->R * d->S * x.c;
   a.kpad = glsdet_conv_kpad(d->R, d->S, x.c, x.dtype);
   a.M = (int)M;

@@ -162,7 +162,7 @@ __global__ __launch_bounds__(256) void conv1x1_ws_kernel(const ConvArgs a, const
           u32x4 v = *reinterpret_cast<const u32x4*>(sE + px_l * ORS + cq * 16);
           if (a.res) {
             const long ro = gls_pix_off(p, HoWo, a.Wo, a.r_sn, a.r_sh, a.r_sw, a.r_lin) + co;
-            v = add_chunk(v, *reinterpret_cast<const u32x4*>(a.res + ro * (long)sizeof(T)), (T*)nullptr);
+            v = add_chunk(v, *reinterpret_cast<const u32x4*>(a.res + ro * (long)sizeof(T)), (T*)nullptr, a.act_post);
           }
           const long yo = gls_pix_off(p, HoWo, a.Wo, a.y_sn, a.y_sh, a.y_sw, a.y_lin) + co;
           *reinterpret_cast<u32x4*>(a.y + yo * (long)sizeof(T)) = v;

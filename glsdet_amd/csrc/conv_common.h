@@ -18,6 +18,7 @@ struct ConvArgs {
   int N, H, W, Cin;
   int Ho, Wo, Cout, cout_pad;
   int R, S, stride, pad, act;
+  int act_post;             // activation applied AFTER the residual add (GLSDET_ACT_RES_FIRST), else 0
   int kreal, kpad;          // elements
   int M;                    // N*Ho*Wo
   int n_co_tiles, n_px_tiles;
@@ -94,16 +95,24 @@ __device__ __forceinline__ void store4(unsigned char* p, const float (&v)[4], fl
   f32x4 h = {v[0], v[1], v[2], v[3]};
   *reinterpret_cast<f32x4*>(p) = h;
 }
-// 16-byte chunk (+)= residual chunk, in fp32
-__device__ __forceinline__ u32x4 add_chunk(u32x4 a, u32x4 b, f16*) {
+// 16-byte chunk (+)= residual chunk, in fp32; act_post != 0: the activation follows the add
+__device__ __forceinline__ u32x4 add_chunk(u32x4 a, u32x4 b, f16*, int act_post) {
   f16x8 x = __builtin_bit_cast(f16x8, a), y = __builtin_bit_cast(f16x8, b);
 #pragma unroll
-  for (int i = 0; i < 8; ++i) x[i] = (f16)((float)x[i] + (float)y[i]);
+  for (int i = 0; i < 8; ++i) {
+    float v = (float)x[i] + (float)y[i];
+    if (act_post) v = apply_act<f16>(v, act_post);
+    x[i] = (f16)v;
+  }
   return __builtin_bit_cast(u32x4, x);
 }
-__device__ __forceinline__ u32x4 add_chunk(u32x4 a, u32x4 b, float*) {
+__device__ __forceinline__ u32x4 add_chunk(u32x4 a, u32x4 b, float*, int act_post) {
   f32x4 x = __builtin_bit_cast(f32x4, a), y = __builtin_bit_cast(f32x4, b);
   x += y;
+  if (act_post) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) x[i] = apply_act<float>(x[i], act_post);
+  }
   return __builtin_bit_cast(u32x4, x);
 }
 

@@ -215,7 +215,7 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const ConvArgs a, const 
       u32x4 v = *reinterpret_cast<const u32x4*>(smem + px_l * ORS + cq * 16);
       if (a.res) {
         const long ro = (long)img * a.r_sn + (long)ho * a.r_sh + (long)wo * a.r_sw + co;
-        v = add_chunk(v, *reinterpret_cast<const u32x4*>(a.res + ro * (long)sizeof(TO)), (TO*)nullptr);
+        v = add_chunk(v, *reinterpret_cast<const u32x4*>(a.res + ro * (long)sizeof(TO)), (TO*)nullptr, a.act_post);
       }
       const long yo = (long)img * a.y_sn + (long)ho * a.y_sh + (long)wo * a.y_sw + co;
       *reinterpret_cast<u32x4*>(a.y + yo * (long)sizeof(TO)) = v;

@@ -286,8 +286,122 @@ __global__ __launch_bounds__(1024) void nms_scan_kernel(int max_cand, int nw, in
   }
 }
 
+// ---------------------------------------------------------------------------- GFL / MPHead
+// gfl_head.py:380-471 per (image, level): sigmoid scores, (position, class) pairs above the
+// threshold, Integral (softmax expectation over reg_max+1 bins) * stride, distance2bbox from
+// the anchor centre, clamp to the image.  grid = (position blocks, image, level); a wave
+// allocates its candidates with one atomic (prefix sum of the lanes' pass counts).
+struct GflArgs {
+  const float* cls[GLS_MAX_LEVELS];
+  const float* reg[GLS_MAX_LEVELS];
+  long csn[GLS_MAX_LEVELS], csh[GLS_MAX_LEVELS], csw[GLS_MAX_LEVELS];
+  long rsn[GLS_MAX_LEVELS], rsh[GLS_MAX_LEVELS], rsw[GLS_MAX_LEVELS];
+  int H[GLS_MAX_LEVELS], W[GLS_MAX_LEVELS];
+  float stride[GLS_MAX_LEVELS];
+  int n_levels, nc, reg_max, n;
+  float in_h, in_w, thr;
+  const float* img_hw;   // optional [n][2]
+};
+
+__global__ __launch_bounds__(256) void gfl_filter_kernel(const GflArgs a, int max_cand, NmsWs ws, int* status) {
+  const int l = blockIdx.z, b = blockIdx.y;
+  const int HW = a.H[l] * a.W[l];
+  if ((int)(blockIdx.x * blockDim.x) >= HW) return;           // block-uniform
+  const int pos = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool live = pos < HW;
+  const int gy = live ? pos / a.W[l] : 0, gx = live ? pos - gy * a.W[l] : 0;
+  const float* pc = a.cls[l] + b * a.csn[l] + gy * a.csh[l] + gx * a.csw[l];
+  int npass = 0;
+  if (live)
+    for (int c = 0; c < a.nc; ++c) npass += sigmoidf_acc(pc[c]) > a.thr;
+  // wave-inclusive prefix sum of npass
+  const int lane = threadIdx.x & 63;
+  int incl = npass;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int v = __shfl_up(incl, o, 64);
+    if (lane >= o) incl += v;
+  }
+  const int total = __shfl(incl, 63, 64);
+  if (total == 0) return;                                       // wave-uniform
+  const int slot_list = b * a.n_levels + l;
+  int base0 = 0;
+  if (lane == 0) base0 = atomicAdd(&ws.cnt[slot_list], total);
+  base0 = __shfl(base0, 0, 64);
+  if (npass == 0) return;
+  int slot = base0 + incl - npass;
+  // Integral (gfl_head.py:16-49) and distance2bbox (core/bbox/transforms.py:153-165)
+  const float* pr = a.reg[l] + b * a.rsn[l] + gy * a.rsh[l] + gx * a.rsw[l];
+  const int bins = a.reg_max + 1;
+  float d[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const float* q = pr + s * bins;
+    float m = q[0];
+    for (int k = 1; k < bins; ++k) m = fmaxf(m, q[k]);
+    float den = 0.f, num = 0.f;
+    for (int k = 0; k < bins; ++k) {
+      const float e = expf(q[k] - m);
+      den += e;
+      num += e * (float)k;
+    }
+    d[s] = num / den * a.stride[l];
+  }
+  const float cx = (float)gx * a.stride[l], cy = (float)gy * a.stride[l];
+  const float mh = a.img_hw ? a.img_hw[2 * b] : a.in_h, mw = a.img_hw ? a.img_hw[2 * b + 1] : a.in_w;
+  float4 bx;
+  bx.x = fminf(fmaxf(cx - d[0], 0.f), mw);
+  bx.y = fminf(fmaxf(cy - d[1], 0.f), mh);
+  bx.z = fminf(fmaxf(cx + d[2], 0.f), mw);
+  bx.w = fminf(fmaxf(cy + d[3], 0.f), mh);
+  for (int c = 0; c < a.nc; ++c) {
+    const float sc = sigmoidf_acc(pc[c]);
+    if (!(sc > a.thr)) continue;
+    if (slot < max_cand) {
+      const long o = (long)slot_list * max_cand + slot;
+      ws.cbox[o] = bx;
+      ws.cext[o] = make_float4(sc, sc, (float)c, sc);
+      ws.canchor[o] = pos * a.nc + c;
+      ws.cscore[o] = sc;
+    } else {
+      atomicOr(status, 1);
+    }
+    ++slot;
+  }
+}
+
+// filter_scores_and_topk's top-k + the level concatenation + `rescale` (base_dense_head.py:
+// 270-272): the nms_pre best of every level's sorted list become the image's candidates.
+__global__ __launch_bounds__(256) void gfl_merge_kernel(int n_levels, int max_cand1, int nms_pre, int max_cand2, NmsWs w1,
+                                                        NmsWs w2, const float* scale) {
+  const int b = blockIdx.y;
+  int start = 0, l = 0, take = 0;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  int total = 0;
+  for (int t = 0; t < n_levels; ++t) total += min(min(w1.cnt[b * n_levels + t], max_cand1), nms_pre);
+  if (i == 0) w2.cnt[b] = total;
+  if (i >= total) return;
+  for (l = 0; l < n_levels; ++l) {
+    take = min(min(w1.cnt[b * n_levels + l], max_cand1), nms_pre);
+    if (i < start + take) break;
+    start += take;
+  }
+  const long src = (long)(b * n_levels + l) * max_cand1 + (i - start);
+  const long dst = (long)b * max_cand2 + i;
+  float4 bx = w1.sbox[src];
+  if (scale) {
+    const float* sf = scale + 4 * b;
+    bx.x /= sf[0]; bx.y /= sf[1]; bx.z /= sf[2]; bx.w /= sf[3];
+  }
+  const float4 ex = w1.sext[src];
+  w2.cbox[dst] = bx;
+  w2.cext[dst] = ex;
+  w2.canchor[dst] = i;
+  w2.cscore[dst] = ex.w;
+}
+
 static inline long align_up(long v, long a) { return (v + a - 1) / a * a; }
-static long nms_layout(int n, int max_cand, NmsWs* ws, char* base) {
+static long nms_layout(int n, int max_cand, NmsWs* ws, char* base, bool with_mask = true) {
   const int nw = (max_cand + 63) / 64;
   long off = 0;
   auto take = [&](long bytes) { long o = off; off = align_up(off + bytes, 256); return o; };
@@ -298,7 +412,7 @@ static long nms_layout(int n, int max_cand, NmsWs* ws, char* base) {
   const long o_csc = take((long)n * max_cand * 4);
   const long o_sbox = take((long)n * max_cand * 16);
   const long o_sext = take((long)n * max_cand * 16);
-  const long o_mask = take((long)n * max_cand * nw * 8);
+  const long o_mask = with_mask ? take((long)n * max_cand * nw * 8) : 0;
   if (ws && base) {
     ws->cnt = (int*)(base + o_cnt);
     ws->cbox = (float4*)(base + o_cbox);
@@ -391,6 +505,74 @@ extern "C" int glsdet_nms(const float* pred, int32_t n, int32_t A, int32_t num_c
     hipLaunchKernelGGL(nms_rank_kernel, dim3((max_cand + 63) / 64, n), dim3(256), 0, st, max_cand, ws);
     hipLaunchKernelGGL(nms_mask_kernel, dim3(2048, n), dim3(64), 0, st, max_cand, nw, nms_thres, ws);
     hipLaunchKernelGGL(nms_scan_kernel, dim3(n), dim3(1024), 0, st, max_cand, nw, max_det, ws, dets, count);
+    GLS_HIP(hipGetLastError());
+    return 0;
+  };
+  return submit(std::move(op), stream);
+}
+
+extern "C" int64_t glsdet_gfl_workspace_bytes(int32_t n, int32_t n_levels, int32_t max_cand, int32_t nms_pre) {
+  if (n < 1 || n_levels < 1 || n_levels > GLS_MAX_LEVELS || max_cand < 1 || nms_pre < 1) return 0;
+  return nms_layout(n * n_levels, max_cand, nullptr, nullptr, false) + 256 +
+         nms_layout(n, n_levels * nms_pre, nullptr, nullptr, true);
+}
+
+extern "C" int glsdet_gfl_detect(const glsdet_view* cls, const glsdet_view* reg, int32_t n_levels,
+                                 const int32_t* strides, int32_t num_classes, int32_t reg_max, int32_t in_h,
+                                 int32_t in_w, const float* img_hw, const float* scale_factors, float score_thr,
+                                 int32_t nms_pre, float iou_thr, int32_t max_cand, int32_t max_det, float* dets,
+                                 int32_t* count, int32_t* status, void* wsp, int64_t ws_bytes, void* stream) {
+  if (!cls || !reg || !strides || !dets || !count || !status || !wsp) GLS_FAIL(GLSDET_E_ARG, "gfl_detect: null argument");
+  if (n_levels < 1 || n_levels > GLS_MAX_LEVELS || num_classes < 1 || reg_max < 1 || reg_max > 63 || nms_pre < 1 ||
+      max_cand < 1 || max_det < 1)
+    GLS_FAIL(GLSDET_E_ARG, "gfl_detect: bad sizes");
+  const int max_cand2 = n_levels * nms_pre;
+  if (max_cand > GLS_NMS_MAXW * 64 || max_cand2 > GLS_NMS_MAXW * 64)
+    GLS_FAIL(GLSDET_E_ARG, "gfl_detect: max_cand / n_levels*nms_pre above %d", GLS_NMS_MAXW * 64);
+  if ((uintptr_t)wsp & 255) GLS_FAIL(GLSDET_E_ALIGN, "gfl_detect: workspace must be 256-byte aligned");
+  GflArgs a = {};
+  int maxhw = 0;
+  for (int l = 0; l < n_levels; ++l) {
+    int rc;
+    if ((rc = check_view(cls[l], "gfl_detect.cls", false))) return rc;
+    if ((rc = check_view(reg[l], "gfl_detect.reg", false))) return rc;
+    if (cls[l].dtype != GLSDET_F32 || reg[l].dtype != GLSDET_F32) GLS_FAIL(GLSDET_E_ARG, "gfl_detect: levels must be fp32");
+    if (cls[l].c < num_classes || reg[l].c < 4 * (reg_max + 1) || cls[l].n != cls[0].n || reg[l].n != cls[0].n ||
+        reg[l].h != cls[l].h || reg[l].w != cls[l].w || strides[l] < 1)
+      GLS_FAIL(GLSDET_E_ARG, "gfl_detect: level %d extent mismatch", l);
+    a.cls[l] = (const float*)cls[l].base; a.reg[l] = (const float*)reg[l].base;
+    a.csn[l] = cls[l].sn; a.csh[l] = cls[l].sh; a.csw[l] = cls[l].sw;
+    a.rsn[l] = reg[l].sn; a.rsh[l] = reg[l].sh; a.rsw[l] = reg[l].sw;
+    a.H[l] = cls[l].h; a.W[l] = cls[l].w;
+    a.stride[l] = (float)strides[l];
+    if (cls[l].h * cls[l].w > maxhw) maxhw = cls[l].h * cls[l].w;
+  }
+  const int n = cls[0].n;
+  a.n_levels = n_levels; a.nc = num_classes; a.reg_max = reg_max; a.n = n;
+  a.in_h = (float)in_h; a.in_w = (float)in_w; a.thr = score_thr; a.img_hw = img_hw;
+  NmsWs w1, w2;
+  const long need1 = nms_layout(n * n_levels, max_cand, &w1, (char*)wsp, false);
+  const long off2 = align_up(need1, 256);
+  const long need = off2 + nms_layout(n, max_cand2, &w2, (char*)wsp + off2, true);
+  if (ws_bytes < need) GLS_FAIL(GLSDET_E_CAPACITY, "gfl_detect: workspace %ld < %ld bytes", (long)ws_bytes, need);
+  const int nw2 = (max_cand2 + 63) / 64;
+  double bytes = 0;
+  for (int l = 0; l < n_levels; ++l) bytes += (double)n * a.H[l] * a.W[l] * (num_classes + 4.0 * (reg_max + 1)) * 4.0;
+  OpRecord op;
+  op.kind = 6;
+  op.flops = 0;
+  op.bytes = bytes;
+  op.name = "gfl_detect(filter+topk+merge+nms)";
+  op.launch = [=](hipStream_t st) -> int {
+    GLS_HIP(hipMemsetAsync(w1.cnt, 0, (size_t)n * n_levels * 4, st));
+    GLS_HIP(hipMemsetAsync(status, 0, 4, st));
+    hipLaunchKernelGGL(gfl_filter_kernel, dim3((maxhw + 255) / 256, n, n_levels), dim3(256), 0, st, a, max_cand, w1, status);
+    hipLaunchKernelGGL(nms_rank_kernel, dim3((max_cand + 63) / 64, n * n_levels), dim3(256), 0, st, max_cand, w1);
+    hipLaunchKernelGGL(gfl_merge_kernel, dim3((max_cand2 + 255) / 256, n), dim3(256), 0, st, n_levels, max_cand, nms_pre,
+                       max_cand2, w1, w2, scale_factors);
+    hipLaunchKernelGGL(nms_rank_kernel, dim3((max_cand2 + 63) / 64, n), dim3(256), 0, st, max_cand2, w2);
+    hipLaunchKernelGGL(nms_mask_kernel, dim3(2048, n), dim3(64), 0, st, max_cand2, nw2, iou_thr, w2);
+    hipLaunchKernelGGL(nms_scan_kernel, dim3(n), dim3(1024), 0, st, max_cand2, nw2, max_det, w2, dets, count);
     GLS_HIP(hipGetLastError());
     return 0;
   };

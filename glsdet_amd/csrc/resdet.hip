@@ -1,0 +1,438 @@
+// HBM-bound helpers of the ResNet-50 / FPN / GFL / MPHead path (SURVEY section 8a rows A10,
+// A11): image packing for the 7x7 stem, strided max pool, FPN nearest-upsample-add,
+// GroupNorm (+ReLU) of the head towers and the MPHead proxy scores.  All are 16-byte-per-lane
+// NHWC kernels; the contractions of this path go through glsdet_conv2d.
+#include "common.h"
+
+namespace glsdet {
+
+template <typename T> struct V16;
+template <> struct V16<f16> { typedef f16x8 type; static constexpr int N = 8; };
+template <> struct V16<float> { typedef f32x4 type; static constexpr int N = 4; };
+
+static inline unsigned rgrid(long work_items, long cap = 256L * 32) {
+  long g = (work_items + 255) / 256;
+  if (g < 1) g = 1;
+  if (g > cap) g = cap;
+  return (unsigned)g;
+}
+
+// ---------------------------------------------------------------- NCHW fp32 -> NHWC pack
+// One thread per pixel: cin strided float loads (coalesced across the wave along W), the
+// padded pixel leaves as 16-byte stores.
+template <typename T>
+__global__ __launch_bounds__(256) void nchw_pack_kernel(const float* __restrict__ img, int n, int cin, int H, int W,
+                                                        unsigned char* y, long sn, long sh, long sw, int cy) {
+  typedef typename V16<T>::type V;
+  constexpr int VN = V16<T>::N;
+  const long total = (long)n * H * W;
+  for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += (long)gridDim.x * blockDim.x) {
+    const int w = (int)(p % W);
+    const int h = (int)((p / W) % H);
+    const int b = (int)(p / ((long)W * H));
+    T* out = reinterpret_cast<T*>(y) + b * sn + h * sh + w * sw;
+    const float* src = img + ((long)b * cin * H + h) * W + w;
+    for (int c0 = 0; c0 < cy; c0 += VN) {
+      V pk;
+#pragma unroll
+      for (int e = 0; e < VN; ++e) pk[e] = (c0 + e) < cin ? (T)src[(long)(c0 + e) * H * W] : (T)0.f;
+      *reinterpret_cast<V*>(out + c0) = pk;
+    }
+  }
+}
+
+// ---------------------------------------------------------------- max pool k, stride, pad
+template <typename T>
+__global__ __launch_bounds__(256) void pool2d_kernel(const unsigned char* x, long xsn, long xsh, long xsw, int H, int W,
+                                                     unsigned char* y, long ysn, long ysh, long ysw, int n, int Ho,
+                                                     int Wo, int C, int k, int stride, int pad) {
+  typedef typename V16<T>::type V;
+  constexpr int VN = V16<T>::N;
+  const int cchunks = C / VN;
+  const long total = (long)n * Ho * Wo * cchunks;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int cc = (int)(i % cchunks);
+    long p = i / cchunks;
+    const int wo = (int)(p % Wo);
+    p /= Wo;
+    const int ho = (int)(p % Ho);
+    const int b = (int)(p / Ho);
+    V m;
+#pragma unroll
+    for (int e = 0; e < VN; ++e) m[e] = (T)(-INFINITY);
+    for (int dy = 0; dy < k; ++dy) {
+      const int hh = ho * stride - pad + dy;
+      if (hh < 0 || hh >= H) continue;
+      for (int dx = 0; dx < k; ++dx) {
+        const int ww = wo * stride - pad + dx;
+        if (ww < 0 || ww >= W) continue;
+        const V v = *reinterpret_cast<const V*>(x + (b * xsn + hh * xsh + ww * xsw + cc * VN) * (long)sizeof(T));
+#pragma unroll
+        for (int e = 0; e < VN; ++e) m[e] = v[e] > m[e] ? v[e] : m[e];
+      }
+    }
+    *reinterpret_cast<V*>(y + (b * ysn + ho * ysh + wo * ysw + cc * VN) * (long)sizeof(T)) = m;
+  }
+}
+
+// ---------------------------------------------------------------- fine += nearest(coarse)
+// torch 'nearest' with size=: src = min((int)floorf(dst * scale), in - 1), scale = (float)in / out.
+template <typename T>
+__global__ __launch_bounds__(256) void upsample_add_kernel(const unsigned char* x, long xsn, long xsh, long xsw, int Hc,
+                                                           int Wc, unsigned char* y, long ysn, long ysh, long ysw,
+                                                           int n, int H, int W, int C, float scale_h, float scale_w) {
+  typedef typename V16<T>::type V;
+  constexpr int VN = V16<T>::N;
+  const int cchunks = C / VN;
+  const long total = (long)n * H * W * cchunks;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int cc = (int)(i % cchunks);
+    long p = i / cchunks;
+    const int w = (int)(p % W);
+    p /= W;
+    const int h = (int)(p % H);
+    const int b = (int)(p / H);
+    const int hs = min((int)floorf((float)h * scale_h), Hc - 1);
+    const int ws = min((int)floorf((float)w * scale_w), Wc - 1);
+    const V a = *reinterpret_cast<const V*>(x + (b * xsn + hs * xsh + ws * xsw + cc * VN) * (long)sizeof(T));
+    V* dst = reinterpret_cast<V*>(y + (b * ysn + h * ysh + w * ysw + cc * VN) * (long)sizeof(T));
+    V d = *dst;
+#pragma unroll
+    for (int e = 0; e < VN; ++e) d[e] = (T)((float)d[e] + (float)a[e]);
+    *dst = d;
+  }
+}
+
+// ---------------------------------------------------------------- GroupNorm
+// Pass 1: a workgroup owns a slice of one image's pixels; thread t always reads vector column
+// t % vcols (256 % vcols == 0), so its elements all belong to ONE group; sum and sum of
+// squares are kept in fp64 (no cancellation issue in E[x^2]-mean^2), folded per group in a
+// fixed order and written as one partial per (image, slice, group).
+#define GLS_GN_SPLIT 64
+template <typename T>
+__global__ __launch_bounds__(256) void gn_stats_kernel(const unsigned char* x, long xsn, long xsh, long xsw, int H, int W,
+                                                       int C, int groups, int chunk, double* partial) {
+  typedef typename V16<T>::type V;
+  constexpr int VN = V16<T>::N;
+  __shared__ double s_sum[256], s_sq[256];
+  const int b = blockIdx.y, z = blockIdx.x;
+  const int vcols = C / VN, rows = 256 / vcols;
+  const int cc = threadIdx.x % vcols, r0 = threadIdx.x / vcols;
+  const int N = H * W;
+  const int pbeg = z * chunk, pend = min(N, pbeg + chunk);
+  double sum = 0.0, sq = 0.0;
+  for (int p = pbeg + r0; p < pend; p += rows) {
+    const V v = *reinterpret_cast<const V*>(x + (b * xsn + (p / W) * xsh + (p % W) * xsw + cc * VN) * (long)sizeof(T));
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int e = 0; e < VN; ++e) {
+      const float f = (float)v[e];
+      s1 += f;
+      s2 += f * f;
+    }
+    sum += (double)s1;
+    sq += (double)s2;
+  }
+  s_sum[threadIdx.x] = sum;
+  s_sq[threadIdx.x] = sq;
+  __syncthreads();
+  if ((int)threadIdx.x < groups) {
+    const int g = threadIdx.x, cpg = C / groups, vpg = cpg / VN;       // vector columns per group
+    double a = 0.0, q = 0.0;
+    for (int r = 0; r < rows; ++r)
+      for (int c = g * vpg; c < (g + 1) * vpg; ++c) {
+        a += s_sum[r * vcols + c];
+        q += s_sq[r * vcols + c];
+      }
+    double* o = partial + (((long)b * GLS_GN_SPLIT + z) * groups + g) * 2;
+    o[0] = a;
+    o[1] = q;
+  }
+}
+
+// Pass 2: fold the partials of this image (fixed order), then y = act((x - mean) * rstd * gamma + beta).
+template <typename T>
+__global__ __launch_bounds__(256) void gn_apply_kernel(const unsigned char* x, long xsn, long xsh, long xsw,
+                                                       unsigned char* y, long ysn, long ysh, long ysw, int H, int W,
+                                                       int C, int groups, int nsplit, const double* partial,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       float eps, int act) {
+  typedef typename V16<T>::type V;
+  constexpr int VN = V16<T>::N;
+  __shared__ float s_mean[256], s_rstd[256];
+  const int b = blockIdx.y;
+  const int N = H * W, cpg = C / groups;
+  if ((int)threadIdx.x < groups) {
+    double a = 0.0, q = 0.0;
+    for (int z = 0; z < nsplit; ++z) {
+      const double* o = partial + (((long)b * GLS_GN_SPLIT + z) * groups + threadIdx.x) * 2;
+      a += o[0];
+      q += o[1];
+    }
+    const double cnt = (double)N * cpg;
+    const double mean = a / cnt;
+    double var = q / cnt - mean * mean;
+    if (var < 0.0) var = 0.0;
+    s_mean[threadIdx.x] = (float)mean;
+    s_rstd[threadIdx.x] = (float)(1.0 / sqrt(var + (double)eps));
+  }
+  __syncthreads();
+  const int vcols = C / VN, rows = 256 / vcols;
+  const int cc = threadIdx.x % vcols, r0 = threadIdx.x / vcols;
+  const int g = cc * VN / cpg;
+  float sc[VN], sh[VN];
+#pragma unroll
+  for (int e = 0; e < VN; ++e) {
+    const float ga = gamma[cc * VN + e] * s_rstd[g];
+    sc[e] = ga;
+    sh[e] = beta[cc * VN + e] - s_mean[g] * ga;
+  }
+  for (int p = blockIdx.x * rows + r0; p < N; p += gridDim.x * rows) {
+    const long ox = (b * xsn + (p / W) * xsh + (p % W) * xsw + cc * VN) * (long)sizeof(T);
+    const long oy = (b * ysn + (p / W) * ysh + (p % W) * ysw + cc * VN) * (long)sizeof(T);
+    V v = *reinterpret_cast<const V*>(x + ox);
+#pragma unroll
+    for (int e = 0; e < VN; ++e) {
+      float f = (float)v[e] * sc[e] + sh[e];
+      if (act == GLSDET_ACT_RELU) f = fmaxf(f, 0.f);
+      v[e] = (T)f;
+    }
+    *reinterpret_cast<V*>(y + oy) = v;
+  }
+}
+
+// ---------------------------------------------------------------- MPHead proxy scores
+// One wave per position: |feat| by a shuffle reduction over the channel vectors, lane k < P
+// holds s_k = dots_k / max(|feat|, 1e-12); every lane walks the proxies of its own class
+// (shuffles) for the softmax-weighted mean; the first lane of a class writes the class score.
+struct ProxyArgs {
+  int P, nc, maxcnt;
+  unsigned char cls_of[256];     // class of proxy k
+  unsigned char first[256];      // first proxy of class c
+  unsigned char count[256];      // proxies of class c
+};
+template <typename T>
+__global__ __launch_bounds__(256) void proxy_scores_kernel(const unsigned char* f, long fsn, long fsh, long fsw,
+                                                           const float* dots, long dsn, long dsh, long dsw, float* out,
+                                                           long osn, long osh, long osw, int n, int H, int W, int C,
+                                                           float gamma, const ProxyArgs a) {
+  typedef typename V16<T>::type V;
+  constexpr int VN = V16<T>::N;
+  const int lane = threadIdx.x & 63;
+  const long wave = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const long nwaves = ((long)gridDim.x * blockDim.x) >> 6;
+  const long total = (long)n * H * W;
+  for (long p = wave; p < total; p += nwaves) {
+    const int w = (int)(p % W);
+    const int h = (int)((p / W) % H);
+    const int b = (int)(p / ((long)W * H));
+    const unsigned char* px = f + (b * fsn + h * fsh + w * fsw) * (long)sizeof(T);
+    float sq = 0.f;
+    for (int c = lane * VN; c < C; c += 64 * VN) {
+      const V v = *reinterpret_cast<const V*>(px + c * (long)sizeof(T));
+#pragma unroll
+      for (int e = 0; e < VN; ++e) sq += (float)v[e] * (float)v[e];
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) sq += __shfl_xor(sq, o, 64);
+    const float inv = 1.0f / fmaxf(sqrtf(sq), 1e-12f);
+    const float* d = dots + b * dsn + h * dsh + w * dsw;
+    float* o = out + b * osn + h * osh + w * osw;
+    for (int k0 = 0; k0 < a.P; k0 += 64) {           // P <= 64 in practice: one round
+      const int k = k0 + lane;
+      const bool live = k < a.P;
+      const float s = live ? d[k] * inv : 0.f;
+      const int c = live ? a.cls_of[k] : 0;
+      const int first = a.first[c] - k0, cnt = a.count[c];      // the class lies inside this round (host checks)
+      float m = -INFINITY;
+      for (int j = 0; j < a.maxcnt; ++j) {            // uniform trip count, shuffles need all lanes
+        const float sj = __shfl(s, min(max(first + j, 0), 63), 64);
+        if (j < cnt) m = fmaxf(m, sj * gamma);
+      }
+      float den = 0.f, num = 0.f;
+      for (int j = 0; j < a.maxcnt; ++j) {
+        const float sj = __shfl(s, min(max(first + j, 0), 63), 64);
+        if (j < cnt) {
+          const float e = expf(sj * gamma - m);
+          den += e;
+          num += e * sj;
+        }
+      }
+      if (live && k == a.first[c]) o[c] = num / den * gamma;
+    }
+  }
+}
+
+}  // namespace glsdet
+
+using namespace glsdet;
+
+extern "C" int glsdet_nchw_pack(const float* img, int32_t n, int32_t cin, int32_t H, int32_t W, const glsdet_view* y,
+                                void* stream) {
+  if (!img || !y) GLS_FAIL(GLSDET_E_ARG, "nchw_pack: null argument");
+  int rc;
+  if ((rc = check_view(*y, "nchw_pack.y"))) return rc;
+  if (n < 1 || cin < 1 || y->n != n || y->h != H || y->w != W || y->c < cin || y->c % 8)
+    GLS_FAIL(GLSDET_E_ARG, "nchw_pack: y must be [n,H,W,c>=cin], c a multiple of 8");
+  const glsdet_view v = *y;
+  OpRecord op;
+  op.kind = 1;
+  op.flops = 0;
+  op.bytes = (double)n * H * W * (cin * 4.0 + v.c * dtype_size(v.dtype));
+  op.name = "nchw_pack";
+  op.launch = [=](hipStream_t st) -> int {
+    const unsigned g = rgrid((long)n * H * W);
+    if (v.dtype == GLSDET_F16)
+      hipLaunchKernelGGL(nchw_pack_kernel<f16>, dim3(g), dim3(256), 0, st, img, n, cin, H, W, (unsigned char*)v.base, v.sn, v.sh, v.sw, v.c);
+    else
+      hipLaunchKernelGGL(nchw_pack_kernel<float>, dim3(g), dim3(256), 0, st, img, n, cin, H, W, (unsigned char*)v.base, v.sn, v.sh, v.sw, v.c);
+    GLS_HIP(hipGetLastError());
+    return 0;
+  };
+  return submit(std::move(op), stream);
+}
+
+extern "C" int glsdet_pool2d(const glsdet_view* x, const glsdet_view* y, int32_t k, int32_t stride, int32_t pad,
+                             void* stream) {
+  if (!x || !y) GLS_FAIL(GLSDET_E_ARG, "pool2d: null argument");
+  int rc;
+  if ((rc = check_view(*x, "pool2d.x"))) return rc;
+  if ((rc = check_view(*y, "pool2d.y"))) return rc;
+  if (k < 1 || k > 31 || stride < 1 || pad < 0 || 2 * pad > k) GLS_FAIL(GLSDET_E_ARG, "pool2d: bad k/stride/pad");
+  if (x->dtype != y->dtype || x->n != y->n || x->c != y->c || x->c % 8 || y->h != (x->h + 2 * pad - k) / stride + 1 ||
+      y->w != (x->w + 2 * pad - k) / stride + 1)
+    GLS_FAIL(GLSDET_E_ARG, "pool2d: y must be [n,(h+2p-k)/s+1,(w+2p-k)/s+1,c] of x's dtype");
+  const glsdet_view a = *x, b = *y;
+  OpRecord op;
+  op.kind = 2;
+  op.flops = 0;
+  op.bytes = ((double)a.n * a.h * a.w + (double)b.n * b.h * b.w) * a.c * dtype_size(a.dtype);
+  op.name = "pool2d";
+  op.launch = [=](hipStream_t st) -> int {
+    const unsigned g = rgrid((long)b.n * b.h * b.w * (b.c * dtype_size(b.dtype) / 16));
+    if (a.dtype == GLSDET_F16)
+      hipLaunchKernelGGL(pool2d_kernel<f16>, dim3(g), dim3(256), 0, st, (const unsigned char*)a.base, a.sn, a.sh, a.sw, a.h, a.w, (unsigned char*)b.base, b.sn, b.sh, b.sw, b.n, b.h, b.w, b.c, k, stride, pad);
+    else
+      hipLaunchKernelGGL(pool2d_kernel<float>, dim3(g), dim3(256), 0, st, (const unsigned char*)a.base, a.sn, a.sh, a.sw, a.h, a.w, (unsigned char*)b.base, b.sn, b.sh, b.sw, b.n, b.h, b.w, b.c, k, stride, pad);
+    GLS_HIP(hipGetLastError());
+    return 0;
+  };
+  return submit(std::move(op), stream);
+}
+
+extern "C" int glsdet_upsample_add(const glsdet_view* coarse, const glsdet_view* fine, void* stream) {
+  if (!coarse || !fine) GLS_FAIL(GLSDET_E_ARG, "upsample_add: null argument");
+  int rc;
+  if ((rc = check_view(*coarse, "upsample_add.coarse"))) return rc;
+  if ((rc = check_view(*fine, "upsample_add.fine"))) return rc;
+  if (coarse->dtype != fine->dtype || coarse->n != fine->n || coarse->c != fine->c || fine->c % 8)
+    GLS_FAIL(GLSDET_E_ARG, "upsample_add: n, c, dtype must match; c a multiple of 8");
+  const glsdet_view a = *coarse, b = *fine;
+  OpRecord op;
+  op.kind = 3;
+  op.flops = 0;
+  op.bytes = 3.0 * b.n * b.h * b.w * b.c * dtype_size(b.dtype);
+  op.name = "upsample_add";
+  op.launch = [=](hipStream_t st) -> int {
+    const float sh = (float)a.h / (float)b.h, sw = (float)a.w / (float)b.w;
+    const unsigned g = rgrid((long)b.n * b.h * b.w * (b.c * dtype_size(b.dtype) / 16));
+    if (a.dtype == GLSDET_F16)
+      hipLaunchKernelGGL(upsample_add_kernel<f16>, dim3(g), dim3(256), 0, st, (const unsigned char*)a.base, a.sn, a.sh, a.sw, a.h, a.w, (unsigned char*)b.base, b.sn, b.sh, b.sw, b.n, b.h, b.w, b.c, sh, sw);
+    else
+      hipLaunchKernelGGL(upsample_add_kernel<float>, dim3(g), dim3(256), 0, st, (const unsigned char*)a.base, a.sn, a.sh, a.sw, a.h, a.w, (unsigned char*)b.base, b.sn, b.sh, b.sw, b.n, b.h, b.w, b.c, sh, sw);
+    GLS_HIP(hipGetLastError());
+    return 0;
+  };
+  return submit(std::move(op), stream);
+}
+
+extern "C" int64_t glsdet_groupnorm_workspace_bytes(int32_t n, int32_t groups) {
+  if (n < 1 || groups < 1) return 0;
+  return (int64_t)n * GLS_GN_SPLIT * groups * 2 * (int64_t)sizeof(double);
+}
+
+extern "C" int glsdet_groupnorm(const glsdet_view* x, const glsdet_view* y, int32_t groups, const float* gamma,
+                                const float* beta, float eps, int32_t act, void* stats, void* stream) {
+  if (!x || !y || !gamma || !beta || !stats) GLS_FAIL(GLSDET_E_ARG, "groupnorm: null argument");
+  int rc;
+  if ((rc = check_view(*x, "groupnorm.x"))) return rc;
+  if ((rc = check_view(*y, "groupnorm.y"))) return rc;
+  if (!same_extent(*x, *y) || x->dtype != y->dtype) GLS_FAIL(GLSDET_E_ARG, "groupnorm: x/y extent or dtype mismatch");
+  if (act != GLSDET_ACT_NONE && act != GLSDET_ACT_RELU) GLS_FAIL(GLSDET_E_ARG, "groupnorm: act must be none or relu");
+  const int vn = 16 / dtype_size(x->dtype);
+  if (groups < 1 || groups > 256 || x->c % groups || (x->c / groups) % vn || x->c / vn > 256 || 256 % (x->c / vn))
+    GLS_FAIL(GLSDET_E_ARG, "groupnorm: need C %% groups == 0, (C/groups) %% %d == 0 and C/%d a divisor of 256 (C=%d groups=%d)",
+             vn, vn, x->c, groups);
+  if ((uintptr_t)stats & 7) GLS_FAIL(GLSDET_E_ALIGN, "groupnorm: stats must be 8-byte aligned");
+  const glsdet_view a = *x, b = *y;
+  const int N = a.h * a.w;
+  int nsplit = (N + 255) / 256;
+  if (nsplit > GLS_GN_SPLIT) nsplit = GLS_GN_SPLIT;
+  const int chunk = (N + nsplit - 1) / nsplit;
+  double* part = (double*)stats;
+  OpRecord op;
+  op.kind = 7;
+  op.flops = 0;
+  op.bytes = 3.0 * a.n * N * a.c * dtype_size(a.dtype);
+  op.name = "groupnorm(stats+apply)";
+  op.launch = [=](hipStream_t st) -> int {
+    const int rows = 256 / (a.c / vn);
+    int gb = (N + rows * 8 - 1) / (rows * 8);
+    if (gb > 1024) gb = 1024;
+    if (a.dtype == GLSDET_F16) {
+      hipLaunchKernelGGL(gn_stats_kernel<f16>, dim3(nsplit, a.n), dim3(256), 0, st, (const unsigned char*)a.base, a.sn, a.sh, a.sw, a.h, a.w, a.c, groups, chunk, part);
+      hipLaunchKernelGGL(gn_apply_kernel<f16>, dim3(gb, a.n), dim3(256), 0, st, (const unsigned char*)a.base, a.sn, a.sh, a.sw, (unsigned char*)b.base, b.sn, b.sh, b.sw, a.h, a.w, a.c, groups, nsplit, part, gamma, beta, eps, act);
+    } else {
+      hipLaunchKernelGGL(gn_stats_kernel<float>, dim3(nsplit, a.n), dim3(256), 0, st, (const unsigned char*)a.base, a.sn, a.sh, a.sw, a.h, a.w, a.c, groups, chunk, part);
+      hipLaunchKernelGGL(gn_apply_kernel<float>, dim3(gb, a.n), dim3(256), 0, st, (const unsigned char*)a.base, a.sn, a.sh, a.sw, (unsigned char*)b.base, b.sn, b.sh, b.sw, a.h, a.w, a.c, groups, nsplit, part, gamma, beta, eps, act);
+    }
+    GLS_HIP(hipGetLastError());
+    return 0;
+  };
+  return submit(std::move(op), stream);
+}
+
+extern "C" int glsdet_proxy_scores(const glsdet_view* feat, const glsdet_view* dots, const int32_t* counts,
+                                   int32_t num_classes, float gamma, const glsdet_view* out, void* stream) {
+  if (!feat || !dots || !counts || !out) GLS_FAIL(GLSDET_E_ARG, "proxy_scores: null argument");
+  int rc;
+  if ((rc = check_view(*feat, "proxy_scores.feat"))) return rc;
+  if ((rc = check_view(*dots, "proxy_scores.dots", false))) return rc;
+  if ((rc = check_view(*out, "proxy_scores.out", false))) return rc;
+  if (dots->dtype != GLSDET_F32 || out->dtype != GLSDET_F32) GLS_FAIL(GLSDET_E_ARG, "proxy_scores: dots/out must be fp32");
+  if (num_classes < 1 || num_classes > 256) GLS_FAIL(GLSDET_E_ARG, "proxy_scores: bad num_classes");
+  ProxyArgs pa = {};
+  int P = 0;
+  for (int c = 0; c < num_classes; ++c) {
+    if (counts[c] < 1 || counts[c] > 64) GLS_FAIL(GLSDET_E_ARG, "proxy_scores: class %d has %d proxies (1..64)", c, counts[c]);
+    if (P / 64 != (P + counts[c] - 1) / 64)
+      GLS_FAIL(GLSDET_E_ARG, "proxy_scores: the proxies of class %d straddle a 64-proxy round", c);
+    if (P + counts[c] > 256) GLS_FAIL(GLSDET_E_ARG, "proxy_scores: more than 256 proxies");
+    pa.first[c] = (unsigned char)P;
+    if (counts[c] > pa.maxcnt) pa.maxcnt = counts[c];
+    pa.count[c] = (unsigned char)counts[c];
+    for (int k = 0; k < counts[c]; ++k) pa.cls_of[P + k] = (unsigned char)c;
+    P += counts[c];
+  }
+  pa.P = P;
+  pa.nc = num_classes;
+  if (dots->c < P || out->c < num_classes || dots->n != feat->n || dots->h != feat->h || dots->w != feat->w ||
+      out->n != feat->n || out->h != feat->h || out->w != feat->w || feat->c % 8)
+    GLS_FAIL(GLSDET_E_ARG, "proxy_scores: extent mismatch (P=%d)", P);
+  const glsdet_view a = *feat, d = *dots, o = *out;
+  OpRecord op;
+  op.kind = 8;
+  op.flops = 0;
+  op.bytes = (double)a.n * a.h * a.w * (a.c * dtype_size(a.dtype) + 4.0 * (P + num_classes));
+  op.name = "proxy_scores";
+  op.launch = [=](hipStream_t st) -> int {
+    const unsigned g = rgrid((long)a.n * a.h * a.w * 64);
+    if (a.dtype == GLSDET_F16)
+      hipLaunchKernelGGL(proxy_scores_kernel<f16>, dim3(g), dim3(256), 0, st, (const unsigned char*)a.base, a.sn, a.sh, a.sw, (const float*)d.base, d.sn, d.sh, d.sw, (float*)o.base, o.sn, o.sh, o.sw, a.n, a.h, a.w, a.c, gamma, pa);
+    else
+      hipLaunchKernelGGL(proxy_scores_kernel<float>, dim3(g), dim3(256), 0, st, (const unsigned char*)a.base, a.sn, a.sh, a.sw, (const float*)d.base, d.sn, d.sh, d.sw, (float*)o.base, o.sn, o.sh, o.sw, a.n, a.h, a.w, a.c, gamma, pa);
+    GLS_HIP(hipGetLastError());
+    return 0;
+  };
+  return submit(std::move(op), stream);
+}

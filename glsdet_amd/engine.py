@@ -184,7 +184,9 @@ class Engine:
 
     # ---- ops (each is one C-ABI call)
     def conv(self, x: TView, packed, stride: int, pad: int, act: str, out: Optional[TView] = None,
-             res: Optional[TView] = None, out_dtype: Optional[int] = None, tile_hint: int = 0) -> TView:
+             res: Optional[TView] = None, out_dtype: Optional[int] = None, tile_hint: int = 0,
+             res_first: bool = False) -> TView:
+        """res_first: act(conv*scale + bias + res) (ResNet) instead of act(conv*scale + bias) + res."""
         wdev, sdev, bdev, cout, R, S = packed
         ho = (x.h + 2 * pad - R) // stride + 1
         wo = (x.w + 2 * pad - S) // stride + 1
@@ -196,6 +198,8 @@ class Engine:
         d.res = res.as_c() if res is not None else View()
         d.w, d.scale, d.bias = wdev.data_ptr(), sdev.data_ptr(), bdev.data_ptr()
         d.R, d.S, d.stride, d.pad, d.act, d.tile_hint = R, S, stride, pad, ACT[act], tile_hint
+        if res_first and res is not None:
+            d.act |= 0x100                      # GLSDET_ACT_RES_FIRST
         if self.autotune and tile_hint == 0:
             key = (x.n, x.h, x.w, x.c, x.sn, x.sh, x.sw, out.c, out.sn, out.sh, out.sw, R, S, stride, pad,
                    res is not None, out.dtype)
@@ -302,6 +306,71 @@ class Engine:
                                   nb["max_cand"], nb["max_det"], nb["dets"].data_ptr(), nb["count"].data_ptr(),
                                   nb["status"].data_ptr(), nb["ws"].data_ptr(), nb["ws"].numel(),
                                   _stream_ptr(self.stream)), "nms")
+        return nb["dets"], nb["count"], nb["status"]
+
+    # ------------------------------------------------------------------ ResNet / FPN / GFL / MPHead ops
+    def nchw_pack(self, img: torch.Tensor, out: Optional[TView] = None) -> TView:
+        assert img.dtype == torch.float32 and img.is_contiguous() and img.device.type == "cuda"
+        n, cin, H, W = img.shape
+        if out is None:
+            out = self.tensor(n, H, W, ceil_to(cin, 8))
+        check(self.lib.glsdet_nchw_pack(img.data_ptr(), n, cin, H, W, C.byref(out.as_c()), _stream_ptr(self.stream)),
+              "nchw_pack")
+        return out
+
+    def pool2d(self, x: TView, k: int, stride: int, pad: int, out: Optional[TView] = None) -> TView:
+        if out is None:
+            out = self.tensor(x.n, (x.h + 2 * pad - k) // stride + 1, (x.w + 2 * pad - k) // stride + 1, x.c, x.dtype)
+        check(self.lib.glsdet_pool2d(C.byref(x.as_c()), C.byref(out.as_c()), k, stride, pad, _stream_ptr(self.stream)),
+              "pool2d")
+        return out
+
+    def upsample_add(self, coarse: TView, fine: TView) -> TView:
+        check(self.lib.glsdet_upsample_add(C.byref(coarse.as_c()), C.byref(fine.as_c()), _stream_ptr(self.stream)),
+              "upsample_add")
+        return fine
+
+    def groupnorm(self, x: TView, groups: int, gamma: torch.Tensor, beta: torch.Tensor, eps: float, act: str = "relu",
+                  out: Optional[TView] = None) -> TView:
+        if out is None:
+            out = x
+        ws = self.raw(self.lib.glsdet_groupnorm_workspace_bytes(x.n, groups))
+        check(self.lib.glsdet_groupnorm(C.byref(x.as_c()), C.byref(out.as_c()), groups, gamma.data_ptr(), beta.data_ptr(),
+                                        eps, ACT[act], ws.data_ptr(), _stream_ptr(self.stream)), "groupnorm")
+        return out
+
+    def proxy_scores(self, feat: TView, dots: TView, counts: Sequence[int], gamma: float,
+                     out: Optional[TView] = None) -> TView:
+        nc = len(counts)
+        if out is None:
+            out = self.tensor(feat.n, feat.h, feat.w, ceil_to(nc, 8), F32)
+        arr = (C.c_int32 * nc)(*counts)
+        check(self.lib.glsdet_proxy_scores(C.byref(feat.as_c()), C.byref(dots.as_c()), arr, nc, gamma,
+                                           C.byref(out.as_c()), _stream_ptr(self.stream)), "proxy_scores")
+        return out
+
+    def gfl_buffers(self, n: int, n_levels: int, max_cand: int, nms_pre: int, max_det: int):
+        nbytes = self.lib.glsdet_gfl_workspace_bytes(n, n_levels, max_cand, nms_pre)
+        return {"ws": self.raw(nbytes), "n": n, "max_cand": max_cand, "nms_pre": nms_pre, "max_det": max_det,
+                "dets": torch.zeros(n, max_det, 7, dtype=torch.float32, device=self.device),
+                "count": torch.zeros(2 * n, dtype=torch.int32, device=self.device),
+                "status": torch.zeros(1, dtype=torch.int32, device=self.device)}
+
+    def gfl_detect(self, cls: Sequence[TView], reg: Sequence[TView], strides: Sequence[int], num_classes: int,
+                   reg_max: int, in_h: int, in_w: int, score_thr: float, iou_thr: float, nb,
+                   img_hw: Optional[torch.Tensor] = None, scale_factors: Optional[torch.Tensor] = None):
+        L = len(cls)
+        ca = (View * L)(*[l.as_c() for l in cls])
+        ra = (View * L)(*[l.as_c() for l in reg])
+        st = (C.c_int32 * L)(*strides)
+        for t, k in ((img_hw, 2), (scale_factors, 4)):
+            assert t is None or (t.dtype == torch.float32 and t.is_contiguous() and t.numel() == k * nb["n"])
+        check(self.lib.glsdet_gfl_detect(ca, ra, L, st, num_classes, reg_max, in_h, in_w,
+                                         img_hw.data_ptr() if img_hw is not None else None,
+                                         scale_factors.data_ptr() if scale_factors is not None else None,
+                                         score_thr, nb["nms_pre"], iou_thr, nb["max_cand"], nb["max_det"],
+                                         nb["dets"].data_ptr(), nb["count"].data_ptr(), nb["status"].data_ptr(),
+                                         nb["ws"].data_ptr(), nb["ws"].numel(), _stream_ptr(self.stream)), "gfl_detect")
         return nb["dets"], nb["count"], nb["status"]
 
     def branch(self, b: int):

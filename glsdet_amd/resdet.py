@@ -1,0 +1,305 @@
+"""ResNet-50 + FPN + GFLHead / MPHead lowered to libglsdet_hip ops (SURVEY section 8a rows
+A10, A11) and the plan-backed detector around them.  State-dict keys are mmdet's:
+
+    backbone.{conv1,bn1,layer{1..4}.{i}.{conv1,bn1,conv2,bn2,conv3,bn3,downsample.{0,1}}}
+                                              ufp/mmdet/models/backbones/resnet.py:371-646
+    neck.{lateral_convs,fpn_convs}.{i}.conv   ufp/mmdet/models/necks/fpn.py:62-148
+    bbox_head.{cls_convs,reg_convs}.{i}.{conv,gn}, gfl_cls | gfl_cls_conv + proxies, gfl_reg,
+    scales.{l}.scale                          ufp/mmdet/models/dense_heads/{gfl_head,mp_head}.py
+
+Graph-level choices (all numerically the reference's arithmetic):
+  * BN folded into the conv epilogue; the Bottleneck's `out += identity; relu` is the
+    residual-before-activation epilogue of conv3 (no separate add / ReLU kernels);
+  * the first cls and reg tower convs read the same feature -> one GEMM with Cout 512, and one
+    GroupNorm over 64 groups of 8 channels (= the two GN32 side by side);
+  * `Scale` is folded into the gfl_reg weights per level; F.normalize(proxies) is folded
+    into a 1x1 weight, the per-position |feat| and the per-class softmax are one small kernel.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from .engine import Engine, F32, TView, fold_bn
+
+RESNET_BN_EPS = 1e-5
+GN_EPS = 1e-5
+STAGE_BLOCKS = {50: (3, 4, 6, 3), 101: (3, 4, 23, 3)}
+
+
+class ResDetBuilder:
+    def __init__(self, eng: Engine, sd: Dict[str, torch.Tensor]):
+        self.e = eng
+        self.sd = {k: v.detach().cpu() for k, v in sd.items()}
+        self._packed = {}
+
+    # ------------------------------------------------------------------ weights
+    def _pack(self, key, parts, cin_pad):
+        k = (key, cin_pad)
+        if k not in self._packed:
+            self._packed[k] = self.e.pack_conv(parts, cin_pad)
+        return self._packed[k]
+
+    def _bn_part(self, conv: str, bn: str):
+        s, b = fold_bn(self.sd[bn + ".weight"], self.sd[bn + ".bias"], self.sd[bn + ".running_mean"],
+                       self.sd[bn + ".running_var"], RESNET_BN_EPS)
+        return self.sd[conv + ".weight"], s, b
+
+    def _plain_part(self, p: str, mul: float = 1.0):
+        w = self.sd[p + ".weight"].float() * mul
+        b = self.sd.get(p + ".bias")
+        b = torch.zeros(w.shape[0]) if b is None else b.float() * mul
+        return w, torch.ones(w.shape[0]), b
+
+    def _dev(self, key: str, t: torch.Tensor) -> torch.Tensor:
+        if key not in self._packed:
+            self._packed[key] = self.e.upload(t.float().contiguous())
+        return self._packed[key]
+
+    # ------------------------------------------------------------------ backbone
+    def bottleneck(self, p: str, x: TView, stride: int) -> TView:
+        """resnet.py:263-303 (style='pytorch': the stride sits on the 3x3)."""
+        e = self.e
+        t = e.conv(x, self._pack(p + ".conv1", [self._bn_part(p + ".conv1", p + ".bn1")], x.c), 1, 0, "relu")
+        t = e.conv(t, self._pack(p + ".conv2", [self._bn_part(p + ".conv2", p + ".bn2")], t.c), stride, 1, "relu")
+        idn = x
+        if p + ".downsample.0.weight" in self.sd:
+            idn = e.conv(x, self._pack(p + ".downsample", [self._bn_part(p + ".downsample.0", p + ".downsample.1")], x.c),
+                         stride, 0, "none")
+        return e.conv(t, self._pack(p + ".conv3", [self._bn_part(p + ".conv3", p + ".bn3")], t.c), 1, 0, "relu",
+                      res=idn, res_first=True)
+
+    def resnet(self, p: str, img: torch.Tensor, depth: int = 50, out_indices: Sequence[int] = (0, 1, 2, 3)) -> List[TView]:
+        """resnet.py:631-646."""
+        e = self.e
+        x = e.nchw_pack(img)
+        x = e.conv(x, self._pack(p + ".conv1", [self._bn_part(p + ".conv1", p + ".bn1")], x.c), 2, 3, "relu")
+        x = e.pool2d(x, 3, 2, 1)
+        outs = []
+        for i, nblocks in enumerate(STAGE_BLOCKS[depth]):
+            for j in range(nblocks):
+                x = self.bottleneck("%s.layer%d.%d" % (p, i + 1, j), x, 2 if (j == 0 and i > 0) else 1)
+            if i in out_indices:
+                outs.append(x)
+        return outs
+
+    # ------------------------------------------------------------------ neck
+    def fpn(self, p: str, inputs: Sequence[TView], start_level: int = 0, num_outs: int = 5,
+            add_extra_convs="on_output", relu_before_extra_convs: bool = False) -> List[TView]:
+        """fpn.py:150-205, norm_cfg=None / act_cfg=None (conv + bias only)."""
+        e = self.e
+        if relu_before_extra_convs:
+            raise NotImplementedError("FPN relu_before_extra_convs is not lowered")
+        n_lat = len(inputs) - start_level
+        conv = lambda name, x, stride, pad: e.conv(x, self._pack(name, [self._plain_part(name)], x.c), stride, pad, "none")
+        lat = [conv("%s.lateral_convs.%d.conv" % (p, i), inputs[i + start_level], 1, 0) for i in range(n_lat)]
+        for i in range(n_lat - 1, 0, -1):
+            e.upsample_add(lat[i], lat[i - 1])
+        outs = [conv("%s.fpn_convs.%d.conv" % (p, i), lat[i], 1, 1) for i in range(n_lat)]
+        if num_outs > len(outs):
+            if not add_extra_convs:
+                for _ in range(num_outs - n_lat):
+                    outs.append(e.pool2d(outs[-1], 1, 2, 0))
+            else:
+                mode = "on_input" if add_extra_convs is True else add_extra_convs
+                src = {"on_input": inputs[-1], "on_lateral": lat[-1], "on_output": outs[-1]}[mode]
+                outs.append(conv("%s.fpn_convs.%d.conv" % (p, n_lat), src, 2, 1))
+                for i in range(n_lat + 1, num_outs):
+                    outs.append(conv("%s.fpn_convs.%d.conv" % (p, i), outs[-1], 2, 1))
+        return outs
+
+    # ------------------------------------------------------------------ heads
+    def _gn(self, key: str, names: Sequence[str], x: TView, groups_each: int = 32) -> TView:
+        ga = self._dev(key + ".gamma", torch.cat([self.sd[n + ".gn.weight"] for n in names]))
+        be = self._dev(key + ".beta", torch.cat([self.sd[n + ".gn.bias"] for n in names]))
+        return self.e.groupnorm(x, groups_each * len(names), ga, be, GN_EPS, "relu")
+
+    def towers(self, p: str, x: TView, stacked: int) -> Tuple[TView, TView]:
+        """cls / reg towers of gfl_head.py:128-152: `stacked` x (3x3 conv, GN32, ReLU) each.
+        Layer 0 of both towers is one fused GEMM + one 64-group GN."""
+        e = self.e
+        names = ["%s.cls_convs.0" % p, "%s.reg_convs.0" % p]
+        raw = lambda n: (self.sd[n + ".conv.weight"], torch.ones(self.sd[n + ".conv.weight"].shape[0]),
+                         torch.zeros(self.sd[n + ".conv.weight"].shape[0]))
+        f = self.sd[names[0] + ".conv.weight"].shape[0]
+        both = e.conv(x, self._pack(p + ".tower0", [raw(n) for n in names], x.c), 1, 1, "none")
+        self._gn(p + ".tower0", names, both)
+        c, r = both.channels(0, f), both.channels(f, 2 * f)
+        for i in range(1, stacked):
+            for which in ("cls", "reg"):
+                n = "%s.%s_convs.%d" % (p, which, i)
+                t = e.conv(c if which == "cls" else r, self._pack(n, [raw(n)], f), 1, 1, "none")
+                self._gn(n, [n], t)
+                if which == "cls":
+                    c = t
+                else:
+                    r = t
+        return c, r
+
+    def _reg_pred(self, p: str, r: TView, level: int) -> TView:
+        scale = float(self.sd["%s.scales.%d.scale" % (p, level)])
+        pk = self._pack("%s.gfl_reg@%d" % (p, level), [self._plain_part(p + ".gfl_reg", scale)], r.c)
+        return self.e.conv(r, pk, 1, 1, "none", out_dtype=F32)
+
+    def gfl_head(self, p: str, feats: Sequence[TView], stacked: int = 4) -> Tuple[List[TView], List[TView]]:
+        """gfl_head.py:179-203 -> fp32 views: cls logits [n,h,w,nc], reg logits [n,h,w,4*(reg_max+1)]."""
+        cls, reg = [], []
+        for l, x in enumerate(feats):
+            c, r = self.towers(p, x, stacked)
+            cls.append(self.e.conv(c, self._pack(p + ".gfl_cls", [self._plain_part(p + ".gfl_cls")], c.c), 1, 1, "none",
+                                   out_dtype=F32))
+            reg.append(self._reg_pred(p, r, l))
+        return cls, reg
+
+    def mp_head(self, p: str, feats: Sequence[TView], proxies_list: Sequence[int], gamma: float = 10.0,
+                stacked: int = 4) -> Tuple[List[TView], List[TView]]:
+        """mp_head.py:123-154 (eval branch) + forward_proxy :105-121."""
+        e = self.e
+        prox = self.sd[p + ".proxies"].float()
+        assert prox.shape[0] == sum(proxies_list), "proxies_list does not match the proxies parameter"
+        centers = prox / prox.norm(dim=1, keepdim=True).clamp_min(1e-12)        # F.normalize(p=2, dim=1)
+        cls, reg = [], []
+        for l, x in enumerate(feats):
+            c, r = self.towers(p, x, stacked)
+            reg.append(self._reg_pred(p, r, l))
+            f = e.conv(c, self._pack(p + ".gfl_cls_conv", [self._plain_part(p + ".gfl_cls_conv")], c.c), 1, 1, "none")
+            w = centers.reshape(centers.shape[0], centers.shape[1], 1, 1)
+            dots = e.conv(f, self._pack(p + ".proxies", [(w, torch.ones(w.shape[0]), torch.zeros(w.shape[0]))], f.c),
+                          1, 0, "none", out_dtype=F32)
+            cls.append(e.proxy_scores(f, dots, list(proxies_list), gamma))
+        return cls, reg
+
+
+class _Compiled:
+    __slots__ = ("img", "plan", "cls", "reg", "nb", "eng", "post", "graph_stream", "scale", "img_hw")
+
+
+class HipGflDetector:
+    """ResNet-50 + FPN + GFLHead ('gfl') or MPHead ('mpdet'); mmdet state-dict names.
+    cfg keys: start_level, num_outs, add_extra_convs, stacked_convs, strides, reg_max,
+    proxies_list, gamma, depth, out_indices (defaults = the GFL r50-FPN / MPDet configs)."""
+
+    DEFAULTS = dict(start_level=1, num_outs=5, add_extra_convs="on_output", relu_before_extra_convs=False,
+                    stacked_convs=4, strides=(8, 16, 32, 64, 128), reg_max=16, depth=50, out_indices=(0, 1, 2, 3),
+                    proxies_list=(2, 3, 2, 5, 4, 8, 8, 4, 3, 3), gamma=10.0)
+
+    def __init__(self, kind: str, state_dict, dtype: str = "f16", device: str = "cuda:0", autotune: bool = False, **cfg):
+        if kind not in ("gfl", "mpdet"):
+            raise ValueError("kind must be 'gfl' or 'mpdet'")
+        unknown = set(cfg) - set(self.DEFAULTS)
+        if unknown:
+            raise TypeError("unknown options %s" % sorted(unknown))
+        self.kind, self.dtype, self.device, self.autotune = kind, dtype, device, autotune
+        self.cfg = dict(self.DEFAULTS, **cfg)
+        self.sd = {k: v.detach().cpu() for k, v in state_dict.items()}
+        if kind == "gfl":
+            self.num_classes = self.sd["bbox_head.gfl_cls.weight"].shape[0]
+        else:
+            self.num_classes = len(self.cfg["proxies_list"])
+        self._compiled: Dict[Tuple, _Compiled] = {}
+
+    def _emit(self, eng: Engine, img: torch.Tensor):
+        b, c = ResDetBuilder(eng, self.sd), self.cfg
+        feats = b.fpn("neck", b.resnet("backbone", img, c["depth"], c["out_indices"]), c["start_level"], c["num_outs"],
+                      c["add_extra_convs"], c["relu_before_extra_convs"])
+        if self.kind == "gfl":
+            return b.gfl_head("bbox_head", feats, c["stacked_convs"])
+        return b.mp_head("bbox_head", feats, c["proxies_list"], c["gamma"], c["stacked_convs"])
+
+    def compile(self, n: int, H: int, W: int, post: Optional[dict] = None, use_graph: bool = False,
+                instance: int = 0) -> _Compiled:
+        """post: None or dict(score_thr, iou_thr, nms_pre=1000, max_per_img=100, max_cand, rescale=False)
+        (the reference's test_cfg keys, base_dense_head.py:168,295-298)."""
+        key = (n, H, W, tuple(sorted(post.items())) if post else None, use_graph, instance)
+        if key in self._compiled:
+            return self._compiled[key]
+        eng = Engine(self.dtype, self.device, autotune=self.autotune)
+        c = _Compiled()
+        c.eng, c.post, c.nb, c.scale = eng, post, None, None
+        c.img = torch.zeros(n, 3, H, W, dtype=torch.float32, device=eng.device)
+        c.img_hw = torch.tensor([[H, W]] * n, dtype=torch.float32, device=eng.device)
+        if post is not None and post.get("rescale"):
+            c.scale = torch.ones(n, 4, dtype=torch.float32, device=eng.device)
+        c.plan = eng.new_plan()
+        with c.plan:
+            c.cls, c.reg = self._emit(eng, c.img)
+            if post is not None:
+                L = len(c.cls)
+                biggest = max(l.h * l.w for l in c.cls) * self.num_classes
+                c.nb = eng.gfl_buffers(n, L, min(post.get("max_cand", 8192), biggest), post.get("nms_pre", 1000),
+                                       post.get("max_per_img", 100))
+                eng.gfl_detect(c.cls, c.reg, self.cfg["strides"][:L], self.num_classes, self.cfg["reg_max"], H, W,
+                               post["score_thr"], post["iou_thr"], c.nb, img_hw=c.img_hw, scale_factors=c.scale)
+        eng.save_tune_cache()
+        c.graph_stream = None
+        if use_graph:
+            c.plan.run()
+            torch.cuda.synchronize()
+            c.graph_stream = torch.cuda.Stream(device=eng.device)
+            with torch.cuda.stream(c.graph_stream):
+                c.plan.capture(c.graph_stream)
+            torch.cuda.synchronize()
+        self._compiled[key] = c
+        return c
+
+    def run(self, c: _Compiled, img: Optional[torch.Tensor] = None, img_hw: Optional[torch.Tensor] = None,
+            scale: Optional[torch.Tensor] = None):
+        def feed():
+            if img is not None:
+                c.img.copy_(img, non_blocking=True)
+            if img_hw is not None:
+                c.img_hw.copy_(img_hw, non_blocking=True)
+            if scale is not None:
+                c.scale.copy_(scale, non_blocking=True)
+        if c.plan.captured:
+            st, cur = c.graph_stream, torch.cuda.current_stream()
+            st.wait_stream(cur)
+            with torch.cuda.stream(st):
+                feed()
+                c.plan.launch(st)
+            cur.wait_stream(st)
+            return
+        feed()
+        c.plan.run(None)
+
+    @staticmethod
+    def run_async(c: _Compiled):
+        assert c.plan.captured, "run_async needs compile(..., use_graph=True)"
+        c.plan.launch(c.graph_stream)
+
+    def forward_raw(self, img: torch.Tensor) -> Tuple[List[torch.Tensor], List[torch.Tensor]]:
+        """Reference-shaped head outputs: (cls_scores, bbox_preds), per level NCHW fp32
+        ([B,nc,H_l,W_l], [B,4*(reg_max+1),H_l,W_l]) -- gfl_head.py:154-177."""
+        n, _, H, W = img.shape
+        c = self.compile(n, H, W)
+        self.run(c, img.to(c.img.device, torch.float32))
+        bins = 4 * (self.cfg["reg_max"] + 1)
+        return [l.to_nchw(self.num_classes) for l in c.cls], [l.to_nchw(bins) for l in c.reg]
+
+    def detect(self, img: torch.Tensor, score_thr: float = 0.05, iou_thr: float = 0.6, nms_pre: int = 1000,
+               max_per_img: int = 100, img_shapes=None, scale_factors=None):
+        """-> list per image of (dets ndarray(k,5) x1,y1,x2,y2,score ; labels ndarray(k) int64)."""
+        n, _, H, W = img.shape
+        post = dict(score_thr=score_thr, iou_thr=iou_thr, nms_pre=nms_pre, max_per_img=max_per_img,
+                    rescale=scale_factors is not None)
+        c = self.compile(n, H, W, post)
+        hw = None if img_shapes is None else torch.tensor([[s[0], s[1]] for s in img_shapes], dtype=torch.float32)
+        sf = None if scale_factors is None else torch.tensor(np.asarray(scale_factors, np.float32).reshape(n, 4))
+        self.run(c, img.to(c.img.device, torch.float32), None if hw is None else hw.to(c.img.device),
+                 None if sf is None else sf.to(c.img.device))
+        return self.collect(c)
+
+    @staticmethod
+    def collect(c: _Compiled):
+        count = c.nb["count"].cpu().numpy()              # the one host sync of the path
+        if int(c.nb["status"].item()) & 1:
+            raise RuntimeError("GFL candidate capacity exceeded on a level (raise max_cand)")
+        dets = c.nb["dets"].cpu().numpy()
+        n = c.nb["n"]
+        out = []
+        for i in range(n):
+            d = dets[i, : count[i]]
+            out.append((d[:, :5].copy(), d[:, 6].astype(np.int64)))
+        return out

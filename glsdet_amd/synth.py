@@ -18,6 +18,16 @@ def synth_tensor(key: str, shape: Tuple[int, ...], seed: int) -> np.ndarray:
     leaf = key.rsplit(".", 1)[-1]
     if leaf == "num_batches_tracked":
         return np.zeros(shape, np.int64)
+    if leaf == "scale":                                  # mmcv Scale (gfl_head.py:151)
+        return rng.uniform(0.7, 1.3, shape).astype(np.float32)
+    if leaf in ("proxies", "_embedding"):               # mp_head.py:78-91
+        return rng.standard_normal(shape).astype(np.float32)
+    if leaf == "project":                               # Integral buffer, gfl_head.py:32-33
+        return np.linspace(0, shape[0] - 1, shape[0]).astype(np.float32)
+    if leaf == "_pos_embedding_ptr":
+        return np.zeros(shape, np.int64)
+    if leaf == "_proxies_prob":
+        return rng.uniform(0.1, 0.5, shape).astype(np.float32)
     if leaf == "running_var":
         return rng.uniform(0.5, 1.5, shape).astype(np.float32)
     if leaf == "running_mean":

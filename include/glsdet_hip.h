@@ -29,11 +29,16 @@
 extern "C" {
 #endif
 
-#define GLSDET_ABI_VERSION 2
+#define GLSDET_ABI_VERSION 3
 
 enum { GLSDET_F16 = 0, GLSDET_F32 = 1 };
 enum { GLSDET_ACT_NONE = 0, GLSDET_ACT_SILU = 1, GLSDET_ACT_RELU = 2, GLSDET_ACT_LRELU = 3,
-       GLSDET_ACT_GELU = 4 /* exact erf form, nn.GELU() */, GLSDET_ACT_SIGMOID = 5 };
+       GLSDET_ACT_GELU = 4 /* exact erf form, nn.GELU() */, GLSDET_ACT_SIGMOID = 5,
+       /* OR-ed into `act`: the residual is added BEFORE the activation, act(conv*scale+bias+res)
+        * (ResNet Bottleneck: `out += identity; out = relu(out)`, ufp/mmdet/models/backbones/
+        * resnet.py:292-301).  Without the flag the order is act(conv*scale+bias) + res
+        * (YOLOX Bottleneck, drone/models/base/darknet.py:61-63).                            */
+       GLSDET_ACT_RES_FIRST = 0x100 };
 enum {
   GLSDET_OK = 0,
   GLSDET_E_ARG = -1,      /* inconsistent shapes / unsupported parameter            */
@@ -167,6 +172,63 @@ int glsdet_nms(const float* pred, int32_t n, int32_t A, int32_t num_classes, int
                void* ws, int64_t ws_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------
+ * ResNet-50 / FPN / GFL / MPHead helpers
+ * --------------------------------------------------------------------------------- */
+/* fp32 NCHW image -> NHWC view of the engine dtype, channels zero padded to y.c (>= cin,
+ * multiple of 8): the input of the 7x7 s2 stem conv (ufp/mmdet/models/backbones/resnet.py:634). */
+int glsdet_nchw_pack(const float* img, int32_t n, int32_t cin, int32_t H, int32_t W,
+                     const glsdet_view* y, void* stream);
+
+/* nn.MaxPool2d(k, stride, pad) (resnet.py:598: k3 s2 p1), floor mode, -inf padding.
+ * y extent must be floor((x + 2*pad - k)/stride) + 1.                                      */
+int glsdet_pool2d(const glsdet_view* x, const glsdet_view* y, int32_t k, int32_t stride, int32_t pad,
+                  void* stream);
+
+/* FPN top-down step (ufp/mmdet/models/necks/fpn.py:165-175):
+ *   fine += F.interpolate(coarse, size=fine.shape[2:], mode='nearest')
+ * source index = min(floor(dst * (float)in/out), in-1) as torch computes it.  In place on fine. */
+int glsdet_upsample_add(const glsdet_view* coarse, const glsdet_view* fine, void* stream);
+
+/* nn.GroupNorm(groups, C) (+ optional ReLU) on an NHWC view, two kernels: fp64 partial sums
+ * per (image, pixel slice, group) into `stats` (caller owned, glsdet_groupnorm_workspace_bytes
+ * bytes, 8-byte aligned), then the fold + affine normalisation.  The conv towers of GFLHead /
+ * MPHead: mmcv ConvModule(norm_cfg=GN32) = conv -> GN -> ReLU (gfl_head.py:128-152).
+ * y may alias x.  gamma, beta: fp32 [C].  act: GLSDET_ACT_NONE or GLSDET_ACT_RELU.          */
+int64_t glsdet_groupnorm_workspace_bytes(int32_t n, int32_t groups);
+int glsdet_groupnorm(const glsdet_view* x, const glsdet_view* y, int32_t groups, const float* gamma,
+                     const float* beta, float eps, int32_t act, void* stats, void* stream);
+
+/* MPHead.forward_proxy (ufp/mmdet/models/dense_heads/mp_head.py:105-121).
+ *   feat : view [n,h,w,C] (the gfl_cls_conv output), engine dtype
+ *   dots : fp32 view [n,h,w,>=P], feat . (proxy_k / max(|proxy_k|, 1e-12)) for the P proxies
+ *          (a glsdet_conv2d with the normalised proxies as a 1x1 weight)
+ *   counts: host int32 [nc], proxies per class (sum = P <= 64 per class and P <= 256 in all)
+ *   out  : fp32 view [n,h,w,>=nc]:  gamma * sum_k softmax_k(gamma*s_k) * s_k  per class,
+ *          s_k = dots_k / max(|feat|, 1e-12)                                              */
+int glsdet_proxy_scores(const glsdet_view* feat, const glsdet_view* dots, const int32_t* counts,
+                        int32_t num_classes, float gamma, const glsdet_view* out, void* stream);
+
+/* GFL post-processing: gfl_head.py:380-471 (_get_bboxes_single) + base_dense_head.py:226-301
+ * (_bbox_post_process) + core/utils/misc.py:119-165 (filter_scores_and_topk).
+ *   cls : fp32 views [n,H_l,W_l,>=nc] raw class logits;  reg: fp32 views [n,H_l,W_l,>=4*(reg_max+1)]
+ *   per level: score = sigmoid(cls) ; (position, class) pairs with score > score_thr ; the
+ *   nms_pre best (ties: lower position*nc+class first) ; distances = Integral(reg) * stride ;
+ *   box = (x*s - l, y*s - t, x*s + r, y*s + b) clamped to [0,img_w] x [0,img_h]
+ *   (img_hw: device fp32 [n][2] = h,w per image, NULL = in_h,in_w) ; levels concatenated ;
+ *   divided by scale_factors (device fp32 [n][4], may be NULL) ; per-class NMS (IoU > iou_thr
+ *   suppresses) ; the first max_det in descending score order.
+ *   dets : fp32 [n][max_det][7] = x1,y1,x2,y2,score,score,label ; count: int32 [2n] as glsdet_nms
+ *   status bit0: a level held more than max_cand passing pairs (results invalid for that image)
+ *   ws   : glsdet_gfl_workspace_bytes(n, n_levels, max_cand, nms_pre) bytes, 256-byte aligned   */
+int64_t glsdet_gfl_workspace_bytes(int32_t n, int32_t n_levels, int32_t max_cand, int32_t nms_pre);
+int glsdet_gfl_detect(const glsdet_view* cls, const glsdet_view* reg, int32_t n_levels,
+                      const int32_t* strides /*host*/, int32_t num_classes, int32_t reg_max,
+                      int32_t in_h, int32_t in_w, const float* img_hw, const float* scale_factors,
+                      float score_thr, int32_t nms_pre, float iou_thr, int32_t max_cand, int32_t max_det,
+                      float* dets, int32_t* count, int32_t* status,
+                      void* ws, int64_t ws_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------
  * Plan: a recorded sequence of the calls above, replayed without Python in the loop and
  * capturable into one hipGraph (HIP streams + graphs instead of a tracing compiler).
  * Recording: glsdet_plan_begin(plan) makes every following entry-point call on this
@@ -182,7 +244,8 @@ int     glsdet_plan_end(glsdet_plan*);
  * forked from / joined into the main stream (parallel nodes of the captured hipGraph). */
 int     glsdet_plan_set_branch(int32_t branch);
 int32_t glsdet_plan_num_ops(const glsdet_plan*);
-/* kind: 0 conv, 1 focus, 2 maxpool, 3 resample, 4 nonlocal, 5 decode, 6 nms; flops = 2*MACs */
+/* kind: 0 conv, 1 focus/pack, 2 pool, 3 resample/upsample-add, 4 nonlocal, 5 decode, 6 nms,
+ * 7 groupnorm, 8 proxy scores; flops = 2*MACs */
 int     glsdet_plan_op_info(const glsdet_plan*, int32_t i, int32_t* kind, double* flops,
                             double* bytes, char* name, int32_t name_cap);
 int     glsdet_plan_run(glsdet_plan*, void* stream);               /* eager replay        */

@@ -1,0 +1,216 @@
+"""CPU oracle for the ResNet-50 + FPN + GFLHead / MPHead detectors (SURVEY section 8a rows
+A10, A11)  --  TEST INFRASTRUCTURE ONLY (same rules as glsdet_oracle.py: only tests/,
+__graft_entry__.smoke() and bench.py's cpu_baseline leg may import it).
+
+PARITY UNPINNED.  The reference's implementation of this path lives in ``yolox-ufp/mmdet``
+on top of mmcv-full (pinned ``>=1.3.17,<1.5.0``, yolox-ufp/mmdet/__init__.py:19-27), which
+is NOT under /root/reference and not importable here (``ConvModule``, ``Scale``,
+``batched_nms``, ``build_norm_layer`` ... are mmcv's).  The reference's own tests hold no
+numeric fixture for these modules.  This file restates the algorithm from the text of
+
+    ufp/mmdet/models/backbones/resnet.py      (Bottleneck :263-303, ResNet.forward :631-646)
+    ufp/mmdet/models/utils/res_layer.py        (downsample :39-61)
+    ufp/mmdet/models/necks/fpn.py              (FPN.forward :150-205)
+    ufp/mmdet/models/dense_heads/gfl_head.py   (Integral :16-49, forward_single :179-203,
+                                                _get_bboxes_single :380-471)
+    ufp/mmdet/models/dense_heads/mp_head.py    (forward_proxy :105-121, forward_single :123-154)
+    ufp/mmdet/models/dense_heads/base_dense_head.py (_bbox_post_process :226-301)
+    ufp/mmdet/core/utils/misc.py               (filter_scores_and_topk :119-165)
+    ufp/mmdet/core/bbox/transforms.py          (distance2bbox :153-165)
+    ufp/mmdet/core/anchor/anchor_generator.py  (single_level_grid_priors :263-281)
+
+and of mmcv's published behaviour for the pieces mmcv owns: ConvModule = conv (bias only
+when there is no norm) -> norm -> ReLU; Scale = multiply by a learned scalar; GroupNorm /
+BatchNorm2d are torch.nn's (eps 1e-5); batched_nms = per-class greedy NMS, IoU > thr
+suppresses, areas without +1, output in descending score order.
+State-dict key names are mmdet's (torchvision ResNet names for the backbone).
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from .glsdet_oracle import batched_nms
+
+Tensor = torch.Tensor
+SD = Dict[str, Tensor]
+RESNET_BN_EPS = 1e-5           # nn.BatchNorm2d default (mmcv build_norm_layer(dict(type='BN')))
+GN_EPS = 1e-5                  # nn.GroupNorm default
+STAGE_BLOCKS = {50: (3, 4, 6, 3), 101: (3, 4, 23, 3)}     # resnet.py arch_settings
+
+
+def _bn(sd: SD, p: str, x: Tensor) -> Tensor:
+    return F.batch_norm(x, sd[p + ".running_mean"], sd[p + ".running_var"], sd[p + ".weight"], sd[p + ".bias"],
+                        False, 0.0, RESNET_BN_EPS)
+
+
+def bottleneck(sd: SD, p: str, x: Tensor, stride: int) -> Tensor:
+    """resnet.py:263-303, style='pytorch' (stride on the 3x3): relu(bn3(conv3(relu(bn2(conv2(
+    relu(bn1(conv1(x)))))))) + identity) with identity = downsample(x) when present."""
+    out = torch.relu(_bn(sd, p + ".bn1", F.conv2d(x, sd[p + ".conv1.weight"])))
+    out = torch.relu(_bn(sd, p + ".bn2", F.conv2d(out, sd[p + ".conv2.weight"], None, stride, 1)))
+    out = _bn(sd, p + ".bn3", F.conv2d(out, sd[p + ".conv3.weight"]))
+    identity = x
+    if p + ".downsample.0.weight" in sd:          # res_layer.py:39-61: 1x1 conv (stride s) + BN
+        identity = _bn(sd, p + ".downsample.1", F.conv2d(x, sd[p + ".downsample.0.weight"], None, stride))
+    return torch.relu(out + identity)
+
+
+def resnet(sd: SD, p: str, x: Tensor, depth: int = 50, out_indices: Sequence[int] = (0, 1, 2, 3)) -> List[Tensor]:
+    """resnet.py:631-646: 7x7 s2 conv + BN + ReLU, 3x3 s2 max pool (pad 1), four stages."""
+    pre = p + "." if p else ""
+    x = torch.relu(_bn(sd, pre + "bn1", F.conv2d(x, sd[pre + "conv1.weight"], None, 2, 3)))
+    x = F.max_pool2d(x, 3, 2, 1)
+    outs = []
+    for i, nblocks in enumerate(STAGE_BLOCKS[depth]):
+        for j in range(nblocks):
+            x = bottleneck(sd, "%slayer%d.%d" % (pre, i + 1, j), x, 2 if (j == 0 and i > 0) else 1)
+        if i in out_indices:
+            outs.append(x)
+    return outs
+
+
+def _conv_b(sd: SD, p: str, x: Tensor, stride: int = 1, pad: int = 0) -> Tensor:
+    return F.conv2d(x, sd[p + ".weight"], sd.get(p + ".bias"), stride, pad)
+
+
+def fpn(sd: SD, p: str, inputs: Sequence[Tensor], start_level: int = 0, num_outs: int = 5,
+        add_extra_convs="on_output", relu_before_extra_convs: bool = False) -> List[Tensor]:
+    """fpn.py:150-205 (norm_cfg=None, act_cfg=None: every ConvModule is conv + bias only).
+    Top-down: laterals[i-1] += interpolate(laterals[i], size=laterals[i-1].shape, 'nearest')."""
+    n_lat = len(inputs) - start_level
+    lat = [_conv_b(sd, "%s.lateral_convs.%d.conv" % (p, i), inputs[i + start_level]) for i in range(n_lat)]
+    for i in range(n_lat - 1, 0, -1):
+        lat[i - 1] = lat[i - 1] + F.interpolate(lat[i], size=lat[i - 1].shape[2:], mode="nearest")
+    outs = [_conv_b(sd, "%s.fpn_convs.%d.conv" % (p, i), lat[i], 1, 1) for i in range(n_lat)]
+    if num_outs > len(outs):
+        if not add_extra_convs:
+            for _ in range(num_outs - n_lat):
+                outs.append(F.max_pool2d(outs[-1], 1, stride=2))
+        else:
+            src = {"on_input": inputs[-1], "on_lateral": lat[-1], "on_output": outs[-1]}[
+                "on_input" if add_extra_convs is True else add_extra_convs]
+            outs.append(_conv_b(sd, "%s.fpn_convs.%d.conv" % (p, n_lat), src, 2, 1))
+            for i in range(n_lat + 1, num_outs):
+                t = torch.relu(outs[-1]) if relu_before_extra_convs else outs[-1]
+                outs.append(_conv_b(sd, "%s.fpn_convs.%d.conv" % (p, i), t, 2, 1))
+    return outs
+
+
+def conv_gn_relu(sd: SD, p: str, x: Tensor, groups: int = 32) -> Tensor:
+    """mmcv ConvModule(norm_cfg=GN32): 3x3 conv without bias -> GroupNorm -> ReLU."""
+    y = F.conv2d(x, sd[p + ".conv.weight"], None, 1, 1)
+    return torch.relu(F.group_norm(y, groups, sd[p + ".gn.weight"], sd[p + ".gn.bias"], GN_EPS))
+
+
+def _towers(sd: SD, p: str, x: Tensor, stacked: int) -> Tuple[Tensor, Tensor]:
+    c = r = x
+    for i in range(stacked):
+        c = conv_gn_relu(sd, "%s.cls_convs.%d" % (p, i), c)
+    for i in range(stacked):
+        r = conv_gn_relu(sd, "%s.reg_convs.%d" % (p, i), r)
+    return c, r
+
+
+def gfl_head(sd: SD, p: str, feats: Sequence[Tensor], stacked: int = 4) -> Tuple[List[Tensor], List[Tensor]]:
+    """gfl_head.py:179-203; the towers and predictors are SHARED by all levels, Scale is per level."""
+    cls, reg = [], []
+    for l, x in enumerate(feats):
+        c, r = _towers(sd, p, x, stacked)
+        cls.append(_conv_b(sd, p + ".gfl_cls", c, 1, 1))
+        reg.append((_conv_b(sd, p + ".gfl_reg", r, 1, 1) * sd["%s.scales.%d.scale" % (p, l)]).float())
+    return cls, reg
+
+
+def forward_proxy(feat: Tensor, proxies: Tensor, proxies_list: Sequence[int], gamma: float) -> Tensor:
+    """mp_head.py:105-121: cosine similarity to every proxy; per class a softmax(gamma*sim)
+    weighted mean of that class's similarities, times gamma."""
+    centers = F.normalize(proxies, p=2, dim=1)
+    feat = F.normalize(feat, p=2, dim=1)
+    sim = feat.matmul(centers.t())
+    out, pos = [], 0
+    for k in proxies_list:
+        sub = sim[:, pos:pos + k]
+        out.append(torch.sum(F.softmax(sub * gamma, dim=1) * sub, dim=1)[:, None])
+        pos += k
+    return torch.cat(out, 1) * gamma
+
+
+def mp_head(sd: SD, p: str, feats: Sequence[Tensor], proxies_list: Sequence[int], gamma: float = 10.0,
+            stacked: int = 4) -> Tuple[List[Tensor], List[Tensor]]:
+    """mp_head.py:123-154 (eval branch): cls feature = gfl_cls_conv(cls tower), scored by
+    forward_proxy per position."""
+    cls, reg = [], []
+    for l, x in enumerate(feats):
+        c, r = _towers(sd, p, x, stacked)
+        reg.append((_conv_b(sd, p + ".gfl_reg", r, 1, 1) * sd["%s.scales.%d.scale" % (p, l)]).float())
+        f = _conv_b(sd, p + ".gfl_cls_conv", c, 1, 1)
+        b, ch, h, w = f.shape
+        s = forward_proxy(f.permute(0, 2, 3, 1).reshape(-1, ch), sd[p + ".proxies"], proxies_list, gamma)
+        cls.append(s.reshape(b, h, w, -1).permute(0, 3, 1, 2).contiguous())
+    return cls, reg
+
+
+def integral(x: Tensor, reg_max: int = 16) -> Tensor:
+    """gfl_head.py:16-49: expectation of the softmax over the reg_max+1 bins."""
+    x = F.softmax(x.reshape(-1, reg_max + 1), dim=1)
+    return F.linear(x, torch.linspace(0, reg_max, reg_max + 1).type_as(x)).reshape(-1, 4)
+
+
+def gfl_get_bboxes(cls_scores: Sequence[Tensor], bbox_preds: Sequence[Tensor], strides: Sequence[int],
+                   img_shapes: Sequence[Sequence[int]], score_thr: float, nms_pre: int, iou_thr: float,
+                   max_per_img: int, scale_factors=None, reg_max: int = 16):
+    """base_dense_head.get_bboxes -> gfl_head._get_bboxes_single :380-471 -> _bbox_post_process
+    :226-301.  Per image and level: sigmoid scores, (position, class) pairs with score >
+    score_thr, the nms_pre best of them (filter_scores_and_topk, misc.py:119-165; ties keep the
+    lower flat index first = stable sort), Integral * stride, distance2bbox from the anchor
+    centre (x*stride, y*stride) clamped to img_shape; levels concatenated, / scale_factor when
+    given, per-class NMS, first max_per_img.
+    -> list[img] of (dets ndarray(n,5) x1,y1,x2,y2,score ; labels ndarray(n) int64)."""
+    nc = cls_scores[0].shape[1]
+    results = []
+    for b in range(cls_scores[0].shape[0]):
+        boxes, scores, labels = [], [], []
+        for cls, reg, s in zip(cls_scores, bbox_preds, strides):
+            h, w = cls.shape[-2:]
+            dist = integral(reg[b].permute(1, 2, 0), reg_max) * s
+            sc = cls[b].permute(1, 2, 0).reshape(-1, nc).sigmoid()
+            valid = sc > score_thr
+            vs = sc[valid]
+            vidx = torch.nonzero(valid)
+            order = torch.sort(vs, descending=True, stable=True)[1][:min(nms_pre, vs.numel())]
+            keep, lab = vidx[order].unbind(1)
+            gy, gx = torch.meshgrid(torch.arange(h), torch.arange(w), indexing="ij")
+            cx, cy = (gx.flatten() * s).float()[keep], (gy.flatten() * s).float()[keep]
+            d = dist[keep]
+            bx = torch.stack((cx - d[:, 0], cy - d[:, 1], cx + d[:, 2], cy + d[:, 3]), -1)
+            bx[:, 0::2] = bx[:, 0::2].clamp(min=0, max=img_shapes[b][1])
+            bx[:, 1::2] = bx[:, 1::2].clamp(min=0, max=img_shapes[b][0])
+            boxes.append(bx), scores.append(vs[order]), labels.append(lab)
+        boxes, scores, labels = torch.cat(boxes), torch.cat(scores), torch.cat(labels)
+        if scale_factors is not None:
+            boxes = boxes / torch.as_tensor(np.asarray(scale_factors[b], np.float32))
+        if boxes.numel() == 0:
+            results.append((np.zeros((0, 5), np.float32), np.zeros((0,), np.int64)))
+            continue
+        bn, sn, ln = boxes.numpy(), scores.numpy(), labels.numpy()
+        keep = batched_nms(bn, sn, ln.astype(np.float32), iou_thr)[:max_per_img]
+        results.append((np.concatenate([bn[keep], sn[keep][:, None]], 1).astype(np.float32), ln[keep]))
+    return results
+
+
+# ------------------------------------------------------------------------------- detectors
+def gfl_forward(sd: SD, x: Tensor, start_level: int = 1, num_outs: int = 5, add_extra_convs="on_output"):
+    """SingleStageDetector.extract_feat + bbox_head (single_stage.py:41-60): GFL r50-FPN."""
+    feats = fpn(sd, "neck", resnet(sd, "backbone", x), start_level, num_outs, add_extra_convs)
+    return gfl_head(sd, "bbox_head", feats)
+
+
+def mpdet_forward(sd: SD, x: Tensor, proxies_list: Sequence[int], gamma: float = 10.0, start_level: int = 1,
+                  num_outs: int = 5, add_extra_convs="on_output"):
+    """MPDet (mpdet.py:9-18) = SingleStageDetector with MPHead."""
+    feats = fpn(sd, "neck", resnet(sd, "backbone", x), start_level, num_outs, add_extra_convs)
+    return mp_head(sd, "bbox_head", feats, proxies_list, gamma)

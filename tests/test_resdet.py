@@ -1,0 +1,380 @@
+"""ResNet-50 + FPN + GFLHead / MPHead.
+
+PARITY UNPINNED: the reference's mmdet/mmcv implementation of this path is not importable
+here and its tests hold no numeric fixtures (oracle/mpdet_oracle.py header).  The CPU part
+holds the restatement to hand-computed known answers and to an independent plain-torch
+re-derivation; the GPU part compares the HIP lowering with the restatement on seeded inputs.
+Tolerances as elsewhere: f32 per op 2e-5, per block 5e-5, whole model max(1e-4, 2 x the
+restatement's own fp32-vs-fp64 noise); f16 4e-3 / 2e-2 / stated per test."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import glsdet_oracle as O
+from oracle import mpdet_oracle as M
+from tests.helpers import calibrated_resdet_sd
+
+
+def _err(a, b):
+    return float((a - b).abs().max()) / max(1.0, float(b.abs().max()))
+
+
+# ------------------------------------------------------------------------------- CPU
+def test_integral_known_answer():
+    # one-hot-ish logits: mass on bin 3 / bin 16 / uniform (mean 8) / two equal bins 0 and 2 (mean 1)
+    x = torch.full((1, 68), -1e4)
+    x[0, 3] = 0.0
+    x[0, 17 + 16] = 0.0
+    x[0, 34:51] = 0.0
+    x[0, 51] = x[0, 53] = 0.0
+    np.testing.assert_allclose(M.integral(x).numpy(), [[3.0, 16.0, 8.0, 1.0]], atol=1e-5)
+
+
+def test_forward_proxy_known_answer():
+    # two classes, 1 and 2 proxies: class 0 score = gamma*cos; class 1 = gamma * softmax-weighted cos
+    prox = torch.tensor([[2.0, 0.0], [0.0, 3.0], [1.0, 1.0]])
+    feat = torch.tensor([[1.0, 0.0]])
+    got = M.forward_proxy(feat, prox, [1, 2], 10.0)
+    s = np.array([0.0, np.sqrt(0.5)])
+    w = np.exp(10 * s) / np.exp(10 * s).sum()
+    np.testing.assert_allclose(got.numpy(), [[10.0, 10 * float((w * s).sum())]], rtol=1e-5)
+
+
+def test_resnet_restatement_equals_an_independent_module_graph():
+    """Same weights through torch.nn modules wired as a torchvision-style ResNet-50."""
+    import torch.nn as nn
+    x = O.synth_input((1, 3, 64, 96), 1)
+    sd = calibrated_resdet_sd("gfl", 0, x)
+
+    class Block(nn.Module):
+        def __init__(self, cin, planes, stride, down):
+            super().__init__()
+            self.conv1, self.bn1 = nn.Conv2d(cin, planes, 1, bias=False), nn.BatchNorm2d(planes)
+            self.conv2, self.bn2 = nn.Conv2d(planes, planes, 3, stride, 1, bias=False), nn.BatchNorm2d(planes)
+            self.conv3, self.bn3 = nn.Conv2d(planes, planes * 4, 1, bias=False), nn.BatchNorm2d(planes * 4)
+            self.downsample = nn.Sequential(nn.Conv2d(cin, planes * 4, 1, stride, bias=False),
+                                            nn.BatchNorm2d(planes * 4)) if down else None
+
+        def forward(self, x):
+            o = F.relu(self.bn1(self.conv1(x)))
+            o = F.relu(self.bn2(self.conv2(o)))
+            o = self.bn3(self.conv3(o))
+            return F.relu(o + (x if self.downsample is None else self.downsample(x)))
+
+    class Net(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.conv1, self.bn1 = nn.Conv2d(3, 64, 7, 2, 3, bias=False), nn.BatchNorm2d(64)
+            cin = 64
+            for i, nb in enumerate((3, 4, 6, 3)):
+                blocks = []
+                for j in range(nb):
+                    blocks.append(Block(cin, 64 * 2 ** i, 2 if (j == 0 and i > 0) else 1, j == 0))
+                    cin = 256 * 2 ** i
+                setattr(self, "layer%d" % (i + 1), nn.Sequential(*blocks))
+
+        def forward(self, x):
+            x = F.max_pool2d(F.relu(self.bn1(self.conv1(x))), 3, 2, 1)
+            outs = []
+            for i in range(4):
+                x = getattr(self, "layer%d" % (i + 1))(x)
+                outs.append(x)
+            return outs
+    net = Net().eval()
+    net.load_state_dict({k[len("backbone."):]: v for k, v in sd.items() if k.startswith("backbone.")})
+    with torch.no_grad():
+        want = net(x)
+    got = M.resnet(sd, "backbone", x)
+    for g, w in zip(got, want):
+        assert g.shape == w.shape and _err(g, w) < 1e-5
+    assert [tuple(g.shape[1:]) for g in got] == [(256, 16, 24), (512, 8, 12), (1024, 4, 6), (2048, 2, 3)]
+
+
+def test_fpn_shapes_and_top_down_by_size():
+    # odd sizes: 13 -> 25 is NOT an integer factor; interpolate(size=) picks floor(dst*13/25)
+    sd = O.synth_state_dict({k: v for k, v in __import__("glsdet_amd.arch", fromlist=["x"]).resdet_state_dict_shapes(
+        "gfl").items() if k.startswith("neck.")}, 0)
+    ins = [O.synth_input((1, c, h, w), i) for i, (c, h, w) in enumerate(
+        [(256, 50, 42), (512, 25, 21), (1024, 13, 11), (2048, 7, 6)])]
+    outs = M.fpn(sd, "neck", ins, 1, 5, "on_output")
+    assert [tuple(o.shape[1:]) for o in outs] == [(256, 25, 21), (256, 13, 11), (256, 7, 6), (256, 4, 3), (256, 2, 2)]
+    lat2 = F.conv2d(ins[3], sd["neck.lateral_convs.2.conv.weight"], sd["neck.lateral_convs.2.conv.bias"])
+    lat1 = F.conv2d(ins[2], sd["neck.lateral_convs.1.conv.weight"], sd["neck.lateral_convs.1.conv.bias"])
+    idx_h = torch.tensor([min(int(np.floor(np.float32(i) * np.float32(7 / 13))), 6) for i in range(13)])
+    idx_w = torch.tensor([min(int(np.floor(np.float32(i) * np.float32(6 / 11))), 5) for i in range(11)])
+    want = F.conv2d(lat1 + lat2[:, :, idx_h][:, :, :, idx_w], sd["neck.fpn_convs.1.conv.weight"],
+                    sd["neck.fpn_convs.1.conv.bias"], 1, 1)
+    assert _err(outs[1], want) < 1e-6
+
+
+def test_gfl_get_bboxes_known_answer():
+    """1 level 2x2, stride 8, 2 classes, reg_max 2: hand-computed boxes, threshold, NMS."""
+    big, small = 10.0, -10.0
+    cls = torch.full((1, 2, 2, 2), small)
+    cls[0, 0, 0, 0] = big          # class 0 at (y0,x0)
+    cls[0, 0, 0, 1] = 2.0          # class 0 at (y0,x1), lower score, overlaps -> suppressed
+    cls[0, 1, 1, 1] = 1.0          # class 1 at (y1,x1)
+    reg = torch.full((1, 12, 2, 2), -1e4)
+    reg[0, [2, 5, 8, 11]] = 0.0    # every side: all mass on bin 2 -> distance 2*8 = 16
+    res = M.gfl_get_bboxes([cls], [reg], [8], [(16, 32, 3)], 0.05, 1000, 0.5, 100, reg_max=2)
+    dets, labels = res[0]
+    # anchors (0,0) and (8,0): boxes [-16,-16,16,16]->clamp [0,0,16,16] and [-8,-16,24,16]->[0,0,24,16]; IoU = 256/384 > .5
+    assert labels.tolist() == [0, 1]
+    np.testing.assert_allclose(dets[0], [0, 0, 16, 16, 1 / (1 + np.exp(-10.0))], rtol=1e-5)
+    np.testing.assert_allclose(dets[1], [0, 0, 24, 16, 1 / (1 + np.exp(-1.0))], rtol=1e-5)
+    # rescale divides boxes; nms_pre=1 keeps only the best pair of the level
+    res = M.gfl_get_bboxes([cls], [reg], [8], [(16, 32, 3)], 0.05, 1, 0.5, 100, scale_factors=[[2, 2, 2, 2]], reg_max=2)
+    np.testing.assert_allclose(res[0][0][:, :4], [[0, 0, 8, 8]])
+
+
+def test_state_dict_tables():
+    from glsdet_amd.arch import resdet_state_dict_shapes
+    t = resdet_state_dict_shapes("gfl", num_classes=80)
+    learn = lambda pre: sum(int(np.prod(v)) for k, v in t.items() if k.startswith(pre) and not k.endswith(
+        ("running_mean", "running_var", "num_batches_tracked", "project")))
+    # torchvision ResNet-50 has 25,557,032 parameters, 2,049,000 of them in the fc layer mmdet drops
+    assert learn("backbone.") == 25557032 - 2049000
+    assert learn("neck.") == (512 + 1024 + 2048) * 256 + 3 * 256 + 5 * (256 * 256 * 9 + 256)
+    assert learn("bbox_head.") == 8 * (256 * 256 * 9 + 512) + (256 * 80 * 9 + 80) + (256 * 68 * 9 + 68) + 5
+    assert t["backbone.layer4.0.downsample.0.weight"] == (2048, 1024, 1, 1)
+    assert t["neck.fpn_convs.4.conv.weight"] == (256, 256, 3, 3) and "neck.lateral_convs.3.conv.weight" not in t
+    m = resdet_state_dict_shapes("mpdet")
+    assert m["bbox_head.proxies"] == (42, 256) and m["bbox_head.gfl_cls_conv.weight"] == (256, 256, 3, 3)
+
+
+# ------------------------------------------------------------------------------- GPU
+@pytest.fixture(scope="module")
+def engines():
+    from glsdet_amd.engine import Engine
+    return {"f32": Engine("f32"), "f16": Engine("f16")}
+
+
+def _r(x, mode):
+    return x.half().float() if mode == "f16" else x
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["f32", "f16"])
+def test_nchw_pack(engines, mode):
+    eng = engines[mode]
+    x = O.synth_input((2, 3, 17, 23), 1)
+    out = eng.nchw_pack(x.cuda())
+    torch.cuda.synchronize()
+    assert out.c == 8
+    got = out.to_nchw().cpu()
+    assert torch.equal(got[:, :3], _r(x, mode)) and float(got[:, 3:].abs().max()) == 0.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["f32", "f16"])
+@pytest.mark.parametrize("k,s,p,hw", [(3, 2, 1, (20, 24)), (3, 2, 1, (25, 21)), (1, 2, 0, (7, 6)), (2, 2, 0, (8, 10))])
+def test_pool2d(engines, mode, k, s, p, hw):
+    from tests.test_hip_ops import _to_view
+    eng = engines[mode]
+    x = O.synth_input((2, 16) + hw, k)
+    out = eng.pool2d(_to_view(eng, x, embed=(32, 8)), k, s, p)
+    torch.cuda.synchronize()
+    assert torch.equal(out.to_nchw().cpu(), F.max_pool2d(_r(x, mode), k, s, p))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["f32", "f16"])
+@pytest.mark.parametrize("fine,coarse", [((20, 24), (10, 12)), ((25, 21), (13, 11)), ((13, 11), (7, 6)), ((9, 9), (9, 9))])
+def test_upsample_add(engines, mode, fine, coarse):
+    from tests.test_hip_ops import _to_view
+    eng = engines[mode]
+    a, b = O.synth_input((2, 32) + coarse, 1), O.synth_input((2, 32) + fine, 2)
+    fv = _to_view(eng, b)
+    eng.upsample_add(_to_view(eng, a, embed=(48, 8)), fv)
+    torch.cuda.synchronize()
+    want = _r(b, mode) + F.interpolate(_r(a, mode), size=fine, mode="nearest")
+    assert _err(fv.to_nchw().cpu(), want) <= (0.0 if mode == "f32" else 1e-3)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["f32", "f16"])
+@pytest.mark.parametrize("c,g,hw", [(256, 32, (20, 24)), (512, 64, (7, 11)), (64, 8, (33, 17)), (256, 32, (1, 2))])
+def test_groupnorm(engines, mode, c, g, hw):
+    from tests.test_hip_ops import _to_view
+    eng = engines[mode]
+    x = O.synth_input((2, c) + hw, c) * 3.0 + 1.5
+    ga, be = O.synth_input((c,), 1) * 0.3 + 1.0, O.synth_input((c,), 2) * 0.2
+    xv = _to_view(eng, x)
+    eng.groupnorm(xv, g, ga.cuda(), be.cuda(), 1e-5, "relu")
+    torch.cuda.synchronize()
+    want = torch.relu(F.group_norm(_r(x, mode), g, ga, be, 1e-5))
+    assert _err(xv.to_nchw().cpu(), want) <= (2e-5 if mode == "f32" else 4e-3)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["f32", "f16"])
+@pytest.mark.parametrize("k,cin,cout", [(1, 64, 256), (3, 32, 32)])
+def test_conv_residual_before_activation(engines, mode, k, cin, cout):
+    from tests.test_hip_ops import _to_view
+    eng = engines[mode]
+    g = torch.Generator().manual_seed(k)
+    x = torch.randn(2, cin, 12, 20, generator=g)
+    w = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5
+    sc, bi = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.2
+    res = torch.randn(2, cout, 12, 20, generator=g)
+    pk = eng.pack_conv([(w, sc, bi)], cin)
+    out = eng.conv(_to_view(eng, x), pk, 1, k // 2, "relu", res=_to_view(eng, res), res_first=True)
+    torch.cuda.synchronize()
+    want = torch.relu(F.conv2d(_r(x, mode), _r(w, mode), None, 1, k // 2) * sc.view(1, -1, 1, 1) + bi.view(1, -1, 1, 1)
+                      + _r(res, mode))
+    assert _err(out.to_nchw(cout).cpu(), want) <= (2e-5 if mode == "f32" else 4e-3)
+    other = torch.relu(want - _r(res, mode)) + _r(res, mode)          # the YOLOX order gives something else
+    assert _err(other, want) > 1e-2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["f32", "f16"])
+def test_proxy_scores(engines, mode):
+    from glsdet_amd.engine import F32
+    from tests.test_hip_ops import _to_view
+    eng = engines[mode]
+    counts = [2, 3, 2, 5, 4, 8, 8, 4, 3, 3]
+    feat = O.synth_input((2, 256, 9, 7), 3)
+    prox = O.synth_input((42, 256), 4)
+    centers = F.normalize(prox, dim=1)
+    fr = _r(feat, mode)
+    dots = torch.einsum("bchw,kc->bkhw", fr, centers)
+    dv = eng.tensor(2, 9, 7, 48, F32)
+    t = torch.zeros(2, 9, 7, 48)
+    t[..., :42] = dots.permute(0, 2, 3, 1)
+    dv.buf.view(torch.float32)[: t.numel()] = t.flatten().cuda()
+    out = eng.proxy_scores(_to_view(eng, feat), dv, counts, 10.0)
+    torch.cuda.synchronize()
+    want = M.forward_proxy(fr.permute(0, 2, 3, 1).reshape(-1, 256), prox, counts, 10.0).reshape(2, 9, 7, 10)
+    assert _err(out.to_nchw(10).cpu().permute(0, 2, 3, 1), want) <= 2e-5
+
+
+def _rand_head_outputs(seed, n, nc, sizes, reg_max=16, bias=-3.0):
+    g = torch.Generator().manual_seed(seed)
+    cls = [torch.randn(n, nc, h, w, generator=g) * 1.5 + bias for h, w in sizes]
+    reg = [torch.randn(n, 4 * (reg_max + 1), h, w, generator=g) * 2.0 for h, w in sizes]
+    return cls, reg
+
+
+def _fp32_view(eng, x_nchw):
+    from glsdet_amd.engine import F32
+    n, c, h, w = x_nchw.shape
+    v = eng.tensor(n, h, w, c, F32)
+    t = torch.zeros(n, h, w, v.c)
+    t[..., :c] = x_nchw.permute(0, 2, 3, 1)
+    v.buf.view(torch.float32)[: t.numel()] = t.flatten().cuda()
+    return v
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", [dict(seed=0, thr=0.05, nms_pre=1000, iou=0.6, maxdet=100, rescale=False),
+                                  dict(seed=1, thr=0.3, nms_pre=50, iou=0.5, maxdet=20, rescale=True),
+                                  dict(seed=2, thr=0.999, nms_pre=1000, iou=0.6, maxdet=100, rescale=False)])
+def test_gfl_detect_vs_oracle(engines, case):
+    """filter + per-level top-k + Integral decode + clamp + rescale + per-class NMS + max_per_img."""
+    eng = engines["f32"]
+    n, nc, strides = 2, 10, [8, 16, 32, 64, 128]
+    sizes = [(20, 24), (10, 12), (5, 6), (3, 3), (2, 2)]
+    cls, reg = _rand_head_outputs(case["seed"], n, nc, sizes)
+    img_shapes = [(150, 180, 3), (160, 192, 3)]
+    sf = [[1.5, 1.25, 1.5, 1.25], [0.5, 0.5, 0.5, 0.5]] if case["rescale"] else None
+    want = M.gfl_get_bboxes(cls, reg, strides, img_shapes, case["thr"], case["nms_pre"], case["iou"], case["maxdet"], sf)
+    nb = eng.gfl_buffers(n, 5, 4800, case["nms_pre"], case["maxdet"])
+    hw = torch.tensor([[s[0], s[1]] for s in img_shapes], dtype=torch.float32).cuda()
+    sft = torch.tensor(sf, dtype=torch.float32).cuda() if sf else None
+    dets, count, status = eng.gfl_detect([_fp32_view(eng, c) for c in cls], [_fp32_view(eng, r) for r in reg], strides,
+                                         nc, 16, 160, 192, case["thr"], case["iou"], nb, img_hw=hw, scale_factors=sft)
+    torch.cuda.synchronize()
+    assert int(status.item()) == 0
+    count, dets = count.cpu().numpy(), dets.cpu().numpy()
+    for i in range(n):
+        wd, wl = want[i]
+        assert count[i] == len(wl), (count[i], len(wl))
+        got = dets[i, : count[i]]
+        np.testing.assert_array_equal(got[:, 6].astype(np.int64), wl)
+        np.testing.assert_allclose(got[:, :4], wd[:, :4], atol=1e-3, rtol=1e-5)
+        np.testing.assert_allclose(got[:, 4], wd[:, 4], atol=1e-6)
+    if case["thr"] > 0.99:
+        assert sum(len(w[1]) for w in want) == 0
+
+
+@pytest.mark.gpu
+def test_gfl_detect_reports_overflow(engines):
+    eng = engines["f32"]
+    cls, reg = _rand_head_outputs(0, 1, 10, [(20, 24)], bias=3.0)      # nearly every pair passes
+    nb = eng.gfl_buffers(1, 1, 64, 1000, 100)
+    _, _, status = eng.gfl_detect([_fp32_view(eng, cls[0])], [_fp32_view(eng, reg[0])], [8], 10, 16, 160, 192, 0.05, 0.6, nb)
+    torch.cuda.synchronize()
+    assert int(status.item()) & 1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["f32", "f16"])
+def test_bottleneck_and_fpn_blocks(engines, mode):
+    from glsdet_amd.resdet import ResDetBuilder
+    from tests.test_hip_ops import _to_view
+    eng = engines[mode]
+    x0 = O.synth_input((1, 3, 64, 96), 1)
+    sd = calibrated_resdet_sd("gfl", 0, x0)
+    b = ResDetBuilder(eng, sd)
+    x = torch.relu(O.synth_input((2, 256, 12, 10), 5))
+    for p, stride in (("backbone.layer2.0", 2), ("backbone.layer1.1", 1)):
+        out = b.bottleneck(p, _to_view(eng, x), stride)
+        torch.cuda.synchronize()
+        want = M.bottleneck(sd, p, x, stride)
+        assert _err(out.to_nchw().cpu(), want) <= (5e-5 if mode == "f32" else 2e-2), p
+    ins = [O.synth_input((1, c, h, w), i) for i, (c, h, w) in enumerate(
+        [(256, 50, 42), (512, 25, 21), (1024, 13, 11), (2048, 7, 6)])]
+    outs = b.fpn("neck", [_to_view(eng, t) for t in ins], 1, 5, "on_output")
+    torch.cuda.synchronize()
+    for o, w in zip(outs, M.fpn(sd, "neck", ins, 1, 5, "on_output")):
+        assert _err(o.to_nchw().cpu(), w) <= (5e-5 if mode == "f32" else 2e-2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["gfl", "mpdet"])
+def test_detector_f32_vs_oracle(kind):
+    from glsdet_amd.resdet import HipGflDetector
+    x = O.synth_input((1, 3, 128, 160), 7)
+    sd = calibrated_resdet_sd(kind, 1, x)
+    fwd = (lambda s, t: M.gfl_forward(s, t)) if kind == "gfl" else \
+        (lambda s, t: M.mpdet_forward(s, t, HipGflDetector.DEFAULTS["proxies_list"]))
+    wc, wr = fwd(sd, x)
+    tc, tr = fwd({k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}, x.double())
+    noise = max(_err(a, b.float()) for a, b in zip(wc + wr, tc + tr))
+    det = HipGflDetector(kind, sd, dtype="f32")
+    gc, gr = det.forward_raw(x.cuda())
+    err = max(_err(g.cpu(), w) for g, w in zip(gc + gr, wc + wr))
+    print("%s f32: hip-vs-oracle %.2e, oracle fp32-vs-fp64 %.2e" % (kind, err, noise))
+    assert [tuple(g.shape) for g in gc] == [tuple(w.shape) for w in wc]
+    assert err <= max(1e-4, 2 * noise)
+    # detections end to end (boxes within 1e-3 px relative to the image size, same labels)
+    res = det.detect(x.cuda(), score_thr=0.3, iou_thr=0.6, nms_pre=1000, max_per_img=100, img_shapes=[(120, 150, 3)])
+    want = M.gfl_get_bboxes(wc, wr, [8, 16, 32, 64, 128], [(120, 150, 3)], 0.3, 1000, 0.6, 100)
+    assert abs(len(res[0][1]) - len(want[0][1])) <= max(2, len(want[0][1]) // 20)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["gfl", "mpdet"])
+def test_detector_f16_vs_oracle_and_graph(kind):
+    from glsdet_amd.resdet import HipGflDetector
+    x = O.synth_input((2, 3, 128, 160), 8)
+    sd = calibrated_resdet_sd(kind, 2, x)
+    wc, wr = M.gfl_forward(sd, x) if kind == "gfl" else M.mpdet_forward(sd, x, HipGflDetector.DEFAULTS["proxies_list"])
+    det = HipGflDetector(kind, sd, dtype="f16")
+    gc, gr = det.forward_raw(x.cuda())
+    scale = max(float(w.abs().max()) for w in wc + wr)
+    err = max(float((g.cpu() - w).abs().max()) for g, w in zip(gc + gr, wc + wr))
+    print("%s f16: max abs err %.3e of max |logit| %.2f" % (kind, err, scale))
+    assert err <= 0.15 * scale
+    post = dict(score_thr=0.3, iou_thr=0.6, nms_pre=1000, max_per_img=100)
+    c1 = det.compile(2, 128, 160, post)
+    det.run(c1, x.cuda())
+    eager = det.collect(c1)
+    c2 = det.compile(2, 128, 160, post, use_graph=True)
+    det.run(c2, x.cuda())
+    torch.cuda.synchronize()
+    graph = det.collect(c2)
+    for (a, la), (b, lb) in zip(eager, graph):
+        assert np.array_equal(a, b) and np.array_equal(la, lb)      # graph replay is bit-identical to eager
