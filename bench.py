@@ -46,7 +46,58 @@ WORKLOADS = {
     "yolox_s_glfusion_1344x800_bs8": ("gl", "gl_s_seed0", 800, 1344, 8),
     "yolox_s_glfusion_640x640_bs8": ("gl", "gl_s_seed0", 640, 640, 8),
     "yolox_s_base_640x640_bs8": ("base", "base_s_seed0", 640, 640, 8),
+    # UFPMP-Det detectors (configs/UFPMP-Det/*.py): ResNet-50 + FPN + GFLHead / MPHead
+    "mp_det_res50_1344x800_bs8": ("mpdet", None, 800, 1344, 8),
+    "coarse_det_1344x800_bs8": ("gfl", None, 800, 1344, 8),
 }
+RESDET = ("gfl", "mpdet")
+
+
+def resdet_algorithmic(kind, H, W, nc=10, proxies=42):
+    """Algorithmic (GMAC conv, GMAC matmul, HBM bytes fp16) per image of ResNet-50 + FPN(start 1,
+    5 outs, extra on_output) + GFLHead/MPHead by SURVEY 8d's rule: conv MACs = out elems x Cin x k^2
+    with the REAL channel counts; bytes = each conv reads its input once and writes its output once."""
+    mac = [0.0]
+    byt = [0.0]
+
+    def conv(h, w, cin, cout, k, s=1, pad=None):
+        pad = k // 2 if pad is None else pad
+        ho, wo = (h + 2 * pad - k) // s + 1, (w + 2 * pad - k) // s + 1
+        mac[0] += ho * wo * cout * cin * k * k
+        byt[0] += 2.0 * (h * w * cin + ho * wo * cout)
+        return ho, wo
+    h, w = conv(H, W, 3, 64, 7, 2)
+    h, w = (h + 2 - 3) // 2 + 1, (w + 2 - 3) // 2 + 1
+    cin, sizes = 64, []
+    for i, nb in enumerate((3, 4, 6, 3)):
+        planes = 64 * 2 ** i
+        for j in range(nb):
+            s = 2 if (j == 0 and i > 0) else 1
+            conv(h, w, cin, planes, 1)
+            ho, wo = conv(h, w, planes, planes, 3, s)
+            if j == 0:
+                conv(h, w, cin, planes * 4, 1, s, 0)
+            conv(ho, wo, planes, planes * 4, 1)
+            h, w, cin = ho, wo, planes * 4
+        sizes.append((h, w, cin))
+    lv = []
+    for (h, w, c) in sizes[1:]:
+        conv(h, w, c, 256, 1)
+        conv(h, w, 256, 256, 3)
+        lv.append((h, w))
+    for _ in range(2):
+        lv.append(conv(lv[-1][0], lv[-1][1], 256, 256, 3, 2))
+    mm = 0.0
+    for (h, w) in lv:
+        for _ in range(8):
+            conv(h, w, 256, 256, 3)
+        conv(h, w, 256, 68, 3)
+        if kind == "gfl":
+            conv(h, w, 256, nc, 3)
+        else:
+            conv(h, w, 256, 256, 3)
+            mm += h * w * 256 * proxies
+    return mac[0] / 1e9, mm / 1e9, byt[0]
 
 
 def synthetic_state_dict(tag):
@@ -92,6 +143,63 @@ def cpu_baseline(sd, kind, n, H, W, conf, nms_thr, budget_s=25.0):
     return {"value": round(n / dt, 3), "unit": "img/s", "cores": torch.get_num_threads(), "kind": "port",
             "sample": "%d timed iters (1 warm) of the same batch: %dx3x%dx%d fp32, forward+decode+NMS, torch CPU oracle"
                       % (iters, n, H, W)}
+
+
+def resdet_cpu_baseline(sd, kind, H, W, thr, budget_s=25.0):
+    """oracle/mpdet_oracle.py timed on the host cores on ONE image of the benchmark shape
+    (a bs-8 batch of ResNet-50 at 800x1344 does not fit the time budget)."""
+    from oracle import glsdet_oracle as O
+    from oracle import mpdet_oracle as M
+    from glsdet_amd.resdet import HipGflDetector
+    try:
+        ncpu = len(os.sched_getaffinity(0))
+    except AttributeError:
+        ncpu = os.cpu_count() or 1
+    torch.set_num_threads(max(1, min(ncpu, 64)))
+    x = O.synth_input((1, 3, H, W), 100)
+
+    def step():
+        with torch.no_grad():
+            c, r = M.gfl_forward(sd, x) if kind == "gfl" else M.mpdet_forward(sd, x, HipGflDetector.DEFAULTS["proxies_list"])
+            M.gfl_get_bboxes(c, r, [8, 16, 32, 64, 128], [(H, W, 3)], thr, 1000, 0.6, 100)
+    t0 = time.perf_counter()
+    step()
+    first = time.perf_counter() - t0
+    iters = int(max(1, min(5, (budget_s - first) // max(first, 1e-3))))
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        step()
+    dt = (time.perf_counter() - t0) / iters
+    return {"value": round(1 / dt, 3), "unit": "img/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "%d timed iters (1 warm) of ONE image 1x3x%dx%d fp32 (the bs-8 batch exceeds the time budget), "
+                      "forward+decode+NMS, torch CPU restatement (oracle/mpdet_oracle.py)" % (iters, H, W)}
+
+
+def calibrate_resdet(sd, kind, img, args, dev):
+    """Random-init class predictors pass almost every (position, class) pair.  To load the
+    post-processing like a real image (about --candidates pairs per image above the threshold):
+    GFLHead: one common shift of the gfl_cls bias (threshold stays the config's 0.05);
+    MPHead: the scores are cosines to random proxies (no bias to shift), so the score threshold
+    itself is bisected and reported in config.score_thr.  Setup only, not timed."""
+    from glsdet_amd.resdet import HipGflDetector
+    cls, _ = HipGflDetector(kind, sd, dtype=args.dtype, device=dev).forward_raw(img)
+    logits = torch.cat([c.flatten(1) for c in cls], 1)
+    if kind == "gfl":
+        lo, hi = -60.0, 20.0
+        for _ in range(40):
+            mid = 0.5 * (lo + hi)
+            n = float((torch.sigmoid(logits + mid) > 0.05).sum(1).float().mean())
+            lo, hi = (mid, hi) if n < args.candidates else (lo, mid)
+        sd = dict(sd)
+        sd["bbox_head.gfl_cls.bias"] = sd["bbox_head.gfl_cls.bias"] + 0.5 * (lo + hi)
+        return sd, 0.05
+    p = torch.sigmoid(logits)
+    lo, hi = 0.0, 1.0
+    for _ in range(40):
+        mid = 0.5 * (lo + hi)
+        n = float((p > mid).sum(1).float().mean())
+        lo, hi = (mid, hi) if n > args.candidates else (lo, mid)
+    return sd, round(0.5 * (lo + hi), 4)
 
 
 def calibrate_objectness(sd, kind, img, args, dev):
@@ -154,13 +262,24 @@ def main():
     from glsdet_amd.dist import gather_detections
 
     kind, tag, H, W, bs = WORKLOADS[args.workload]
-    sd = synthetic_state_dict(tag)
     gen = torch.Generator(device=dev).manual_seed(rank)
     img = torch.randn(bs, 3, H, W, generator=gen, device=dev)
-    sd = calibrate_objectness(sd, kind, img, args, dev)          # setup only, not timed
-    det = HipDetector(kind, sd, dtype=args.dtype, device=dev, autotune=not args.no_autotune)
-    post = dict(conf_thres=args.conf, nms_thres=args.nms, max_det=args.max_det)
     nstreams = 1 if args.no_graph else max(1, args.streams)
+    if kind in RESDET:
+        from glsdet_amd.resdet import HipGflDetector
+        from glsdet_amd.synth import synth_input, synth_resdet_state_dict
+        sd = synth_resdet_state_dict(kind, 0, synth_input((1, 3, 128, 160), 100))
+        sd, score_thr = calibrate_resdet(sd, kind, img, args, dev)
+        det = HipGflDetector(kind, sd, dtype=args.dtype, device=dev, autotune=not args.no_autotune)
+        post = dict(score_thr=score_thr, iou_thr=0.6, nms_pre=1000, max_per_img=100 if kind == "gfl" else 500,
+                    max_cand=16384)
+        buf = lambda ci: ci.nb
+    else:
+        sd = synthetic_state_dict(tag)
+        sd = calibrate_objectness(sd, kind, img, args, dev)          # setup only, not timed
+        det = HipDetector(kind, sd, dtype=args.dtype, device=dev, autotune=not args.no_autotune)
+        post = dict(conf_thres=args.conf, nms_thres=args.nms, max_det=args.max_det)
+        buf = lambda ci: ci.nmsb
     cs = [det.compile(bs, H, W, post, use_graph=not args.no_graph, instance=i) for i in range(nstreams)]
     for ci in cs:
         ci.img.copy_(img)                                        # resident in HBM before timing
@@ -174,14 +293,14 @@ def main():
         if args.no_graph:
             det.run(ci)
             if world > 1:
-                gather_detections(ci.nmsb["dets"], ci.nmsb["count"])
+                gather_detections(buf(ci)["dets"], buf(ci)["count"])
             return
         # one batch = one graph replay on the instance's own stream (+ its gather when N>1);
         # consecutive batches alternate instances, so two batches are in flight
-        HipDetector.run_async(ci)
+        det.run_async(ci)
         if world > 1:
             with torch.cuda.stream(ci.graph_stream):
-                gather_detections(ci.nmsb["dets"], ci.nmsb["count"])
+                gather_detections(buf(ci)["dets"], buf(ci)["count"])
 
     def fence():
         if world > 1:
@@ -200,7 +319,9 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    dets = HipDetector.collect(c)            # also checks the NMS capacity/overflow flags
+    dets = det.collect(c)                    # also checks the NMS capacity/overflow flags
+    if kind in RESDET:
+        dets = [d[0] for d in dets]
 
     # ---- per-op timing of the same plan (eager replay, HIP events on the launch stream)
     ops = c.plan.ops()
@@ -211,7 +332,11 @@ def main():
     torch.cuda.synchronize()
     conv = [(o, t) for o, t in zip(ops, ms) if o["kind"] == 0]
     executed_conv_flops = sum(o["flops"] for o, _ in conv)
-    alg_conv_gmac, alg_mm_gmac = ALGORITHMIC_GMAC[args.workload]
+    if kind in RESDET:
+        alg_conv_gmac, alg_mm_gmac, alg_bytes = resdet_algorithmic(kind, H, W)
+    else:
+        alg_conv_gmac, alg_mm_gmac = ALGORITHMIC_GMAC[args.workload]
+        alg_bytes = 431.8e6 if (H, W) == (800, 1344) else 164.5e6
     conv_flops = 2.0 * alg_conv_gmac * 1e9 * bs
     conv_ms = sum(t for _, t in conv)
     all_ms = float(ms.sum())
@@ -221,14 +346,17 @@ def main():
     # profiles/*/traffic.json, FETCH_SIZE doubled per the gfx950 correction) is reported.
     traffic = None
     cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "traffic.json")), key=os.path.getmtime)
-    if cands and args.workload == "yolox_s_glfusion_1344x800_bs8" and args.dtype == "f16":
-        with open(cands[-1]) as f:
-            traffic = round(json.load(f)["hbm_bytes_per_launch"])
+    for cand in reversed(cands):
+        with open(cand) as f:
+            tj = json.load(f)
+        if tj.get("workload", "yolox_s_glfusion_1344x800_bs8") == args.workload and args.dtype == "f16":
+            traffic = round(tj["hbm_bytes_per_launch"])
+            break
     roofline = {"bound": "mfma", "kernel": "conv family: conv_igemm + conv_halo + conv1x1_ws (all instantiations)",
                 "achieved": round(achieved, 2), "peak": PEAK_F16_TFLOPS if args.dtype == "f16" else 157.3,
                 "unit": "TFLOP/s", "frac": round(achieved / (PEAK_F16_TFLOPS if args.dtype == "f16" else 157.3), 4),
                 "traffic": traffic, "traffic_unit": "HBM bytes per conv launch (rocprofv3 PMC, profiles/)",
-                "algorithmic_bytes_per_launch": round(8 * 431.8e6 / max(1, len(conv))),
+                "algorithmic_bytes_per_launch": round(bs * alg_bytes / max(1, len(conv))),
                 "launches_per_step": len(conv),
                 "avg_launch_us": round(conv_ms * 1e3 / max(1, len(conv)), 2),
                 "gflop_per_launch": round(conv_flops / max(1, len(conv)) / 1e9, 3),
@@ -243,6 +371,11 @@ def main():
                     i, o["kind"], t, o["flops"] / 1e9, o["flops"] / max(t, 1e-6) / 1e9, o["bytes"] / 1e6,
                     o["bytes"] / max(t, 1e-6) / 1e6, o["name"]))
 
+    if kind in RESDET:      # stage-1 counters: [image][level] pairs above the threshold
+        nl = len(c.cls)
+        cand_counts = c.nb["ws"][: 4 * bs * nl].view(torch.int32).view(bs, nl).sum(1).cpu().tolist()
+    else:
+        cand_counts = [int(v) for v in c.nmsb["ws"][: 4 * bs].view(torch.int32).cpu().tolist()]
     if rank == 0:
         n_img = bs * world * args.steps
         line = {
@@ -251,17 +384,20 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": args.workload, "detector": "YOLOX-s + GL-fusion neck" if kind == "gl" else "YOLOX-s",
+            "config": {"workload": args.workload,
+                       "detector": {"gl": "YOLOX-s + GL-fusion neck", "base": "YOLOX-s", "gfl": "GFL ResNet-50 + FPN",
+                                    "mpdet": "MPDet ResNet-50 + FPN + MPHead"}[kind],
                        "input": [bs, 3, H, W], "images_per_gpu": bs, "global_batch": bs * world, "num_classes": 10,
-                       "conf_thres": args.conf, "nms_thres": args.nms, "hip_graph": not args.no_graph,
+                       "post": post, "hip_graph": not args.no_graph,
                        "batches_in_flight": nstreams,
                        "detections_per_image_rank0": [int(len(d)) for d in dets],
-                       "candidates_per_image_rank0": [int(v) for v in c.nmsb["ws"][: 4 * bs].view(torch.int32).cpu().tolist()],
+                       "candidates_per_image_rank0": cand_counts,
                        "parallelism": "image-sharded dp%d, one all_gather of detections per step" % world},
             "roofline": roofline,
         }
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(sd, kind, bs, H, W, args.conf, args.nms)
+            line["cpu_baseline"] = resdet_cpu_baseline(sd, kind, H, W, post["score_thr"]) if kind in RESDET else \
+                cpu_baseline(sd, kind, bs, H, W, args.conf, args.nms)
         print(json.dumps(line))
     if world > 1:
         dist.barrier()

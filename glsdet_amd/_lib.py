@@ -39,6 +39,9 @@ class ConvDesc(C.Structure):
 
 _SIGS = {
     "glsdet_conv2d": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
+    "glsdet_conv2d_multi": (C.c_int, [C.POINTER(ConvDesc), C.c_int32, C.c_void_p]),
+    "glsdet_conv2d_multi_tune": (C.c_int, [C.POINTER(ConvDesc), C.c_int32, C.c_void_p, C.POINTER(C.c_int32),
+                                           C.POINTER(C.c_float)]),
     "glsdet_conv2d_tune": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_float)]),
     "glsdet_dwconv2d": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
     "glsdet_conv_weight_elems": (C.c_int64, [C.c_int32] * 5),

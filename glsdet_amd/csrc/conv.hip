@@ -15,6 +15,8 @@
 //        identically for A and B, so the dot product is unchanged) -- exact f32.
 // Epilogue: scale/bias/activation in fp32 on the accumulator, tile transposed through LDS,
 // written (and the residual read) as full 16-byte channel chunks per pixel.
+#include <stdlib.h>
+
 #include "conv_common.h"
 
 namespace glsdet {
@@ -26,8 +28,11 @@ constexpr int conv_lds_bytes() {
   return stage > epi ? stage : epi;
 }
 
-template <typename T, typename TO, int CO_T, int PX_T, int KB, int WCO>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
+// UT ("uniform tap"): Cin * sizeof(T) is a multiple of KB, so all chunks of a K step belong to ONE
+// filter tap and the tap walk (kr, ks, channel base) is scalar: a K step then costs one VALU add
+// per 16-byte chunk (plus the padding test when the conv pads) instead of ~10.
+template <typename T, typename TO, int CO_T, int PX_T, int KB, int WCO, bool UT>
+__device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid, const int nwg) {
   constexpr int RS = KB + 16;                    // LDS row stride, bytes
   constexpr int VEC = 16 / (int)sizeof(T);       // elements per 16-B chunk
   constexpr int KE = KB / (int)sizeof(T);        // k elements per step
@@ -49,7 +54,6 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
   // run of tiles, cout tile fastest, so the im2col rows they share stay in that XCD's L2.
   int tile;
   {
-    const int nwg = gridDim.x, bid = blockIdx.x;
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, local = bid >> 3;
     tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
   }
@@ -102,17 +106,57 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
     ks = tap - kr * a.S;
   }
 
+  const int nsteps = (a.kreal + KE - 1) / KE;
   // register ring of three K-step tiles: the loads of step t+3 are issued while step t is
   // multiplied (a 64x64 tile's MFMA phase is ~0.1 us, one step of lookahead cannot cover an
   // L2/HBM round trip; the small-K / small-tile layers were latency bound on it)
   u32x4 ra0[NA], rb0[NB], ra1[NA], rb1[NB], ra2[NA], rb2[NB];
-  const int nsteps = (a.kreal + KE - 1) / KE;
 
+  // Every load below is issued UNCONDITIONALLY (steps past the end read through GLS_OOB and
+  // return zeros without touching memory): the compiler can then count the loads in flight
+  // and waits with s_waitcnt vmcnt(N) for exactly the set it needs.  A load under a branch
+  // makes it fall back to vmcnt(0), which exposes a full L2/HBM round trip per K step.
+  // UT state: scalar tap walk + per-chunk byte offsets that already hold everything per-thread
+  int u_kr = 0, u_ks = 0, u_kci = 0;                     // wave-uniform
+  unsigned ub[NB];                                       // x_off + (pixel origin + chunk column) bytes, or GLS_OOB
+  const bool u_nopad = a.pad == 0 && (a.Ho - 1) * a.stride + a.R <= a.H && (a.Wo - 1) * a.stride + a.S <= a.W;
+  if (UT) {
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+      ub[i] = pok[i] ? a.x_off + (unsigned)((boff[i] + kc * VEC) * (int)sizeof(T)) : GLS_OOB;
+  }
   auto gload = [&](int step, u32x4 (&ra)[NA], u32x4 (&rb)[NB]) __attribute__((always_inline)) {
+    const bool live = step < nsteps && !((a.dbg & 1) && step > 0);
+    if (UT) {
+      const unsigned kbyte = live ? (unsigned)step * KB : GLS_OOB;       // scalar
+#pragma unroll
+      for (int i = 0; i < NA; ++i) ra[i] = gls_buf_load16(wrs, wp[i] + kbyte);
+      const unsigned toff = live ? (unsigned)(((long)u_kr * a.x_sh + (long)u_ks * a.x_sw + u_kci) * (long)sizeof(T))
+                                 : GLS_OOB;                             // scalar
+      if (u_nopad) {
+#pragma unroll
+        for (int i = 0; i < NB; ++i) rb[i] = gls_buf_load16(xrs, ub[i] + toff);
+      } else {
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+          const bool ok = (unsigned)(hi0[i] + u_kr) < (unsigned)a.H && (unsigned)(wi0[i] + u_ks) < (unsigned)a.W;
+          rb[i] = gls_buf_load16(xrs, ok ? ub[i] + toff : GLS_OOB);
+        }
+      }
+      u_kci += KE;
+      if (u_kci == a.Cin) {
+        u_kci = 0;
+        if (++u_ks == a.S) {
+          u_ks = 0;
+          ++u_kr;
+        }
+      }
+      return;
+    }
     const unsigned kbyte = (unsigned)step * KB;
 #pragma unroll
-    for (int i = 0; i < NA; ++i) ra[i] = gls_buf_load16(wrs, wp[i] + kbyte);   // GLS_OOB + small stays out of range
-    const bool kval = kr < a.R;
+    for (int i = 0; i < NA; ++i) ra[i] = gls_buf_load16(wrs, live ? wp[i] + kbyte : GLS_OOB);   // GLS_OOB + small stays out of range
+    const bool kval = live && kr < a.R;
     const int tapoff = (int)((long)kr * a.x_sh + (long)ks * a.x_sw) + kci;
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
@@ -121,11 +165,20 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
       rb[i] = gls_buf_load16(xrs, ok ? a.x_off + (unsigned)((boff[i] + tapoff) * (int)sizeof(T)) : GLS_OOB);
     }
     kci += KE;
-    while (kci >= a.Cin) {
-      kci -= a.Cin;
-      if (++ks == a.S) {
-        ks = 0;
-        ++kr;
+    if (a.Cin >= KE) {          // at most one tap boundary per step: selects, no loop
+      const bool wrap = kci >= a.Cin;
+      kci -= wrap ? a.Cin : 0;
+      ks += wrap ? 1 : 0;
+      const bool wrap2 = ks == a.S;
+      ks = wrap2 ? 0 : ks;
+      kr += wrap2 ? 1 : 0;
+    } else {
+      while (kci >= a.Cin) {
+        kci -= a.Cin;
+        if (++ks == a.S) {
+          ks = 0;
+          ++kr;
+        }
       }
     }
   };
@@ -134,13 +187,13 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
       const int row = row0 + i * ROWS_PER_PASS;
-      if (row < CO_T) *reinterpret_cast<u32x4*>(sa + row * RS) = ra[i];
+      if (CO_T % ROWS_PER_PASS == 0 || row < CO_T) *reinterpret_cast<u32x4*>(sa + row * RS) = ra[i];
     }
     unsigned char* sb = sa + CO_T * RS;
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
       const int row = row0 + i * ROWS_PER_PASS;
-      if (row < PX_T) *reinterpret_cast<u32x4*>(sb + row * RS) = rb[i];
+      if (PX_T % ROWS_PER_PASS == 0 || row < PX_T) *reinterpret_cast<u32x4*>(sb + row * RS) = rb[i];
     }
   };
 
@@ -159,40 +212,44 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
 
   gload(0, ra0, rb0);
   lstore(0, ra0, rb0);
-  if (nsteps > 1) gload(1, ra1, rb1);
-  if (nsteps > 2) gload(2, ra2, rb2);
+  gload(1, ra1, rb1);
+  gload(2, ra2, rb2);
   __syncthreads();
 
   // one K step: issue step t+3 into the set that held step t (already in LDS), multiply step t
-  // from LDS buffer t&1, then move step t+1 (in flight for two steps) into the other buffer
+  // from LDS buffer t&1, then move step t+1 (in flight for two steps) into the other buffer.
+  // Loads, LDS stores and the barrier are unconditional (see gload); only the LDS-read + MFMA
+  // part is skipped for the up to two padding steps that round the loop to a multiple of 3.
   auto kstep = [&](int t, u32x4 (&fa)[NA], u32x4 (&fb)[NB], const u32x4 (&na)[NA], const u32x4 (&nb)[NB])
       __attribute__((always_inline)) {
     const int cur = t & 1;
-    if (t + 3 < nsteps) gload(t + 3, fa, fb);
+    gload(t + 3, fa, fb);
     const unsigned char* sbuf = smem + cur * STAGE;
+    if (t < nsteps && !(a.dbg & 2)) {
 #pragma unroll
-    for (int kk = 0; kk < KB / 32; ++kk) {
-      u32x4 af[TM], bf[TN];
+      for (int kk = 0; kk < KB / 32; ++kk) {
+        u32x4 af[TM], bf[TN];
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
-        af[i] = *reinterpret_cast<const u32x4*>(sbuf + a_off + i * 32 * RS + kk * 32);
+        for (int i = 0; i < TM; ++i)
+          af[i] = *reinterpret_cast<const u32x4*>(sbuf + a_off + i * 32 * RS + kk * 32);
 #pragma unroll
-      for (int j = 0; j < TN; ++j)
-        bf[j] = *reinterpret_cast<const u32x4*>(sbuf + b_off + j * 32 * RS + kk * 32);
+        for (int j = 0; j < TN; ++j)
+          bf[j] = *reinterpret_cast<const u32x4*>(sbuf + b_off + j * 32 * RS + kk * 32);
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) MMA<T>::run(af[i], bf[j], acc[i][j]);
+          for (int j = 0; j < TN; ++j) MMA<T>::run(af[i], bf[j], acc[i][j]);
+      }
     }
-    if (t + 1 < nsteps) lstore(cur ^ 1, na, nb);
+    lstore(cur ^ 1, na, nb);
     __syncthreads();
   };
   for (int t = 0; t < nsteps; t += 3) {
     kstep(t, ra0, rb0, ra1, rb1);
-    if (t + 1 < nsteps) kstep(t + 1, ra1, rb1, ra2, rb2);
-    if (t + 2 < nsteps) kstep(t + 2, ra2, rb2, ra0, rb0);
+    kstep(t + 1, ra1, rb1, ra2, rb2);
+    kstep(t + 2, ra2, rb2, ra0, rb0);
   }
-
+  if (a.dbg & 4) return;
   // ---- epilogue: fp32 scale/bias/act, transpose through LDS, 16-B channel chunks out
   constexpr int ORS = CO_T * (int)sizeof(TO) + 16;
 #pragma unroll
@@ -233,12 +290,36 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
   }
 }
 
+template <typename T, typename TO, int CO_T, int PX_T, int KB, int WCO, bool UT>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
+  conv_igemm_body<T, TO, CO_T, PX_T, KB, WCO, UT>(a, blockIdx.x, gridDim.x);
+}
+
+// Several independent convolutions of the SAME shape class (kernel size, stride, channels, dtypes:
+// the four quadrant convs of the GL-fusion block, the cls/reg tower convs of one level) as ONE
+// launch: each is too small to fill 256 CUs on its own.  The argument blocks travel in the kernarg
+// segment; a workgroup finds its problem from the prefix of tile counts (wave-uniform).
+#define GLS_MULTI 4
+struct ConvArgsN {
+  ConvArgs p[GLS_MULTI];
+  int start[GLS_MULTI + 1];
+  int n;
+};
+template <typename T, typename TO, int CO_T, int PX_T, int KB, int WCO, bool UT>
+__global__ __launch_bounds__(256) void conv_igemm_multi_kernel(const ConvArgsN m) {
+  int g = 0;
+#pragma unroll
+  for (int i = 1; i < GLS_MULTI; ++i)
+    if (i < m.n && (int)blockIdx.x >= m.start[i]) g = i;
+  conv_igemm_body<T, TO, CO_T, PX_T, KB, WCO, UT>(m.p[g], (int)blockIdx.x - m.start[g], m.start[g + 1] - m.start[g]);
+}
+
 // ---- host side --------------------------------------------------------------------------
-template <typename T, typename TO, int CO_T, int PX_T, int KB, int WCO>
+template <typename T, typename TO, int CO_T, int PX_T, int KB, int WCO, bool UT>
 static int launch_conv(const ConvArgs& a, hipStream_t st) {
   constexpr int lds = conv_lds_bytes<CO_T, PX_T, KB, TO>();
   static bool attr_set = false;
-  auto kern = conv_igemm_kernel<T, TO, CO_T, PX_T, KB, WCO>;
+  auto kern = conv_igemm_kernel<T, TO, CO_T, PX_T, KB, WCO, UT>;
   if (!attr_set && lds > 64 * 1024) {
     GLS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds));
@@ -256,12 +337,60 @@ static int launch_conv(const ConvArgs& a, hipStream_t st) {
   return 0;
 }
 
+template <typename T, typename TO, int CO_T, int PX_T, int KB, int WCO, bool UT>
+static int launch_conv_multi(const ConvArgsN& m0, hipStream_t st) {
+  constexpr int lds = conv_lds_bytes<CO_T, PX_T, KB, TO>();
+  static bool attr_set = false;
+  auto kern = conv_igemm_multi_kernel<T, TO, CO_T, PX_T, KB, WCO, UT>;
+  if (!attr_set && lds > 64 * 1024) {
+    GLS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    attr_set = true;
+  }
+  ConvArgsN m = m0;
+  long grid = 0;
+  for (int i = 0; i < m.n; ++i) {
+    ConvArgs& b = m.p[i];
+    b.n_co_tiles = (b.cout_pad + CO_T - 1) / CO_T;
+    if ((b.n_co_tiles - 1) * CO_T >= b.Cout) b.n_co_tiles = (b.Cout + CO_T - 1) / CO_T;
+    b.n_px_tiles = (b.M + PX_T - 1) / PX_T;
+    m.start[i] = (int)grid;
+    grid += (long)b.n_co_tiles * b.n_px_tiles;
+  }
+  for (int i = m.n; i <= GLS_MULTI; ++i) m.start[i] = (int)grid;
+  if (grid <= 0 || grid > 0x7fffffffL) GLS_FAIL(GLSDET_E_ARG, "conv2d_multi: grid %ld out of range", grid);
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, st, m);
+  GLS_HIP(hipGetLastError());
+  return 0;
+}
+
+template <typename T, typename TO>
+static int dispatch_tile_multi(const ConvArgsN& m, int co_t, int px_t, int kb, hipStream_t st) {
+  const bool ut = ((long)m.p[0].Cin * (long)sizeof(T)) % kb == 0;
+#define GLS_CASE(CO, PX, WCO_)                                                                      \
+  if (co_t == CO && px_t == PX) {                                                                   \
+    if (ut) return kb == 128 ? launch_conv_multi<T, TO, CO, PX, 128, WCO_, true>(m, st)             \
+                             : launch_conv_multi<T, TO, CO, PX, 64, WCO_, true>(m, st);             \
+    return kb == 128 ? launch_conv_multi<T, TO, CO, PX, 128, WCO_, false>(m, st)                    \
+                     : launch_conv_multi<T, TO, CO, PX, 64, WCO_, false>(m, st);                    \
+  }
+  GLS_CASE(128, 128, 2)
+  GLS_CASE(64, 128, 2)
+  GLS_CASE(64, 64, 2)
+#undef GLS_CASE
+  GLS_FAIL(GLSDET_E_ARG, "conv2d_multi: no kernel for tile %dx%d", co_t, px_t);
+}
+
 template <typename T, typename TO>
 static int dispatch_tile(const ConvArgs& a, int co_t, int px_t, int kb, hipStream_t st) {
-#define GLS_CASE(CO, PX, WCO_)                                              \
-  if (co_t == CO && px_t == PX) {                                           \
-    return kb == 128 ? launch_conv<T, TO, CO, PX, 128, WCO_>(a, st)         \
-                     : launch_conv<T, TO, CO, PX, 64, WCO_>(a, st);         \
+  static const bool no_ut = getenv("GLSDET_NO_UT") != nullptr;            // A/B switch for measurements
+  const bool ut = !no_ut && ((long)a.Cin * (long)sizeof(T)) % kb == 0;     // every K step inside one filter tap
+#define GLS_CASE(CO, PX, WCO_)                                                                      \
+  if (co_t == CO && px_t == PX) {                                                                   \
+    if (ut) return kb == 128 ? launch_conv<T, TO, CO, PX, 128, WCO_, true>(a, st)                   \
+                             : launch_conv<T, TO, CO, PX, 64, WCO_, true>(a, st);                   \
+    return kb == 128 ? launch_conv<T, TO, CO, PX, 128, WCO_, false>(a, st)                          \
+                     : launch_conv<T, TO, CO, PX, 64, WCO_, false>(a, st);                          \
   }
   GLS_CASE(128, 128, 2)
   GLS_CASE(64, 128, 2)
@@ -274,7 +403,7 @@ static int dispatch_tile(const ConvArgs& a, int co_t, int px_t, int kb, hipStrea
 static void pick_tile(const ConvArgs& a, int elem, int hint, int* co_t, int* px_t, int* kb) {
   if (hint) {
     *co_t = hint >> 16;
-    *px_t = hint & 0x7fff;
+    *px_t = hint & 0xff;
   } else {
     // largest tile that still gives the chip >= 3 workgroups per CU; below that the layer
     // is latency bound and more, smaller workgroups win over MFMA density
@@ -309,8 +438,8 @@ extern "C" int64_t glsdet_conv_weight_elems(int32_t cout, int32_t R, int32_t S, 
   return (int64_t)glsdet_conv_cout_pad(cout) * glsdet_conv_kpad(R, S, cin, dtype);
 }
 
-// validate the descriptor and build the op for `hint` (d->tile_hint is ignored here)
-static int build_conv_op(const glsdet_conv_desc* d, int hint, OpRecord& op) {
+// validate the descriptor and fill the kernel argument block
+static int make_conv_args(const glsdet_conv_desc* d, int hint, ConvArgs& a, double* flops, double* bytes) {
   if (!d) GLS_FAIL(GLSDET_E_ARG, "conv2d: null descriptor");
   const glsdet_view &x = d->x, &y = d->y;
   int rc;
@@ -338,7 +467,6 @@ static int build_conv_op(const glsdet_conv_desc* d, int hint, OpRecord& op) {
   const long M = (long)x.n * Ho * Wo;
   if (M <= 0 || M > 0x7fffffffL) GLS_FAIL(GLSDET_E_ARG, "conv2d: pixel count %ld out of range", M);
 
-  ConvArgs a;
   a.x = (const unsigned char*)x.base;
   a.w = (const unsigned char*)d->w;
   a.scale = d->scale;
@@ -353,6 +481,7 @@ static int build_conv_op(const glsdet_conv_desc* d, int hint, OpRecord& op) {
   a.R = d->R; a.S = d->S; a.stride = d->stride; a.pad = d->pad;
   a.act = d->act & 0xff;
   a.act_post = 0;
+  a.dbg = hint > 3 ? (hint >> 8) & 7 : 0;
   if ((d->act & GLSDET_ACT_RES_FIRST) && has_res) { a.act_post = a.act; a.act = GLSDET_ACT_NONE; }
   a.kreal = d->R * d->S * x.c;
   a.kpad = glsdet_conv_kpad(d->R, d->S, x.c, x.dtype);
@@ -372,10 +501,20 @@ static int build_conv_op(const glsdet_conv_desc* d, int hint, OpRecord& op) {
   a.r_lin = (has_res && d->res.sh == (int64_t)Wo * d->res.sw && d->res.sn == (int64_t)Ho * d->res.sh) ? 1 : 0;
 
   const int xdt = x.dtype, ydt = y.dtype;
+  *flops = 2.0 * (double)M * y.c * a.kreal;
+  *bytes = (double)x.n * x.h * x.w * x.c * dtype_size(xdt) + (double)M * y.c * dtype_size(ydt) * (has_res ? 2 : 1) +
+           (double)a.cout_pad * a.kpad * dtype_size(xdt);
+  return 0;
+}
+
+// validate the descriptor and build the op for `hint` (d->tile_hint is ignored here)
+static int build_conv_op(const glsdet_conv_desc* d, int hint, OpRecord& op) {
+  ConvArgs a;
   op.kind = 0;
-  op.flops = 2.0 * (double)M * y.c * a.kreal;
-  op.bytes = (double)x.n * x.h * x.w * x.c * dtype_size(xdt) + (double)M * y.c * dtype_size(ydt) * (has_res ? 2 : 1) +
-             (double)a.cout_pad * a.kpad * dtype_size(xdt);
+  int rc = make_conv_args(d, hint, a, &op.flops, &op.bytes);
+  if (rc) return rc;
+  const glsdet_view &x = d->x, &y = d->y;
+  const int xdt = x.dtype, ydt = y.dtype;
   // tile_hint: 0 auto, 1 generic kernel, 2 halo kernel, 3 weight-stationary 1x1 kernel, else co<<16|px (generic)
   if (hint == 3) {
     if (conv1x1_ws_try(a, xdt, ydt, &op) == 0) return 0;
@@ -396,6 +535,85 @@ static int build_conv_op(const glsdet_conv_desc* d, int hint, OpRecord& op) {
     if (xdt == GLSDET_F16 && ydt == GLSDET_F32) return dispatch_tile<f16, float>(a, co_t, px_t, kb, st);
     return dispatch_tile<float, float>(a, co_t, px_t, kb, st);
   };
+  return 0;
+}
+
+static int build_conv_multi_op(const glsdet_conv_desc* d, int32_t n, int hint, OpRecord& op) {
+  if (!d || n < 1 || n > GLS_MULTI) GLS_FAIL(GLSDET_E_ARG, "conv2d_multi: 1..%d descriptors", GLS_MULTI);
+  ConvArgsN m = {};
+  m.n = n;
+  op.kind = 0;
+  op.flops = op.bytes = 0;
+  long Mtot = 0;
+  for (int i = 0; i < n; ++i) {
+    double fl, by;
+    int rc = make_conv_args(&d[i], hint, m.p[i], &fl, &by);
+    if (rc) return rc;
+    op.flops += fl;
+    op.bytes += by;
+    Mtot += m.p[i].M;
+    const ConvArgs &a = m.p[i], &b = m.p[0];
+    if (d[i].x.dtype != d[0].x.dtype || d[i].y.dtype != d[0].y.dtype || a.R != b.R || a.S != b.S || a.stride != b.stride ||
+        a.pad != b.pad || a.Cin != b.Cin || a.Cout != b.Cout)
+      GLS_FAIL(GLSDET_E_ARG, "conv2d_multi: descriptor %d is not of the shape class of descriptor 0", i);
+  }
+  int co_t, px_t, kb;
+  ConvArgs probe = m.p[0];
+  probe.M = (int)(Mtot > 0x7fffffffL ? 0x7fffffffL : Mtot);
+  pick_tile(probe, dtype_size(d[0].x.dtype), hint > 3 ? hint : 0, &co_t, &px_t, &kb);
+  if (co_t == 32) { co_t = 64; px_t = 64; }
+  const int xdt = d[0].x.dtype, ydt = d[0].y.dtype;
+  char nm[112];
+  snprintf(nm, sizeof nm, "conv_igemm_multi[%d]<%s,%s,%dx%d,kb%d> %dx%d s%d cin%d cout%d", n, xdt ? "f32" : "f16",
+           ydt ? "f32" : "f16", co_t, px_t, kb, d[0].R, d[0].S, d[0].stride, d[0].x.c, d[0].y.c);
+  op.name = nm;
+  op.launch = [m, co_t, px_t, kb, xdt, ydt](hipStream_t st) -> int {
+    if (xdt == GLSDET_F16 && ydt == GLSDET_F16) return dispatch_tile_multi<f16, f16>(m, co_t, px_t, kb, st);
+    if (xdt == GLSDET_F16 && ydt == GLSDET_F32) return dispatch_tile_multi<f16, float>(m, co_t, px_t, kb, st);
+    return dispatch_tile_multi<float, float>(m, co_t, px_t, kb, st);
+  };
+  return 0;
+}
+
+extern "C" int glsdet_conv2d_multi(const glsdet_conv_desc* d, int32_t n, void* stream) {
+  OpRecord op;
+  int rc = build_conv_multi_op(d, n, d ? d[0].tile_hint : 0, op);
+  if (rc) return rc;
+  return submit(std::move(op), stream);
+}
+
+extern "C" int glsdet_conv2d_multi_tune(const glsdet_conv_desc* d, int32_t n, void* stream, int32_t* best_hint,
+                                        float* best_us) {
+  if (!d || !best_hint) GLS_FAIL(GLSDET_E_ARG, "conv2d_multi_tune: null argument");
+  hipStream_t st = (hipStream_t)stream;
+  const int hints[] = {(128 << 16) | 128, (64 << 16) | 128, (64 << 16) | 64, (64 << 16) | 64 | 0x8000,
+                       (64 << 16) | 128 | 0x8000, (128 << 16) | 128 | 0x8000};
+  hipEvent_t e0, e1;
+  GLS_HIP(hipEventCreate(&e0));
+  GLS_HIP(hipEventCreate(&e1));
+  float best = 1e30f;
+  int bh = 0, any = 0;
+  for (int h : hints) {
+    OpRecord op;
+    if (build_conv_multi_op(d, n, h, op)) continue;
+    int rc = op.launch(st);
+    if (rc) continue;
+    const int reps = 5;
+    (void)hipEventRecord(e0, st);
+    for (int r = 0; r < reps && !rc; ++r) rc = op.launch(st);
+    (void)hipEventRecord(e1, st);
+    if (hipEventSynchronize(e1) != hipSuccess || rc) continue;
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    any = 1;
+    if (ms < best) { best = ms; bh = h; }
+  }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  if (!any) GLS_FAIL(GLSDET_E_ARG, "conv2d_multi_tune: no variant applies");
+  *best_hint = bh;
+  if (best_us) *best_us = best * 1000.f / 5.f;
+  set_error("");
   return 0;
 }
 

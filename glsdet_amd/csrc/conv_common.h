@@ -18,6 +18,7 @@ struct ConvArgs {
   int N, H, W, Cin;
   int Ho, Wo, Cout, cout_pad;
   int R, S, stride, pad, act;
+  int dbg;                  // diagnostic bits of tile_hint (timing experiments; results are then invalid)
   int act_post;             // activation applied AFTER the residual add (GLSDET_ACT_RES_FIRST), else 0
   int kreal, kpad;          // elements
   int M;                    // N*Ho*Wo

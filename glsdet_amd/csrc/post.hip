@@ -55,6 +55,14 @@ __global__ __launch_bounds__(256) void decode_kernel(const DecodeArgs a) {
   }
 }
 
+// Counter reset as a kernel of our own: hipMemsetAsync nodes inside a captured graph were seen to
+// scribble over their target when two graphs replay concurrently on two streams (stale fill
+// patterns / pointers in the counters), so the plan contains no memset nodes at all.
+__global__ __launch_bounds__(256) void reset_counters_kernel(int* cnt, int n, int* status) {
+  for (int i = threadIdx.x; i < n; i += blockDim.x) cnt[i] = 0;
+  if (threadIdx.x == 0) *status = 0;
+}
+
 // ---------------------------------------------------------------------------- NMS
 // workspace layout (per call): see nms_layout()
 struct NmsWs {
@@ -496,8 +504,7 @@ extern "C" int glsdet_nms(const float* pred, int32_t n, int32_t A, int32_t num_c
   op.bytes = (double)n * A * (5 + num_classes) * 4.0;
   op.name = "nms(filter+rank+mask+scan)";
   op.launch = [=](hipStream_t st) -> int {
-    GLS_HIP(hipMemsetAsync(ws.cnt, 0, (size_t)n * 4, st));
-    GLS_HIP(hipMemsetAsync(status, 0, 4, st));
+    hipLaunchKernelGGL(reset_counters_kernel, dim3(1), dim3(256), 0, st, ws.cnt, n, status);
     long g = ((long)n * A + 255) / 256;
     if (g > 8192) g = 8192;
     hipLaunchKernelGGL(nms_filter_kernel, dim3((unsigned)g), dim3(256), 0, st, pred, n, A, num_classes, box_mode,
@@ -564,8 +571,7 @@ extern "C" int glsdet_gfl_detect(const glsdet_view* cls, const glsdet_view* reg,
   op.bytes = bytes;
   op.name = "gfl_detect(filter+topk+merge+nms)";
   op.launch = [=](hipStream_t st) -> int {
-    GLS_HIP(hipMemsetAsync(w1.cnt, 0, (size_t)n * n_levels * 4, st));
-    GLS_HIP(hipMemsetAsync(status, 0, 4, st));
+    hipLaunchKernelGGL(reset_counters_kernel, dim3(1), dim3(256), 0, st, w1.cnt, n * n_levels, status);
     hipLaunchKernelGGL(gfl_filter_kernel, dim3((maxhw + 255) / 256, n, n_levels), dim3(256), 0, st, a, max_cand, w1, status);
     hipLaunchKernelGGL(nms_rank_kernel, dim3((max_cand + 63) / 64, n * n_levels), dim3(256), 0, st, max_cand, w1);
     hipLaunchKernelGGL(gfl_merge_kernel, dim3((max_cand2 + 255) / 256, n), dim3(256), 0, st, n_levels, max_cand, nms_pre,

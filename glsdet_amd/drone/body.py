@@ -39,7 +39,15 @@ class TableModule(nn.Module):
                 self.register_buffer(flat, torch.zeros(shape))
             elif key.endswith("running_var"):
                 self.register_buffer(flat, torch.ones(shape))
-            elif key.endswith("bn.weight"):
+            elif key.endswith(("_embedding", "_proxies_prob")):          # MPHead buffers (mp_head.py:78-91)
+                self.register_buffer(flat, torch.randn(shape) if key.endswith("_embedding") else torch.ones(shape))
+            elif key.endswith("_pos_embedding_ptr"):
+                self.register_buffer(flat, torch.zeros(shape, dtype=torch.long))
+            elif key.endswith("integral.project"):                        # gfl_head.py:32-33
+                self.register_buffer(flat, torch.linspace(0, shape[0] - 1, shape[0]))
+            elif key.endswith("proxies"):
+                self.register_parameter(flat, nn.Parameter(torch.randn(shape) * 0.01, requires_grad=False))
+            elif (key.endswith("weight") and len(shape) == 1) or len(shape) == 0:   # BN / GN gamma, mmcv Scale
                 self.register_parameter(flat, nn.Parameter(torch.ones(shape), requires_grad=False))
             elif key.endswith("bias"):
                 self.register_parameter(flat, nn.Parameter(torch.zeros(shape), requires_grad=False))

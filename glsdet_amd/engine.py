@@ -213,6 +213,72 @@ class Engine:
         check(self.lib.glsdet_conv2d(C.byref(d), _stream_ptr(self.stream)), "conv2d")
         return out
 
+    def conv_multi(self, xs: Sequence[TView], packs, stride: int, pad: int, act: str,
+                   outs: Optional[Sequence[Optional[TView]]] = None, ress: Optional[Sequence[Optional[TView]]] = None,
+                   out_dtype: Optional[int] = None, tile_hint: int = 0) -> List[TView]:
+        """Up to 4 independent convs of one shape class (same k, stride, Cin, Cout) as ONE launch
+        (glsdet_conv2d_multi): each alone is too small to fill the chip."""
+        n = len(xs)
+        assert 1 <= n <= 4 and len(packs) == n
+        outs = list(outs) if outs is not None else [None] * n
+        ress = list(ress) if ress is not None else [None] * n
+        arr = (ConvDesc * n)()
+        for i, (x, pk) in enumerate(zip(xs, packs)):
+            wdev, sdev, bdev, cout, R, S = pk
+            if outs[i] is None:
+                outs[i] = self.tensor(x.n, (x.h + 2 * pad - R) // stride + 1, (x.w + 2 * pad - S) // stride + 1, cout, out_dtype)
+            d = arr[i]
+            d.x, d.y = x.as_c(), outs[i].as_c()
+            d.res = ress[i].as_c() if ress[i] is not None else View()
+            d.w, d.scale, d.bias = wdev.data_ptr(), sdev.data_ptr(), bdev.data_ptr()
+            d.R, d.S, d.stride, d.pad, d.act, d.tile_hint = R, S, stride, pad, ACT[act], tile_hint
+        check(self.lib.glsdet_conv2d_multi(arr, n, _stream_ptr(self.stream)), "conv2d_multi")
+        return outs
+
+    def conv_group(self, xs: Sequence[TView], packs, stride: int, pad: int, act: str,
+                   outs: Optional[Sequence[Optional[TView]]] = None, ress: Optional[Sequence[Optional[TView]]] = None,
+                   out_dtype: Optional[int] = None) -> List[TView]:
+        """n independent convs of one shape class: ONE grouped launch when that is faster than n
+        launches (measured at build time with autotune, a size heuristic without), else n convs."""
+        n = len(xs)
+        outs = list(outs) if outs is not None else [None] * n
+        ress = list(ress) if ress is not None else [None] * n
+        R, S, cout = packs[0][4], packs[0][5], packs[0][3]
+        for i, x in enumerate(xs):
+            if outs[i] is None:
+                outs[i] = self.tensor(x.n, (x.h + 2 * pad - R) // stride + 1, (x.w + 2 * pad - S) // stride + 1, cout, out_dtype)
+        separate = lambda: [self.conv(x, pk, stride, pad, act, out=o, res=r, out_dtype=out_dtype)
+                            for x, pk, o, r in zip(xs, packs, outs, ress)]
+        if n < 2 or n > 4 or len({(pk[3], pk[4], pk[5], x.c) for x, pk in zip(xs, packs)}) != 1 or \
+                os.environ.get("GLSDET_NO_GROUP"):          # A/B switch for measurements
+            return separate()
+        if not self.autotune:
+            small = all(o.n * o.h * o.w * o.c <= 64 * 64 * 384 for o in outs)
+            return self.conv_multi(xs, packs, stride, pad, act, outs=outs, ress=ress) if small else separate()
+        key = ("multi", n, stride, pad, R, S) + tuple(v for x, o, r in zip(xs, outs, ress) for v in (
+            x.n, x.h, x.w, x.c, x.sn, x.sh, x.sw, o.c, o.sn, o.sh, o.sw, r is not None, o.dtype))
+        if key not in self._tuned:
+            arr = (ConvDesc * n)()
+            single_us = 0.0
+            for i, (x, pk, o, r) in enumerate(zip(xs, packs, outs, ress)):
+                d = arr[i]
+                d.x, d.y = x.as_c(), o.as_c()
+                d.res = r.as_c() if r is not None else View()
+                d.w, d.scale, d.bias = pk[0].data_ptr(), pk[1].data_ptr(), pk[2].data_ptr()
+                d.R, d.S, d.stride, d.pad, d.act, d.tile_hint = R, S, stride, pad, ACT[act], 0
+                best, us = C.c_int32(0), C.c_float(0)
+                check(self.lib.glsdet_conv2d_tune(C.byref(d), _stream_ptr(self.stream), C.byref(best), C.byref(us)), "conv2d_tune")
+                single_us += us.value
+            best, us = C.c_int32(0), C.c_float(0)
+            check(self.lib.glsdet_conv2d_multi_tune(arr, n, _stream_ptr(self.stream), C.byref(best), C.byref(us)),
+                  "conv2d_multi_tune")
+            self._tuned[key] = best.value if us.value < 0.95 * single_us else -1
+            self._tune_dirty = True
+        hint = self._tuned[key]
+        if hint < 0:
+            return separate()
+        return self.conv_multi(xs, packs, stride, pad, act, outs=outs, ress=ress, tile_hint=hint)
+
     def pack_dw(self, w: torch.Tensor, scale: torch.Tensor, bias: torch.Tensor, c_pad: int):
         """depthwise weights [C,1,R,S] -> ([R*S][c_pad] in engine dtype, scale, bias, C, R, S)"""
         C_, one, R, S = w.shape

@@ -4,6 +4,7 @@ from .registry import (BACKBONES, DETECTORS, HEADS, MODELS, NECKS, Config, Confi
                        build_backbone, build_detector, build_head, build_neck)
 from .models import (CSPDarknet, GLFusionPAFPN, YOLOX, YOLOXHead, YOLOXPAFPN, bbox2result,  # noqa: F401
                      mmdet_to_drone_key)
+from .resdet_models import FPN, GFL, GFLHead, MPDet, MPHead, ResNet, SingleStageDetector  # noqa: F401
 
 
 def init_detector(config, checkpoint=None, device="cuda:0", cfg_options=None):

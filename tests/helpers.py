@@ -43,38 +43,6 @@ def model_case(golden, shapes, tag):
 
 
 def calibrated_resdet_sd(kind, seed, x, **kw):
-    """Synthetic ResNet-50 + FPN + GFL/MP state_dict whose BN running statistics are the
-    (perturbed) batch statistics of input x, computed stage by stage with plain torch ops in
-    the order the backbone executes -- the same recipe as make_golden.calibrate_bn, so the
-    signal neither dies nor explodes over the 53 conv layers.  Data preparation only."""
-    import numpy as np
-    import torch.nn.functional as F
-    from glsdet_amd.arch import RESNET_STAGE_BLOCKS, resdet_state_dict_shapes
-    sd = O.synth_state_dict(resdet_state_dict_shapes(kind, **kw), seed)
-    rng = np.random.default_rng([seed, 0xB17])
-
-    def bn(p, t):
-        var = t.var((0, 2, 3), unbiased=False)
-        var = var + 0.5 * var.mean() + 1e-4
-        mean = t.mean((0, 2, 3))
-        c = mean.numel()
-        sd[p + ".running_var"] = var * torch.from_numpy(rng.uniform(0.8, 1.25, c).astype(np.float32))
-        sd[p + ".running_mean"] = mean + var.sqrt() * torch.from_numpy((0.1 * rng.standard_normal(c)).astype(np.float32))
-        return F.batch_norm(t, sd[p + ".running_mean"], sd[p + ".running_var"], sd[p + ".weight"], sd[p + ".bias"],
-                            False, 0.0, 1e-5)
-
-    with torch.no_grad():
-        t = torch.relu(bn("backbone.bn1", F.conv2d(x, sd["backbone.conv1.weight"], None, 2, 3)))
-        t = F.max_pool2d(t, 3, 2, 1)
-        for i, nb in enumerate(RESNET_STAGE_BLOCKS[kw.get("depth", 50)]):
-            for j in range(nb):
-                p = "backbone.layer%d.%d" % (i + 1, j)
-                s = 2 if (j == 0 and i > 0) else 1
-                o = torch.relu(bn(p + ".bn1", F.conv2d(t, sd[p + ".conv1.weight"])))
-                o = torch.relu(bn(p + ".bn2", F.conv2d(o, sd[p + ".conv2.weight"], None, s, 1)))
-                o = bn(p + ".bn3", F.conv2d(o, sd[p + ".conv3.weight"]))
-                idn = t
-                if p + ".downsample.0.weight" in sd:
-                    idn = bn(p + ".downsample.1", F.conv2d(t, sd[p + ".downsample.0.weight"], None, s))
-                t = torch.relu(o + idn)
-    return sd
+    """Synthetic ResNet-50 + FPN + GFL/MP weights with BN statistics calibrated on x (data only)."""
+    from glsdet_amd.synth import synth_resdet_state_dict
+    return synth_resdet_state_dict(kind, seed, x, **kw)

@@ -288,3 +288,37 @@ def test_conv1x1_weight_stationary(engines, mode, case):
     out = eng.conv(xv, eng.pack_conv([(w, scale, bias)], cin), 1, 0, "silu", out=ov, res=rv, tile_hint=3)
     torch.cuda.synchronize()
     _cmp(out.to_nchw(cout), ref, TOL[mode], "conv1x1 ws")
+
+
+@pytest.mark.parametrize("mode", ["f32", "f16"])
+@pytest.mark.parametrize("case", [
+    # cin, cout, k, stride, act, [(H, W) per problem], residual
+    (256, 128, 3, 1, "silu", [(13, 21), (12, 21), (13, 21), (12, 21)], False),
+    (128, 64, 3, 2, "silu", [(50, 84), (50, 84), (50, 84), (50, 84)], False),
+    (64, 192, 1, 1, "none", [(25, 42), (25, 41)], False),
+    (128, 128, 3, 1, "relu", [(20, 24), (10, 12), (5, 6)], True),
+    (16, 32, 3, 1, "lrelu", [(9, 9)], False),
+])
+def test_conv2d_multi_equals_separate_convs(engines, mode, case):
+    """glsdet_conv2d_multi: n problems of one shape class, own weights / extents / residuals each."""
+    eng = engines[mode]
+    cin, cout, k, stride, act, sizes, use_res = case
+    xs, packs, refs, ress = [], [], [], []
+    for i, (h, w) in enumerate(sizes):
+        g = torch.Generator().manual_seed(100 + i)
+        x = torch.randn(2, cin, h, w, generator=g)
+        wt = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5
+        sc, bi = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.2
+        ho, wo = (h + 2 * (k // 2) - k) // stride + 1, (w + 2 * (k // 2) - k) // stride + 1
+        res = torch.randn(2, cout, ho, wo, generator=g) if use_res else None
+        r = lambda t: t.half().float() if mode == "f16" else t
+        y = O._act(F.conv2d(r(x), r(wt), None, stride, k // 2) * sc.view(1, -1, 1, 1) + bi.view(1, -1, 1, 1), act)
+        refs.append(y + r(res) if use_res else y)
+        xs.append(_to_view(eng, x, embed=(cin + 16, 8)) if i % 2 else _to_view(eng, x))
+        packs.append(eng.pack_conv([(wt, sc, bi)], cin))
+        ress.append(_to_view(eng, res) if use_res else None)
+    for hint in (0, (64 << 16) | 64, (128 << 16) | 128 | 0x8000):
+        outs = eng.conv_multi(xs, packs, stride, k // 2, act, ress=ress, tile_hint=hint)
+        torch.cuda.synchronize()
+        for o, ref in zip(outs, refs):
+            _cmp(o.to_nchw(cout), ref, TOL[mode], "conv multi hint %x" % hint)

@@ -378,3 +378,85 @@ def test_detector_f16_vs_oracle_and_graph(kind):
     graph = det.collect(c2)
     for (a, la), (b, lb) in zip(eager, graph):
         assert np.array_equal(a, b) and np.array_equal(la, lb)      # graph replay is bit-identical to eager
+
+
+# ------------------------------------------------------------------------------- mmdet surface
+import os  # noqa: E402
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_ufpmp_configs_build_with_the_reference_key_names():
+    from glsdet_amd.arch import resdet_state_dict_shapes
+    from glsdet_amd.mmdet_surface import init_detector
+    for path, typ, kind in (("configs/UFPMP-Det/coarse_det.py", "GFL", "gfl"),
+                            ("configs/UFPMP-Det/mp_det_res50.py", "MPDet", "mpdet")):
+        m = init_detector(os.path.join(ROOT, path))
+        assert not m.training and m.cfg.model.type == typ and type(m).__name__ == typ
+        got = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+        assert list(got.items()) == [(k, tuple(v)) for k, v in resdet_state_dict_shapes(kind).items()]
+        assert "backbone.layer1.0.downsample.1.running_var" in got and "neck.fpn_convs.4.conv.bias" in got
+        assert m.cfg.data.test.pipeline[1].img_scale == (1333, 800)          # ufpmp_det_eval.py:122 reads this
+    assert m.bbox_head.proxies_list == [2, 3, 2, 5, 4, 8, 8, 4, 3, 3] and m.bbox_head.test_cfg.max_per_img == 500
+    sd = {("module." + k): v for k, v in m.state_dict().items()}
+    m.load_state_dict({"state_dict": sd, "meta": {}})                        # mmcv checkpoint layout, DataParallel prefix
+
+
+def test_surface_argument_validation():
+    from glsdet_amd.mmdet_surface import FPN, MPHead, ResNet
+    with pytest.raises(KeyError):
+        ResNet(depth=20)                                                     # resnet.py:390-391
+    with pytest.raises(NotImplementedError):
+        ResNet(depth=50, deep_stem=True)
+    with pytest.raises(AssertionError):
+        ResNet(depth=50, out_indices=(0, 4))
+    with pytest.raises(AssertionError):
+        FPN([256, 512], 256, num_outs=1)                                     # fpn.py:91
+    with pytest.raises(AssertionError):
+        FPN([256, 512], 256, num_outs=2, add_extra_convs="sideways")         # fpn.py:101-103
+    with pytest.raises(AssertionError):
+        MPHead(num_classes=3, in_channels=256)                               # mp_head.py:39
+    from glsdet_amd.mmdet_surface import build_detector
+    with pytest.raises(NotImplementedError):
+        build_detector(dict(type="GFL", backbone=dict(type="CSPDarknet"), neck=dict(
+            type="FPN", in_channels=[256, 512, 1024, 2048], out_channels=256, num_outs=5),
+            bbox_head=dict(type="GFLHead", num_classes=10, in_channels=256)))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", ["coarse_det.py", "mp_det_res50.py"])
+def test_surface_call_flow_vs_oracle(cfg):
+    """init_detector(config) -> load_state_dict -> model(return_loss=False, rescale=True, img=[..],
+    img_metas=[[..]]) -> list[img] of list[class] of (n,5), against the restatement."""
+    from glsdet_amd.mmdet_surface import init_detector
+    m = init_detector(os.path.join(ROOT, "configs/UFPMP-Det", cfg))
+    m.hip_dtype = "f32"
+    kind = "mpdet" if cfg.startswith("mp_") else "gfl"
+    x = O.synth_input((2, 3, 128, 160), 11)
+    sd = calibrated_resdet_sd(kind, 3, x)
+    # a bias on the class logits so that a moderate number of pairs pass score_thr
+    m.load_state_dict(sd)
+    metas = [dict(img_shape=(120, 150, 3), ori_shape=(60, 75, 3), pad_shape=(128, 160, 3),
+                  scale_factor=np.array([2.0, 2.0, 2.0, 2.0], np.float32), flip=False),
+             dict(img_shape=(128, 160, 3), ori_shape=(128, 160, 3), pad_shape=(128, 160, 3),
+                  scale_factor=np.array([1.0, 1.0, 1.0, 1.0], np.float32), flip=False)]
+    with pytest.raises(NotImplementedError):
+        m(img=[x], img_metas=[metas], return_loss=True)
+    m.bbox_head.test_cfg["score_thr"] = 0.3
+    res = m(return_loss=False, rescale=True, img=[x], img_metas=[metas])
+    assert len(res) == 2 and all(len(r) == 10 for r in res)
+    fw = M.gfl_forward(sd, x) if kind == "gfl" else M.mpdet_forward(sd, x, m.bbox_head.proxies_list)
+    want = M.gfl_get_bboxes(fw[0], fw[1], [8, 16, 32, 64, 128], [mt["img_shape"] for mt in metas], 0.3, 1000, 0.6,
+                            m.bbox_head.test_cfg.max_per_img, [mt["scale_factor"] for mt in metas])
+    total = 0
+    for r, (wd, wl) in zip(res, want):
+        for c in range(10):
+            assert r[c].dtype == np.float32 and r[c].shape[1] == 5
+            w = wd[wl == c]
+            total += len(w)
+            # the logits are chaotic at 2e-4 (see test_detector_f32_vs_oracle): the kept set may differ by
+            # borderline candidates; everything the restatement keeps well above threshold must be there
+            strong = w[w[:, 4] > 0.35]
+            for row in strong:
+                assert len(r[c]) and np.min(np.abs(r[c][:, :4] - row[:4]).max(1)) < 0.05, (c, row)
+    assert total > 0

@@ -26,14 +26,32 @@ SHAPES = [  # n, H, W, cin, cout, k, stride
     (8, 200, 336, 64, 128, 3, 2),
     (8, 400, 672, 16, 32, 3, 1),
 ]
+RESNET = [  # ResNet-50 / FPN / head layers at 8 x 800 x 1344
+    (8, 50, 84, 1024, 256, 1, 1),
+    (8, 50, 84, 256, 1024, 1, 1),
+    (8, 100, 168, 512, 128, 1, 1),
+    (8, 100, 168, 128, 512, 1, 1),
+    (8, 200, 336, 64, 256, 1, 1),
+    (8, 25, 42, 2048, 512, 1, 1),
+    (8, 25, 42, 512, 2048, 1, 1),
+    (8, 50, 84, 256, 256, 3, 1),
+    (8, 25, 42, 512, 512, 3, 1),
+    (8, 100, 168, 256, 256, 3, 1),
+    (8, 100, 168, 128, 128, 3, 1),
+]
 HINTS = {"auto": 0, "halo": 2, "ws1x1": 3, "g128x128": (128 << 16) | 128, "g64x128": (64 << 16) | 128,
-         "g64x64": (64 << 16) | 64, "g64x64k64": (64 << 16) | 64 | 0x8000, "g64x128k64": (64 << 16) | 128 | 0x8000, "g32x128": (32 << 16) | 128}
+         "g64x64": (64 << 16) | 64, "g64x64k64": (64 << 16) | 64 | 0x8000, "g64x128k64": (64 << 16) | 128 | 0x8000, "g32x128": (32 << 16) | 128,
+         "g128x128k64": (128 << 16) | 128 | 0x8000}
 
 
 def main():
-    only = sys.argv[1:] or None
+    args = sys.argv[1:]
+    shapes = SHAPES
+    if args and args[0] == "resnet":
+        shapes, args = RESNET, args[1:]
+    only = args or None
     eng = Engine("f16")
-    for (n, H, W, cin, cout, k, s) in SHAPES:
+    for (n, H, W, cin, cout, k, s) in shapes:
         x = eng.tensor(n, H, W, cin)
         x.buf.view(torch.float16).normal_()
         w = torch.randn(cout, cin, k, k) / (cin * k * k) ** 0.5
