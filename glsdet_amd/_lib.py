@@ -98,14 +98,16 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    # A/B measurements only: an alternative build of the same ABI (tools/ab_lib.sh)
+    path = os.environ.get("GLSDET_LIB_PATH", LIB_PATH)
+    if not os.path.exists(path):
         raise GlsdetLibraryError(
             "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950).  glsdet_amd has no fallback path." % LIB_PATH)
     try:
-        lib = C.CDLL(LIB_PATH)
+        lib = C.CDLL(path)
     except OSError as e:  # pragma: no cover
-        raise GlsdetLibraryError("cannot load %s: %s" % (LIB_PATH, e))
+        raise GlsdetLibraryError("cannot load %s: %s" % (path, e))
     for name, (res, args) in _SIGS.items():
         try:
             fn = getattr(lib, name)

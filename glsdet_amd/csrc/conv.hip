@@ -112,10 +112,10 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
   // L2/HBM round trip; the small-K / small-tile layers were latency bound on it)
   u32x4 ra0[NA], rb0[NB], ra1[NA], rb1[NB], ra2[NA], rb2[NB];
 
-  // Every load below is issued UNCONDITIONALLY (steps past the end read through GLS_OOB and
-  // return zeros without touching memory): the compiler can then count the loads in flight
-  // and waits with s_waitcnt vmcnt(N) for exactly the set it needs.  A load under a branch
-  // makes it fall back to vmcnt(0), which exposes a full L2/HBM round trip per K step.
+  // (Measured, tools/ab_lib.sh: issuing the loads unconditionally with padding steps -- so that the
+  // compiler can count them and wait with vmcnt(N) -- was 5-20 % SLOWER than this branchy form on
+  // the short-K layers and no faster on the long-K ones; the extra barriers cost more than the
+  // exposed waits.)
   // UT state: scalar tap walk + per-chunk byte offsets that already hold everything per-thread
   int u_kr = 0, u_ks = 0, u_kci = 0;                     // wave-uniform
   unsigned ub[NB];                                       // x_off + (pixel origin + chunk column) bytes, or GLS_OOB
@@ -212,18 +212,16 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
 
   gload(0, ra0, rb0);
   lstore(0, ra0, rb0);
-  gload(1, ra1, rb1);
-  gload(2, ra2, rb2);
+  if (nsteps > 1) gload(1, ra1, rb1);
+  if (nsteps > 2) gload(2, ra2, rb2);
   __syncthreads();
 
   // one K step: issue step t+3 into the set that held step t (already in LDS), multiply step t
-  // from LDS buffer t&1, then move step t+1 (in flight for two steps) into the other buffer.
-  // Loads, LDS stores and the barrier are unconditional (see gload); only the LDS-read + MFMA
-  // part is skipped for the up to two padding steps that round the loop to a multiple of 3.
+  // from LDS buffer t&1, then move step t+1 (in flight for two steps) into the other buffer
   auto kstep = [&](int t, u32x4 (&fa)[NA], u32x4 (&fb)[NB], const u32x4 (&na)[NA], const u32x4 (&nb)[NB])
       __attribute__((always_inline)) {
     const int cur = t & 1;
-    gload(t + 3, fa, fb);
+    if (t + 3 < nsteps) gload(t + 3, fa, fb);
     const unsigned char* sbuf = smem + cur * STAGE;
     if (t < nsteps && !(a.dbg & 2)) {
 #pragma unroll
@@ -241,13 +239,13 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
           for (int j = 0; j < TN; ++j) MMA<T>::run(af[i], bf[j], acc[i][j]);
       }
     }
-    lstore(cur ^ 1, na, nb);
+    if (t + 1 < nsteps) lstore(cur ^ 1, na, nb);
     __syncthreads();
   };
   for (int t = 0; t < nsteps; t += 3) {
     kstep(t, ra0, rb0, ra1, rb1);
-    kstep(t + 1, ra1, rb1, ra2, rb2);
-    kstep(t + 2, ra2, rb2, ra0, rb0);
+    if (t + 1 < nsteps) kstep(t + 1, ra1, rb1, ra2, rb2);
+    if (t + 2 < nsteps) kstep(t + 2, ra2, rb2, ra0, rb0);
   }
   if (a.dbg & 4) return;
   // ---- epilogue: fp32 scale/bias/act, transpose through LDS, 16-B channel chunks out

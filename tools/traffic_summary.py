@@ -19,7 +19,7 @@ def per_launch(sub, counter):
 
 fk, fn = per_launch("pmc_f", "FETCH_SIZE")
 wk, wn = per_launch("pmc_w", "WRITE_SIZE")
-res = {"conv_launches_counted": fn,
+res = {"workload": sys.argv[2] if len(sys.argv) > 2 else "yolox_s_glfusion_1344x800_bs8", "conv_launches_counted": fn,
        "fetch_bytes_per_launch_corrected": 2.0 * fk * 1024 / max(fn, 1),
        "write_bytes_per_launch": wk * 1024 / max(wn, 1)}
 res["hbm_bytes_per_launch"] = res["fetch_bytes_per_launch_corrected"] + res["write_bytes_per_launch"]
