@@ -54,6 +54,8 @@ _SIGS = {
     "glsdet_resample_copy": (C.c_int, [C.POINTER(View), C.POINTER(View), C.c_int32, C.c_void_p]),
     "glsdet_nonlocal": (C.c_int, [C.POINTER(View), C.POINTER(View), C.c_int32, C.c_void_p, C.c_void_p,
                                   C.c_void_p, C.POINTER(View), C.c_void_p]),
+    "glsdet_nonlocal_multi": (C.c_int, [C.POINTER(View), C.POINTER(View), C.c_int32, C.c_int32, C.POINTER(C.c_void_p),
+                                        C.POINTER(C.c_void_p), C.c_void_p, C.POINTER(View), C.c_void_p]),
     "glsdet_yolox_decode": (C.c_int, [C.POINTER(View), C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                       C.POINTER(C.c_int32), C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "glsdet_nms_workspace_bytes": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),

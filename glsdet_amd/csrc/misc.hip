@@ -169,17 +169,38 @@ __global__ __launch_bounds__(256) void resample_kernel(const unsigned char* x, l
 // Gp[z][b][c1][c2] = sum_{j in slice z} phi[b,j,c1] * g[b,j,c2]   (16x16 block per workgroup;
 // the position range is split over blockIdx.z for parallelism, partial sums are added in a
 // fixed order by nl_fold_kernel -> deterministic)
+// Up to GLS_NL_SETS independent blocks (the four quadrants of Patch_Conv_NonLocal) per launch:
+// every kernel below takes the per-set operands in one kernarg struct and finds its set from
+// the block index.
+#define GLS_NL_SETS 4
+struct NlSet {
+  const unsigned char *x, *tpg;
+  unsigned char* out;
+  long xsn, xsh, xsw, tsn, tsh, tsw, osn, osh, osw;
+  const float *wout, *bout;
+  float *gram, *P;
+  int H, W, nsplit, jchunk;
+  float invN;
+};
+struct NlArgs {
+  NlSet s[GLS_NL_SETS];
+  int n, nimg, ci, cx, kc;
+};
+
 template <typename T>
-__global__ __launch_bounds__(256) void nl_gram_kernel(const unsigned char* tpg, long sn, long sh, long sw, int H, int W,
-                                                      int ci, int jchunk, float* Gp) {
+__global__ __launch_bounds__(256) void nl_gram_kernel(const NlArgs a) {
   __shared__ float ph[64][17], gg[64][17];
+  const int q = blockIdx.z >> 3, z = blockIdx.z & 7;
+  const NlSet& S = a.s[q];
+  if (z >= S.nsplit) return;
+  const int ci = a.ci;
   const int nb = (ci + 15) / 16;
   const int c1_0 = (blockIdx.x / nb) * 16, c2_0 = (blockIdx.x % nb) * 16;
-  const int b = blockIdx.y, z = blockIdx.z;
+  const int b = blockIdx.y;
   const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
-  const int N = H * W;
-  const int jbeg = z * jchunk, jend = min(N, jbeg + jchunk);
-  const T* base = reinterpret_cast<const T*>(tpg) + b * sn;
+  const int W = S.W, N = S.H * W;
+  const int jbeg = z * S.jchunk, jend = min(N, jbeg + S.jchunk);
+  const T* base = reinterpret_cast<const T*>(S.tpg) + b * S.tsn;
   float acc = 0.f;
   for (int j0 = jbeg; j0 < jend; j0 += 64) {
 #pragma unroll
@@ -189,7 +210,7 @@ __global__ __launch_bounds__(256) void nl_gram_kernel(const unsigned char* tpg, 
       const int j = j0 + jj;
       float vp = 0.f, vg = 0.f;
       if (j < jend) {
-        const T* px = base + (j / W) * sh + (j % W) * sw;
+        const T* px = base + (j / W) * S.tsh + (j % W) * S.tsw;
         if (c1_0 + cc < ci) vp = (float)px[ci + c1_0 + cc];
         if (c2_0 + cc < ci) vg = (float)px[2 * ci + c2_0 + cc];
       }
@@ -202,7 +223,7 @@ __global__ __launch_bounds__(256) void nl_gram_kernel(const unsigned char* tpg, 
     __syncthreads();
   }
   if (c1_0 + ty < ci && c2_0 + tx < ci)
-    Gp[(((long)z * gridDim.y + b) * ci + c1_0 + ty) * ci + c2_0 + tx] = acc;
+    S.gram[(((long)z * a.nimg + b) * ci + c1_0 + ty) * ci + c2_0 + tx] = acc;
 }
 
 // P[b][co][c1] = (1/N) sum_c2 Wout[co][c2] * (sum_z Gp[z][b][c1][c2]).  Workgroup = (image,
@@ -213,11 +234,16 @@ __global__ __launch_bounds__(256) void nl_gram_kernel(const unsigned char* tpg, 
 // conflict-free).  Any ci works: LDS holds one chunk, never the whole Gram.
 #define GLS_FOLD_CO 16
 #define GLS_NL_KC 128
-__global__ __launch_bounds__(256) void nl_fold_kernel(const float* __restrict__ Gp, int nsplit, int nimg,
-                                                      const float* __restrict__ wout, int ci, int cx, float invN,
-                                                      float* P, int kc) {
+__global__ __launch_bounds__(256) void nl_fold_kernel(const NlArgs a) {
   extern __shared__ float gs[];   // [64][kc+1]
-  const int b = blockIdx.x, co0 = blockIdx.y * GLS_FOLD_CO, c1_0 = blockIdx.z * 64, ld = kc + 1;
+  const int q = blockIdx.x / a.nimg, b = blockIdx.x - q * a.nimg;
+  const NlSet& S = a.s[q];
+  const float* __restrict__ Gp = S.gram;
+  const float* __restrict__ wout = S.wout;
+  float* P = S.P;
+  const int nsplit = S.nsplit, nimg = a.nimg, ci = a.ci, cx = a.cx, kc = a.kc;
+  const float invN = S.invN;
+  const int co0 = blockIdx.y * GLS_FOLD_CO, c1_0 = blockIdx.z * 64, ld = kc + 1;
   const long slice = (long)nimg * ci * ci;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const float* w[4];
@@ -267,14 +293,20 @@ __global__ __launch_bounds__(256) void nl_fold_kernel(const float* __restrict__ 
 // accumulators share each theta read and persist across the chunks.
 #define GLS_APPLY_CO 32
 template <typename T>
-__global__ __launch_bounds__(256) void nl_apply_kernel(const unsigned char* x, long xsn, long xsh, long xsw,
-                                                       const unsigned char* tpg, long tsn, long tsh, long tsw,
-                                                       unsigned char* out, long osn, long osh, long osw, int H, int W,
-                                                       int ci, int cx, const float* __restrict__ P,
-                                                       const float* __restrict__ bout, int kc) {
+__global__ __launch_bounds__(256) void nl_apply_kernel(const NlArgs a) {
   extern __shared__ float th[];   // [64][kc+1] theta, then [GLS_APPLY_CO][kc] P rows
-  const int N = H * W;
-  const int b = blockIdx.y, j0 = blockIdx.x * 64, co0 = blockIdx.z * GLS_APPLY_CO;
+  const int q = blockIdx.y / a.nimg, b = blockIdx.y - q * a.nimg;
+  const NlSet& S = a.s[q];
+  const unsigned char *x = S.x, *tpg = S.tpg;
+  unsigned char* out = S.out;
+  const long xsn = S.xsn, xsh = S.xsh, xsw = S.xsw, tsn = S.tsn, tsh = S.tsh, tsw = S.tsw, osn = S.osn, osh = S.osh,
+             osw = S.osw;
+  const float* __restrict__ P = S.P;
+  const float* __restrict__ bout = S.bout;
+  const int W = S.W, ci = a.ci, cx = a.cx, kc = a.kc;
+  const int N = S.H * W;
+  const int j0 = blockIdx.x * 64, co0 = blockIdx.z * GLS_APPLY_CO;
+  if (j0 >= N) return;            // block-uniform: this set is smaller than the largest one
   const int ld = kc + 1;
   float* pr = th + 64 * ld;
   const int jj = threadIdx.x & 63, grp = threadIdx.x >> 6;
@@ -434,47 +466,75 @@ extern "C" int glsdet_resample_copy(const glsdet_view* x, const glsdet_view* y, 
   return submit(std::move(op), stream);
 }
 
-extern "C" int glsdet_nonlocal(const glsdet_view* x, const glsdet_view* tpg, int32_t ci, const float* wout,
-                               const float* bout, float* gram, const glsdet_view* out, void* stream) {
+extern "C" int glsdet_nonlocal_multi(const glsdet_view* x, const glsdet_view* tpg, int32_t n_sets, int32_t ci,
+                                     const float* const* wout, const float* const* bout, float* gram,
+                                     const glsdet_view* out, void* stream) {
   if (!x || !tpg || !out || !wout || !bout || !gram) GLS_FAIL(GLSDET_E_ARG, "nonlocal: null argument");
-  int rc;
-  if ((rc = check_view(*x, "nonlocal.x", false))) return rc;
-  if ((rc = check_view(*tpg, "nonlocal.tpg", false))) return rc;
-  if ((rc = check_view(*out, "nonlocal.out", false))) return rc;
-  if (!same_extent(*x, *out) || x->dtype != out->dtype || tpg->dtype != x->dtype)
-    GLS_FAIL(GLSDET_E_ARG, "nonlocal: x/out extent or dtype mismatch");
-  if (tpg->n != x->n || tpg->h != x->h || tpg->w != x->w || ci < 1 || tpg->c < 3 * ci)
-    GLS_FAIL(GLSDET_E_ARG, "nonlocal: theta|phi|g view must be [n,h,w,>=3*ci]");
-  const int cx = x->c;
-  const glsdet_view vx = *x, vt = *tpg, vo = *out;
-  const int N = vx.h * vx.w;
+  if (n_sets < 1 || n_sets > GLS_NL_SETS) GLS_FAIL(GLSDET_E_ARG, "nonlocal: 1..%d sets", GLS_NL_SETS);
+  NlArgs a = {};
+  a.n = n_sets;
+  a.ci = ci;
+  a.cx = x[0].c;
+  a.nimg = x[0].n;
+  a.kc = ci < GLS_NL_KC ? ci : GLS_NL_KC;
   OpRecord op;
   op.kind = 4;
-  // algorithmic count of the reference's two matmuls: 2 * (N*N*ci) MACs per image
-  op.flops = 2.0 * 2.0 * (double)vx.n * N * (double)N * ci;
-  op.bytes = (double)vx.n * N * (3.0 * ci + 2.0 * cx) * dtype_size(vx.dtype);
-  op.name = "nonlocal(gram+fold+apply)";
-  const int nsplit = N >= 1024 ? 8 : (N >= 256 ? 4 : 1);
-  const int jchunk = (((N + nsplit - 1) / nsplit) + 63) / 64 * 64;
-  float* P = gram + (long)vx.n * 8 * ci * ci;
+  op.flops = op.bytes = 0;
+  int maxN = 0;
+  const int dt = x[0].dtype;
+  const long per_set = (long)a.nimg * (8L * ci * ci + (long)a.cx * ci);      // floats of workspace per set
+  for (int q = 0; q < n_sets; ++q) {
+    int rc;
+    if ((rc = check_view(x[q], "nonlocal.x", false))) return rc;
+    if ((rc = check_view(tpg[q], "nonlocal.tpg", false))) return rc;
+    if ((rc = check_view(out[q], "nonlocal.out", false))) return rc;
+    if (!wout[q] || !bout[q]) GLS_FAIL(GLSDET_E_ARG, "nonlocal: null weight");
+    if (!same_extent(x[q], out[q]) || x[q].dtype != dt || out[q].dtype != dt || tpg[q].dtype != dt)
+      GLS_FAIL(GLSDET_E_ARG, "nonlocal: x/out extent or dtype mismatch");
+    if (tpg[q].n != x[q].n || tpg[q].h != x[q].h || tpg[q].w != x[q].w || ci < 1 || tpg[q].c < 3 * ci)
+      GLS_FAIL(GLSDET_E_ARG, "nonlocal: theta|phi|g view must be [n,h,w,>=3*ci]");
+    if (x[q].c != a.cx || x[q].n != a.nimg) GLS_FAIL(GLSDET_E_ARG, "nonlocal: the sets must agree in n and channels");
+    NlSet& S = a.s[q];
+    const int N = x[q].h * x[q].w;
+    S.x = (const unsigned char*)x[q].base; S.tpg = (const unsigned char*)tpg[q].base; S.out = (unsigned char*)out[q].base;
+    S.xsn = x[q].sn; S.xsh = x[q].sh; S.xsw = x[q].sw;
+    S.tsn = tpg[q].sn; S.tsh = tpg[q].sh; S.tsw = tpg[q].sw;
+    S.osn = out[q].sn; S.osh = out[q].sh; S.osw = out[q].sw;
+    S.wout = wout[q]; S.bout = bout[q];
+    S.gram = gram + q * per_set;
+    S.P = S.gram + (long)a.nimg * 8 * ci * ci;
+    S.H = x[q].h; S.W = x[q].w;
+    S.nsplit = N >= 1024 ? 8 : (N >= 256 ? 4 : 1);
+    S.jchunk = (((N + S.nsplit - 1) / S.nsplit) + 63) / 64 * 64;
+    S.invN = 1.0f / (float)N;
+    if (N > maxN) maxN = N;
+    // algorithmic count of the reference's two matmuls: 2 * (N*N*ci) MACs per image
+    op.flops += 2.0 * 2.0 * (double)a.nimg * N * (double)N * ci;
+    op.bytes += (double)a.nimg * N * (3.0 * ci + 2.0 * a.cx) * dtype_size(dt);
+  }
+  op.name = n_sets > 1 ? "nonlocal_multi(gram+fold+apply)" : "nonlocal(gram+fold+apply)";
   op.launch = [=](hipStream_t st) -> int {
-    const int nb = (ci + 15) / 16;
-    const int kc = ci < GLS_NL_KC ? ci : GLS_NL_KC;
-    const dim3 g1(nb * nb, vx.n, nsplit), g2(vx.n, (cx + GLS_FOLD_CO - 1) / GLS_FOLD_CO, (ci + 63) / 64),
-        g3((N + 63) / 64, vx.n, (cx + GLS_APPLY_CO - 1) / GLS_APPLY_CO);
-    const size_t lds2 = (size_t)64 * (kc + 1) * 4;
-    const size_t lds3 = ((size_t)64 * (kc + 1) + (size_t)GLS_APPLY_CO * kc) * 4;
-    if (vx.dtype == GLSDET_F16) {
-      hipLaunchKernelGGL(nl_gram_kernel<f16>, g1, dim3(256), 0, st, (const unsigned char*)vt.base, vt.sn, vt.sh, vt.sw, vt.h, vt.w, ci, jchunk, gram);
-      hipLaunchKernelGGL(nl_fold_kernel, g2, dim3(256), lds2, st, gram, nsplit, vx.n, wout, ci, cx, 1.0f / (float)N, P, kc);
-      hipLaunchKernelGGL(nl_apply_kernel<f16>, g3, dim3(256), lds3, st, (const unsigned char*)vx.base, vx.sn, vx.sh, vx.sw, (const unsigned char*)vt.base, vt.sn, vt.sh, vt.sw, (unsigned char*)vo.base, vo.sn, vo.sh, vo.sw, vx.h, vx.w, ci, cx, P, bout, kc);
+    const int nb = (a.ci + 15) / 16;
+    const dim3 g1(nb * nb, a.nimg, 8 * a.n), g2(a.nimg * a.n, (a.cx + GLS_FOLD_CO - 1) / GLS_FOLD_CO, (a.ci + 63) / 64),
+        g3((maxN + 63) / 64, a.nimg * a.n, (a.cx + GLS_APPLY_CO - 1) / GLS_APPLY_CO);
+    const size_t lds2 = (size_t)64 * (a.kc + 1) * 4;
+    const size_t lds3 = ((size_t)64 * (a.kc + 1) + (size_t)GLS_APPLY_CO * a.kc) * 4;
+    if (dt == GLSDET_F16) {
+      hipLaunchKernelGGL(nl_gram_kernel<f16>, g1, dim3(256), 0, st, a);
+      hipLaunchKernelGGL(nl_fold_kernel, g2, dim3(256), lds2, st, a);
+      hipLaunchKernelGGL(nl_apply_kernel<f16>, g3, dim3(256), lds3, st, a);
     } else {
-      hipLaunchKernelGGL(nl_gram_kernel<float>, g1, dim3(256), 0, st, (const unsigned char*)vt.base, vt.sn, vt.sh, vt.sw, vt.h, vt.w, ci, jchunk, gram);
-      hipLaunchKernelGGL(nl_fold_kernel, g2, dim3(256), lds2, st, gram, nsplit, vx.n, wout, ci, cx, 1.0f / (float)N, P, kc);
-      hipLaunchKernelGGL(nl_apply_kernel<float>, g3, dim3(256), lds3, st, (const unsigned char*)vx.base, vx.sn, vx.sh, vx.sw, (const unsigned char*)vt.base, vt.sn, vt.sh, vt.sw, (unsigned char*)vo.base, vo.sn, vo.sh, vo.sw, vx.h, vx.w, ci, cx, P, bout, kc);
+      hipLaunchKernelGGL(nl_gram_kernel<float>, g1, dim3(256), 0, st, a);
+      hipLaunchKernelGGL(nl_fold_kernel, g2, dim3(256), lds2, st, a);
+      hipLaunchKernelGGL(nl_apply_kernel<float>, g3, dim3(256), lds3, st, a);
     }
     GLS_HIP(hipGetLastError());
     return 0;
   };
   return submit(std::move(op), stream);
+}
+
+extern "C" int glsdet_nonlocal(const glsdet_view* x, const glsdet_view* tpg, int32_t ci, const float* wout,
+                               const float* bout, float* gram, const glsdet_view* out, void* stream) {
+  return glsdet_nonlocal_multi(x, tpg, 1, ci, &wout, &bout, gram, out, stream);
 }

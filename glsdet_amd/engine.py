@@ -340,6 +340,18 @@ class Engine:
                                        ws.data_ptr(), C.byref(out.as_c()), _stream_ptr(self.stream)), "nonlocal")
         return out
 
+    def nonlocal_multi(self, xs: Sequence[TView], tpgs: Sequence[TView], ci: int, wouts, bouts) -> List[TView]:
+        """1..4 independent non-local blocks (in place on each x) in one set of three launches."""
+        n = len(xs)
+        ws = self.raw(n * xs[0].n * (8 * ci * ci + xs[0].c * ci) * 4)
+        xa = (View * n)(*[x.as_c() for x in xs])
+        ta = (View * n)(*[t.as_c() for t in tpgs])
+        wa = (C.c_void_p * n)(*[w.data_ptr() for w in wouts])
+        ba = (C.c_void_p * n)(*[b.data_ptr() for b in bouts])
+        check(self.lib.glsdet_nonlocal_multi(xa, ta, n, ci, wa, ba, ws.data_ptr(), xa, _stream_ptr(self.stream)),
+              "nonlocal_multi")
+        return list(xs)
+
     def decode(self, levels: Sequence[TView], num_classes: int, in_h: int, in_w: int,
                strides: Optional[Sequence[int]] = None, mode: int = 0, out: Optional[torch.Tensor] = None,
                scale_factors: Optional[torch.Tensor] = None) -> torch.Tensor:

@@ -19,6 +19,8 @@ drone/models/block/non_local/{Identity_Conv,yolo_patch_nonlocal_plus}.py.
 """
 from __future__ import annotations
 
+import os
+
 from typing import Dict, List, Optional, Sequence
 
 import torch
@@ -186,16 +188,19 @@ class NetBuilder:
             parts = [self._plain_part(p + ".theta"), self._plain_part(p + ".phi"), self._plain_part(p + ".g")]
             packs.append(self._pack(p + ".tpg", parts, x.c))
         tpgs = self.e.conv_group(xs, packs, 1, 0, "none")
-        outs = []
-        for p, x, tpg in zip(ps, xs, tpgs):
+        wouts, bouts = [], []
+        for p, x in zip(ps, xs):
             key = p + ".tpg"
             if key + ".out" not in self._packed:
                 w = self.sd[p + ".conv_out.weight"].float().reshape(-1, ci)
                 self._packed[key + ".out"] = (self.e.upload(w), self.e.upload(self.sd[p + ".conv_out.bias"].float()))
             wout, bout = self._packed[key + ".out"]
             assert wout.shape[0] == x.c, "Non_local_Block conv_out must map back to the input channels"
-            outs.append(self.e.nonlocal_(x, tpg, ci, wout, bout, out=x))
-        return outs
+            wouts.append(wout)
+            bouts.append(bout)
+        if len({(x.n, x.c) for x in xs}) == 1 and len(xs) <= 4 and not os.environ.get("GLSDET_NO_GROUP"):
+            return self.e.nonlocal_multi(xs, tpgs, ci, wouts, bouts)
+        return [self.e.nonlocal_(x, tpg, ci, w, b, out=x) for x, tpg, w, b in zip(xs, tpgs, wouts, bouts)]
 
     def patch_conv(self, p: str, x: TView, stride: int, with_nonlocal: bool, out: Optional[TView] = None) -> TView:
         """Patch_Conv / Patch_Conv_NonLocal (Identity_Conv.py:267-387)."""

@@ -141,6 +141,13 @@ int glsdet_resample_copy(const glsdet_view* x, const glsdet_view* y, int32_t fac
 int glsdet_nonlocal(const glsdet_view* x, const glsdet_view* tpg, int32_t ci,
                     const float* wout, const float* bout, float* gram,
                     const glsdet_view* out, void* stream);
+/* 1..4 independent non-local blocks with the same n, channel counts and dtype (the four
+ * quadrants of Patch_Conv_NonLocal, Identity_Conv.py:361-364) in one set of three launches.
+ * x, tpg, out: arrays of n_sets views; wout, bout: arrays of n_sets device pointers;
+ * gram: n_sets times the single-block workspace.                                           */
+int glsdet_nonlocal_multi(const glsdet_view* x, const glsdet_view* tpg, int32_t n_sets, int32_t ci,
+                          const float* const* wout, const float* const* bout, float* gram,
+                          const glsdet_view* out, void* stream);
 
 /* ---------------------------------------------------------------------------------
  * YOLOX decode        drone/models/core/utils_bbox.py:254-306  (mode 0, normalised cxcywh)

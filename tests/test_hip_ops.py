@@ -322,3 +322,28 @@ def test_conv2d_multi_equals_separate_convs(engines, mode, case):
         torch.cuda.synchronize()
         for o, ref in zip(outs, refs):
             _cmp(o.to_nchw(cout), ref, TOL[mode], "conv multi hint %x" % hint)
+
+
+@pytest.mark.parametrize("mode", ["f32", "f16"])
+def test_nonlocal_multi_unequal_sets(engines, mode):
+    """glsdet_nonlocal_multi: four quadrant windows of one tensor with different extents and weights."""
+    from glsdet_amd.nets import NetBuilder
+    eng = engines[mode]
+    cx = ci = 32
+    x = O.synth_input((2, cx, 13, 19), 9)
+    shapes = {}
+    names = ["q%d" % i for i in range(4)]
+    for nm in names:
+        shapes.update({nm + ".g.weight": (ci, cx, 1, 1), nm + ".g.bias": (ci,), nm + ".theta.weight": (ci, cx, 1, 1),
+                       nm + ".theta.bias": (ci,), nm + ".phi.weight": (ci, cx, 1, 1), nm + ".phi.bias": (ci,),
+                       nm + ".conv_out.weight": (cx, ci, 1, 1), nm + ".conv_out.bias": (cx,)})
+    sd = O.synth_state_dict(shapes, 5)
+    wins = [(0, 6, 0, 9), (6, 13, 0, 9), (0, 6, 9, 19), (6, 13, 9, 19)]
+    ref = x.clone()
+    for nm, (h0, h1, w0, w1) in zip(names, wins):
+        ref[:, :, h0:h1, w0:w1] = O.non_local_block(sd, nm, x[:, :, h0:h1, w0:w1])
+    xv = _to_view(eng, x)
+    b = NetBuilder(eng, sd)
+    b.nonlocal_blocks(names, [xv.window(h0, h1, w0, w1) for (h0, h1, w0, w1) in wins])
+    torch.cuda.synchronize()
+    _cmp(xv.to_nchw(), ref, 1e-4 if mode == "f32" else 2e-2, "nonlocal multi")
