@@ -315,22 +315,25 @@ class NetBuilder:
         return w, torch.ones(5 + nc), b
 
     def yolox_head(self, p: str, feats: Sequence[TView]) -> List[TView]:
-        """YOLOXHead.forward (base/yolox.py:46-92) -> per level fp32 [n,H,W,ceil8(5+nc)]."""
-        outs = []
-        self.stems = []
-        for k, x in enumerate(feats):
-            nc = self.sd["%s.cls_preds.%d.weight" % (p, k)].shape[0]
-            f = self.conv_out_channels("%s.stems.%d" % (p, k))
-            s = self.cba("%s.stems.%d" % (p, k), x)
-            self.stems.append(s)
-            T = self.cba(["%s.cls_convs.%d.0" % (p, k), "%s.reg_convs.%d.0" % (p, k)], s)
-            U = self.e.tensor(x.n, x.h, x.w, 2 * f)
-            self.cba_group(["%s.cls_convs.%d.1" % (p, k), "%s.reg_convs.%d.1" % (p, k)],
-                           [T.channels(0, f), T.channels(f, 2 * f)], outs=[U.channels(0, f), U.channels(f, 2 * f)])
-            pk = self._pack("%s.preds.%d" % (p, k), [self._pred_parts(p, k, f, nc)], U.c)
-            outs.append(self.e.conv(U, pk, 1, 0, "none", out_dtype=F32))
-            self.num_classes = nc
-        return outs
+        """YOLOXHead.forward (base/yolox.py:46-92) -> per level fp32 [n,H,W,ceil8(5+nc)].
+        Emitted stage by stage over the levels so that the small levels' convs of one shape class
+        (second tower convs, predictors) can share a grouped launch."""
+        L = len(feats)
+        nc = self.sd["%s.cls_preds.0.weight" % p].shape[0]
+        f = self.conv_out_channels("%s.stems.0" % p)
+        self.stems = [self.cba("%s.stems.%d" % (p, k), x) for k, x in enumerate(feats)]
+        T = [self.cba(["%s.cls_convs.%d.0" % (p, k), "%s.reg_convs.%d.0" % (p, k)], s) for k, s in enumerate(self.stems)]
+        U = [self.e.tensor(x.n, x.h, x.w, 2 * f) for x in feats]
+        pairs = lambda ks: (["%s.%s_convs.%d.1" % (p, t, k) for k in ks for t in ("cls", "reg")],
+                            [T[k].channels(i * f, (i + 1) * f) for k in ks for i in (0, 1)],
+                            [U[k].channels(i * f, (i + 1) * f) for k in ks for i in (0, 1)])
+        groups = [[0]] + ([[1, 2]] if L == 3 else [[k] for k in range(1, L)])     # level 0 is big enough alone
+        for ks in groups:
+            names, xs, outs = pairs(ks)
+            self.cba_group(names, xs, outs=outs)
+        packs = [self._pack("%s.preds.%d" % (p, k), [self._pred_parts(p, k, f, nc)], U[k].c) for k in range(L)]
+        self.num_classes = nc
+        return self.e.conv_group(U, packs, 1, 0, "none", out_dtype=F32)
 
 
     def cross_scale_head(self, p: str, feats: Sequence[TView]) -> List[TView]:
