@@ -68,6 +68,8 @@ _SIGS = {
     "glsdet_groupnorm_workspace_bytes": (C.c_int64, [C.c_int32, C.c_int32]),
     "glsdet_groupnorm": (C.c_int, [C.POINTER(View), C.POINTER(View), C.c_int32, C.c_void_p, C.c_void_p, C.c_float,
                                    C.c_int32, C.c_void_p, C.c_void_p]),
+    "glsdet_groupnorm_multi": (C.c_int, [C.POINTER(View), C.POINTER(View), C.c_int32, C.c_int32, C.POINTER(C.c_void_p),
+                                         C.POINTER(C.c_void_p), C.c_float, C.c_int32, C.c_void_p, C.c_void_p]),
     "glsdet_proxy_scores": (C.c_int, [C.POINTER(View), C.POINTER(View), C.POINTER(C.c_int32), C.c_int32, C.c_float,
                                       C.POINTER(View), C.c_void_p]),
     "glsdet_gfl_workspace_bytes": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),

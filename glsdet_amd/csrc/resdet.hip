@@ -109,20 +109,39 @@ __global__ __launch_bounds__(256) void upsample_add_kernel(const unsigned char* 
 // squares are kept in fp64 (no cancellation issue in E[x^2]-mean^2), folded per group in a
 // fixed order and written as one partial per (image, slice, group).
 #define GLS_GN_SPLIT 64
+#define GLS_GN_SETS 16
+// 1..16 independent tensors of the same C / groups / image count per launch pair (the cls and reg
+// towers of all five pyramid levels): operands in one kernarg struct, set = blockIdx.z.
+struct GnSet {
+  const unsigned char* x;
+  unsigned char* y;
+  long xsn, xsh, xsw, ysn, ysh, ysw;
+  const float *gamma, *beta;
+  double* partial;
+  int H, W, nsplit, chunk, gb;
+};
+struct GnArgs {
+  GnSet s[GLS_GN_SETS];
+  int n, C, groups, act;
+  float eps;
+};
+
 template <typename T>
-__global__ __launch_bounds__(256) void gn_stats_kernel(const unsigned char* x, long xsn, long xsh, long xsw, int H, int W,
-                                                       int C, int groups, int chunk, double* partial) {
+__global__ __launch_bounds__(256) void gn_stats_kernel(const GnArgs a) {
   typedef typename V16<T>::type V;
   constexpr int VN = V16<T>::N;
   __shared__ double s_sum[256], s_sq[256];
+  const GnSet& S = a.s[blockIdx.z];
   const int b = blockIdx.y, z = blockIdx.x;
+  if (z >= S.nsplit) return;
+  const int C = a.C, groups = a.groups, W = S.W;
   const int vcols = C / VN, rows = 256 / vcols;
   const int cc = threadIdx.x % vcols, r0 = threadIdx.x / vcols;
-  const int N = H * W;
-  const int pbeg = z * chunk, pend = min(N, pbeg + chunk);
+  const int N = S.H * W;
+  const int pbeg = z * S.chunk, pend = min(N, pbeg + S.chunk);
   double sum = 0.0, sq = 0.0;
   for (int p = pbeg + r0; p < pend; p += rows) {
-    const V v = *reinterpret_cast<const V*>(x + (b * xsn + (p / W) * xsh + (p % W) * xsw + cc * VN) * (long)sizeof(T));
+    const V v = *reinterpret_cast<const V*>(S.x + (b * S.xsn + (p / W) * S.xsh + (p % W) * S.xsw + cc * VN) * (long)sizeof(T));
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int e = 0; e < VN; ++e) {
@@ -138,43 +157,42 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const unsigned char* x, l
   __syncthreads();
   if ((int)threadIdx.x < groups) {
     const int g = threadIdx.x, cpg = C / groups, vpg = cpg / VN;       // vector columns per group
-    double a = 0.0, q = 0.0;
+    double t = 0.0, q = 0.0;
     for (int r = 0; r < rows; ++r)
       for (int c = g * vpg; c < (g + 1) * vpg; ++c) {
-        a += s_sum[r * vcols + c];
+        t += s_sum[r * vcols + c];
         q += s_sq[r * vcols + c];
       }
-    double* o = partial + (((long)b * GLS_GN_SPLIT + z) * groups + g) * 2;
-    o[0] = a;
+    double* o = S.partial + (((long)b * GLS_GN_SPLIT + z) * groups + g) * 2;
+    o[0] = t;
     o[1] = q;
   }
 }
 
 // Pass 2: fold the partials of this image (fixed order), then y = act((x - mean) * rstd * gamma + beta).
 template <typename T>
-__global__ __launch_bounds__(256) void gn_apply_kernel(const unsigned char* x, long xsn, long xsh, long xsw,
-                                                       unsigned char* y, long ysn, long ysh, long ysw, int H, int W,
-                                                       int C, int groups, int nsplit, const double* partial,
-                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                       float eps, int act) {
+__global__ __launch_bounds__(256) void gn_apply_kernel(const GnArgs a) {
   typedef typename V16<T>::type V;
   constexpr int VN = V16<T>::N;
   __shared__ float s_mean[256], s_rstd[256];
+  const GnSet& S = a.s[blockIdx.z];
+  if ((int)blockIdx.x >= S.gb) return;
   const int b = blockIdx.y;
-  const int N = H * W, cpg = C / groups;
+  const int C = a.C, groups = a.groups, W = S.W;
+  const int N = S.H * W, cpg = C / groups;
   if ((int)threadIdx.x < groups) {
-    double a = 0.0, q = 0.0;
-    for (int z = 0; z < nsplit; ++z) {
-      const double* o = partial + (((long)b * GLS_GN_SPLIT + z) * groups + threadIdx.x) * 2;
-      a += o[0];
+    double t = 0.0, q = 0.0;
+    for (int z = 0; z < S.nsplit; ++z) {
+      const double* o = S.partial + (((long)b * GLS_GN_SPLIT + z) * groups + threadIdx.x) * 2;
+      t += o[0];
       q += o[1];
     }
     const double cnt = (double)N * cpg;
-    const double mean = a / cnt;
+    const double mean = t / cnt;
     double var = q / cnt - mean * mean;
     if (var < 0.0) var = 0.0;
     s_mean[threadIdx.x] = (float)mean;
-    s_rstd[threadIdx.x] = (float)(1.0 / sqrt(var + (double)eps));
+    s_rstd[threadIdx.x] = (float)(1.0 / sqrt(var + (double)a.eps));
   }
   __syncthreads();
   const int vcols = C / VN, rows = 256 / vcols;
@@ -183,21 +201,21 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const unsigned char* x, l
   float sc[VN], sh[VN];
 #pragma unroll
   for (int e = 0; e < VN; ++e) {
-    const float ga = gamma[cc * VN + e] * s_rstd[g];
+    const float ga = S.gamma[cc * VN + e] * s_rstd[g];
     sc[e] = ga;
-    sh[e] = beta[cc * VN + e] - s_mean[g] * ga;
+    sh[e] = S.beta[cc * VN + e] - s_mean[g] * ga;
   }
-  for (int p = blockIdx.x * rows + r0; p < N; p += gridDim.x * rows) {
-    const long ox = (b * xsn + (p / W) * xsh + (p % W) * xsw + cc * VN) * (long)sizeof(T);
-    const long oy = (b * ysn + (p / W) * ysh + (p % W) * ysw + cc * VN) * (long)sizeof(T);
-    V v = *reinterpret_cast<const V*>(x + ox);
+  for (int p = blockIdx.x * rows + r0; p < N; p += S.gb * rows) {
+    const long ox = (b * S.xsn + (p / W) * S.xsh + (p % W) * S.xsw + cc * VN) * (long)sizeof(T);
+    const long oy = (b * S.ysn + (p / W) * S.ysh + (p % W) * S.ysw + cc * VN) * (long)sizeof(T);
+    V v = *reinterpret_cast<const V*>(S.x + ox);
 #pragma unroll
     for (int e = 0; e < VN; ++e) {
       float f = (float)v[e] * sc[e] + sh[e];
-      if (act == GLSDET_ACT_RELU) f = fmaxf(f, 0.f);
+      if (a.act == GLSDET_ACT_RELU) f = fmaxf(f, 0.f);
       v[e] = (T)f;
     }
-    *reinterpret_cast<V*>(y + oy) = v;
+    *reinterpret_cast<V*>(S.y + oy) = v;
   }
 }
 
@@ -351,45 +369,68 @@ extern "C" int64_t glsdet_groupnorm_workspace_bytes(int32_t n, int32_t groups) {
   return (int64_t)n * GLS_GN_SPLIT * groups * 2 * (int64_t)sizeof(double);
 }
 
-extern "C" int glsdet_groupnorm(const glsdet_view* x, const glsdet_view* y, int32_t groups, const float* gamma,
-                                const float* beta, float eps, int32_t act, void* stats, void* stream) {
+extern "C" int glsdet_groupnorm_multi(const glsdet_view* x, const glsdet_view* y, int32_t n_sets, int32_t groups,
+                                      const float* const* gamma, const float* const* beta, float eps, int32_t act,
+                                      void* stats, void* stream) {
   if (!x || !y || !gamma || !beta || !stats) GLS_FAIL(GLSDET_E_ARG, "groupnorm: null argument");
-  int rc;
-  if ((rc = check_view(*x, "groupnorm.x"))) return rc;
-  if ((rc = check_view(*y, "groupnorm.y"))) return rc;
-  if (!same_extent(*x, *y) || x->dtype != y->dtype) GLS_FAIL(GLSDET_E_ARG, "groupnorm: x/y extent or dtype mismatch");
+  if (n_sets < 1 || n_sets > GLS_GN_SETS) GLS_FAIL(GLSDET_E_ARG, "groupnorm: 1..%d sets", GLS_GN_SETS);
   if (act != GLSDET_ACT_NONE && act != GLSDET_ACT_RELU) GLS_FAIL(GLSDET_E_ARG, "groupnorm: act must be none or relu");
-  const int vn = 16 / dtype_size(x->dtype);
-  if (groups < 1 || groups > 256 || x->c % groups || (x->c / groups) % vn || x->c / vn > 256 || 256 % (x->c / vn))
-    GLS_FAIL(GLSDET_E_ARG, "groupnorm: need C %% groups == 0, (C/groups) %% %d == 0 and C/%d a divisor of 256 (C=%d groups=%d)",
-             vn, vn, x->c, groups);
   if ((uintptr_t)stats & 7) GLS_FAIL(GLSDET_E_ALIGN, "groupnorm: stats must be 8-byte aligned");
-  const glsdet_view a = *x, b = *y;
-  const int N = a.h * a.w;
-  int nsplit = (N + 255) / 256;
-  if (nsplit > GLS_GN_SPLIT) nsplit = GLS_GN_SPLIT;
-  const int chunk = (N + nsplit - 1) / nsplit;
-  double* part = (double*)stats;
+  const int dt = x[0].dtype, C = x[0].c, nimg = x[0].n;
+  const int vn = 16 / dtype_size(dt);
+  if (groups < 1 || groups > 256 || C % groups || (C / groups) % vn || C / vn > 256 || 256 % (C / vn))
+    GLS_FAIL(GLSDET_E_ARG, "groupnorm: need C %% groups == 0, (C/groups) %% %d == 0 and C/%d a divisor of 256 (C=%d groups=%d)",
+             vn, vn, C, groups);
+  GnArgs a = {};
+  a.n = n_sets; a.C = C; a.groups = groups; a.act = act; a.eps = eps;
+  const int rows = 256 / (C / vn);
+  int max_split = 1, max_gb = 1;
   OpRecord op;
   op.kind = 7;
-  op.flops = 0;
-  op.bytes = 3.0 * a.n * N * a.c * dtype_size(a.dtype);
-  op.name = "groupnorm(stats+apply)";
+  op.flops = op.bytes = 0;
+  const long per_set = (long)nimg * GLS_GN_SPLIT * groups * 2;      // doubles
+  for (int q = 0; q < n_sets; ++q) {
+    int rc;
+    if ((rc = check_view(x[q], "groupnorm.x"))) return rc;
+    if ((rc = check_view(y[q], "groupnorm.y"))) return rc;
+    if (!same_extent(x[q], y[q]) || x[q].dtype != dt || y[q].dtype != dt || x[q].c != C || x[q].n != nimg)
+      GLS_FAIL(GLSDET_E_ARG, "groupnorm: set %d extent / dtype / channel mismatch", q);
+    if (!gamma[q] || !beta[q]) GLS_FAIL(GLSDET_E_ARG, "groupnorm: null gamma/beta");
+    GnSet& S = a.s[q];
+    const int N = x[q].h * x[q].w;
+    S.x = (const unsigned char*)x[q].base; S.y = (unsigned char*)y[q].base;
+    S.xsn = x[q].sn; S.xsh = x[q].sh; S.xsw = x[q].sw;
+    S.ysn = y[q].sn; S.ysh = y[q].sh; S.ysw = y[q].sw;
+    S.gamma = gamma[q]; S.beta = beta[q];
+    S.partial = (double*)stats + q * per_set;
+    S.H = x[q].h; S.W = x[q].w;
+    S.nsplit = (N + 255) / 256;
+    if (S.nsplit > GLS_GN_SPLIT) S.nsplit = GLS_GN_SPLIT;
+    S.chunk = (N + S.nsplit - 1) / S.nsplit;
+    S.gb = (N + rows * 8 - 1) / (rows * 8);
+    if (S.gb > 1024) S.gb = 1024;
+    if (S.nsplit > max_split) max_split = S.nsplit;
+    if (S.gb > max_gb) max_gb = S.gb;
+    op.bytes += 3.0 * nimg * N * C * dtype_size(dt);
+  }
+  op.name = n_sets > 1 ? "groupnorm_multi(stats+apply)" : "groupnorm(stats+apply)";
   op.launch = [=](hipStream_t st) -> int {
-    const int rows = 256 / (a.c / vn);
-    int gb = (N + rows * 8 - 1) / (rows * 8);
-    if (gb > 1024) gb = 1024;
-    if (a.dtype == GLSDET_F16) {
-      hipLaunchKernelGGL(gn_stats_kernel<f16>, dim3(nsplit, a.n), dim3(256), 0, st, (const unsigned char*)a.base, a.sn, a.sh, a.sw, a.h, a.w, a.c, groups, chunk, part);
-      hipLaunchKernelGGL(gn_apply_kernel<f16>, dim3(gb, a.n), dim3(256), 0, st, (const unsigned char*)a.base, a.sn, a.sh, a.sw, (unsigned char*)b.base, b.sn, b.sh, b.sw, a.h, a.w, a.c, groups, nsplit, part, gamma, beta, eps, act);
+    if (dt == GLSDET_F16) {
+      hipLaunchKernelGGL(gn_stats_kernel<f16>, dim3(max_split, nimg, a.n), dim3(256), 0, st, a);
+      hipLaunchKernelGGL(gn_apply_kernel<f16>, dim3(max_gb, nimg, a.n), dim3(256), 0, st, a);
     } else {
-      hipLaunchKernelGGL(gn_stats_kernel<float>, dim3(nsplit, a.n), dim3(256), 0, st, (const unsigned char*)a.base, a.sn, a.sh, a.sw, a.h, a.w, a.c, groups, chunk, part);
-      hipLaunchKernelGGL(gn_apply_kernel<float>, dim3(gb, a.n), dim3(256), 0, st, (const unsigned char*)a.base, a.sn, a.sh, a.sw, (unsigned char*)b.base, b.sn, b.sh, b.sw, a.h, a.w, a.c, groups, nsplit, part, gamma, beta, eps, act);
+      hipLaunchKernelGGL(gn_stats_kernel<float>, dim3(max_split, nimg, a.n), dim3(256), 0, st, a);
+      hipLaunchKernelGGL(gn_apply_kernel<float>, dim3(max_gb, nimg, a.n), dim3(256), 0, st, a);
     }
     GLS_HIP(hipGetLastError());
     return 0;
   };
   return submit(std::move(op), stream);
+}
+
+extern "C" int glsdet_groupnorm(const glsdet_view* x, const glsdet_view* y, int32_t groups, const float* gamma,
+                                const float* beta, float eps, int32_t act, void* stats, void* stream) {
+  return glsdet_groupnorm_multi(x, y, 1, groups, &gamma, &beta, eps, act, stats, stream);
 }
 
 extern "C" int glsdet_proxy_scores(const glsdet_view* feat, const glsdet_view* dots, const int32_t* counts,

@@ -417,6 +417,21 @@ class Engine:
                                         eps, ACT[act], ws.data_ptr(), _stream_ptr(self.stream)), "groupnorm")
         return out
 
+    def groupnorm_multi(self, xs: Sequence[TView], groups: int, gammas, betas, eps: float, act: str = "relu") -> List[TView]:
+        """In place on each x: up to 16 tensors of the same n / C per launch pair."""
+        done = 0
+        while done < len(xs):
+            part = list(range(done, min(done + 16, len(xs))))
+            n = len(part)
+            ws = self.raw(n * self.lib.glsdet_groupnorm_workspace_bytes(xs[0].n, groups))
+            xa = (View * n)(*[xs[i].as_c() for i in part])
+            ga = (C.c_void_p * n)(*[gammas[i].data_ptr() for i in part])
+            ba = (C.c_void_p * n)(*[betas[i].data_ptr() for i in part])
+            check(self.lib.glsdet_groupnorm_multi(xa, xa, n, groups, ga, ba, eps, ACT[act], ws.data_ptr(),
+                                                  _stream_ptr(self.stream)), "groupnorm_multi")
+            done += n
+        return list(xs)
+
     def proxy_scores(self, feat: TView, dots: TView, counts: Sequence[int], gamma: float,
                      out: Optional[TView] = None) -> TView:
         nc = len(counts)

@@ -111,47 +111,70 @@ class ResDetBuilder:
         return outs
 
     # ------------------------------------------------------------------ heads
-    def _gn(self, key: str, names: Sequence[str], x: TView, groups_each: int = 32) -> TView:
+    @staticmethod
+    def _level_groups(feats: Sequence[TView], per_level: int = 1) -> List[List[int]]:
+        """Levels whose maps are small share grouped launches (<= 4 convs per launch); a big level
+        fills the chip alone."""
+        big = [i for i, f in enumerate(feats) if f.h * f.w > 64 * 64 // 2]
+        small = [i for i, f in enumerate(feats) if f.h * f.w <= 64 * 64 // 2]
+        groups = [[i] for i in big]
+        step = max(1, 4 // per_level)
+        groups += [small[i:i + step] for i in range(0, len(small), step)]
+        return groups
+
+    def _conv_levels(self, xs: Sequence[TView], packs, pad: int, out_dtype=None, per_level: int = 1) -> List[TView]:
+        """One conv per entry (entries ordered level-major, `per_level` consecutive entries per level),
+        grouped over the small levels."""
+        L = len(xs) // per_level
+        outs: List[Optional[TView]] = [None] * len(xs)
+        for g in self._level_groups(xs[::per_level], per_level):
+            idx = [l * per_level + j for l in g for j in range(per_level)]
+            res = self.e.conv_group([xs[i] for i in idx], [packs[i] for i in idx], 1, pad, "none", out_dtype=out_dtype)
+            for i, r in zip(idx, res):
+                outs[i] = r
+        return outs
+
+    def _gn_params(self, key: str, names: Sequence[str]):
         ga = self._dev(key + ".gamma", torch.cat([self.sd[n + ".gn.weight"] for n in names]))
         be = self._dev(key + ".beta", torch.cat([self.sd[n + ".gn.bias"] for n in names]))
-        return self.e.groupnorm(x, groups_each * len(names), ga, be, GN_EPS, "relu")
+        return ga, be
 
-    def towers(self, p: str, x: TView, stacked: int) -> Tuple[TView, TView]:
-        """cls / reg towers of gfl_head.py:128-152: `stacked` x (3x3 conv, GN32, ReLU) each.
-        Layer 0 of both towers is one fused GEMM + one 64-group GN."""
-        e = self.e
-        names = ["%s.cls_convs.0" % p, "%s.reg_convs.0" % p]
+    def towers(self, p: str, feats: Sequence[TView], stacked: int) -> Tuple[List[TView], List[TView]]:
+        """cls / reg towers of gfl_head.py:128-152 for ALL levels (shared weights), emitted layer by
+        layer: `stacked` x (3x3 conv, GN32, ReLU) each.  Layer 0 of both towers is one fused GEMM
+        (Cout 512) + one 64-group GN; per layer the GroupNorms of all levels and both towers are
+        one launch pair, the convs of the small levels share grouped launches."""
+        e, L = self.e, len(feats)
         raw = lambda n: (self.sd[n + ".conv.weight"], torch.ones(self.sd[n + ".conv.weight"].shape[0]),
                          torch.zeros(self.sd[n + ".conv.weight"].shape[0]))
-        f = self.sd[names[0] + ".conv.weight"].shape[0]
-        both = e.conv(x, self._pack(p + ".tower0", [raw(n) for n in names], x.c), 1, 1, "none")
-        self._gn(p + ".tower0", names, both)
-        c, r = both.channels(0, f), both.channels(f, 2 * f)
+        names0 = ["%s.cls_convs.0" % p, "%s.reg_convs.0" % p]
+        f = self.sd[names0[0] + ".conv.weight"].shape[0]
+        pk0 = self._pack(p + ".tower0", [raw(n) for n in names0], feats[0].c)
+        both = self._conv_levels(feats, [pk0] * L, 1)
+        ga, be = self._gn_params(p + ".tower0", names0)
+        e.groupnorm_multi(both, 64, [ga] * L, [be] * L, GN_EPS, "relu")
+        cur = [t.channels(j * f, (j + 1) * f) for t in both for j in (0, 1)]      # level-major: cls_l, reg_l
         for i in range(1, stacked):
-            for which in ("cls", "reg"):
-                n = "%s.%s_convs.%d" % (p, which, i)
-                t = e.conv(c if which == "cls" else r, self._pack(n, [raw(n)], f), 1, 1, "none")
-                self._gn(n, [n], t)
-                if which == "cls":
-                    c = t
-                else:
-                    r = t
-        return c, r
+            names = ["%s.%s_convs.%d" % (p, which, i) for which in ("cls", "reg")]
+            pks = [self._pack(n, [raw(n)], f) for n in names]
+            gb = [self._gn_params(n, [n]) for n in names]
+            cur = self._conv_levels(cur, pks * L, 1, per_level=2)
+            e.groupnorm_multi(cur, 32, [gb[j][0] for _ in range(L) for j in (0, 1)],
+                              [gb[j][1] for _ in range(L) for j in (0, 1)], GN_EPS, "relu")
+        return cur[0::2], cur[1::2]
 
-    def _reg_pred(self, p: str, r: TView, level: int) -> TView:
-        scale = float(self.sd["%s.scales.%d.scale" % (p, level)])
-        pk = self._pack("%s.gfl_reg@%d" % (p, level), [self._plain_part(p + ".gfl_reg", scale)], r.c)
-        return self.e.conv(r, pk, 1, 1, "none", out_dtype=F32)
+    def _reg_preds(self, p: str, regs: Sequence[TView]) -> List[TView]:
+        pks = []
+        for l, r in enumerate(regs):
+            scale = float(self.sd["%s.scales.%d.scale" % (p, l)])          # mmcv Scale folded into the weights
+            pks.append(self._pack("%s.gfl_reg@%d" % (p, l), [self._plain_part(p + ".gfl_reg", scale)], r.c))
+        return self._conv_levels(regs, pks, 1, out_dtype=F32)
 
     def gfl_head(self, p: str, feats: Sequence[TView], stacked: int = 4) -> Tuple[List[TView], List[TView]]:
         """gfl_head.py:179-203 -> fp32 views: cls logits [n,h,w,nc], reg logits [n,h,w,4*(reg_max+1)]."""
-        cls, reg = [], []
-        for l, x in enumerate(feats):
-            c, r = self.towers(p, x, stacked)
-            cls.append(self.e.conv(c, self._pack(p + ".gfl_cls", [self._plain_part(p + ".gfl_cls")], c.c), 1, 1, "none",
-                                   out_dtype=F32))
-            reg.append(self._reg_pred(p, r, l))
-        return cls, reg
+        cs, rs = self.towers(p, feats, stacked)
+        pk = self._pack(p + ".gfl_cls", [self._plain_part(p + ".gfl_cls")], cs[0].c)
+        return self._conv_levels(cs, [pk] * len(cs), 1, out_dtype=F32), self._reg_preds(p, rs)
 
     def mp_head(self, p: str, feats: Sequence[TView], proxies_list: Sequence[int], gamma: float = 10.0,
                 stacked: int = 4) -> Tuple[List[TView], List[TView]]:
@@ -160,16 +183,14 @@ class ResDetBuilder:
         prox = self.sd[p + ".proxies"].float()
         assert prox.shape[0] == sum(proxies_list), "proxies_list does not match the proxies parameter"
         centers = prox / prox.norm(dim=1, keepdim=True).clamp_min(1e-12)        # F.normalize(p=2, dim=1)
-        cls, reg = [], []
-        for l, x in enumerate(feats):
-            c, r = self.towers(p, x, stacked)
-            reg.append(self._reg_pred(p, r, l))
-            f = e.conv(c, self._pack(p + ".gfl_cls_conv", [self._plain_part(p + ".gfl_cls_conv")], c.c), 1, 1, "none")
-            w = centers.reshape(centers.shape[0], centers.shape[1], 1, 1)
-            dots = e.conv(f, self._pack(p + ".proxies", [(w, torch.ones(w.shape[0]), torch.zeros(w.shape[0]))], f.c),
-                          1, 0, "none", out_dtype=F32)
-            cls.append(e.proxy_scores(f, dots, list(proxies_list), gamma))
-        return cls, reg
+        cs, rs = self.towers(p, feats, stacked)
+        reg = self._reg_preds(p, rs)
+        pkf = self._pack(p + ".gfl_cls_conv", [self._plain_part(p + ".gfl_cls_conv")], cs[0].c)
+        fs = self._conv_levels(cs, [pkf] * len(cs), 1)
+        w = centers.reshape(centers.shape[0], centers.shape[1], 1, 1)
+        pkp = self._pack(p + ".proxies", [(w, torch.ones(w.shape[0]), torch.zeros(w.shape[0]))], fs[0].c)
+        dots = self._conv_levels(fs, [pkp] * len(fs), 0, out_dtype=F32)
+        return [e.proxy_scores(f, d, list(proxies_list), gamma) for f, d in zip(fs, dots)], reg
 
 
 class _Compiled:

@@ -212,6 +212,11 @@ int glsdet_upsample_add(const glsdet_view* coarse, const glsdet_view* fine, void
 int64_t glsdet_groupnorm_workspace_bytes(int32_t n, int32_t groups);
 int glsdet_groupnorm(const glsdet_view* x, const glsdet_view* y, int32_t groups, const float* gamma,
                      const float* beta, float eps, int32_t act, void* stats, void* stream);
+/* 1..16 tensors of the same n / C / groups in one launch pair (cls and reg tower outputs of all
+ * pyramid levels); stats = n_sets times the single-tensor workspace. */
+int glsdet_groupnorm_multi(const glsdet_view* x, const glsdet_view* y, int32_t n_sets, int32_t groups,
+                           const float* const* gamma, const float* const* beta, float eps, int32_t act,
+                           void* stats, void* stream);
 
 /* MPHead.forward_proxy (ufp/mmdet/models/dense_heads/mp_head.py:105-121).
  *   feat : view [n,h,w,C] (the gfl_cls_conv output), engine dtype
