@@ -273,17 +273,56 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
   __syncthreads();
   constexpr int VO = 16 / (int)sizeof(TO);
   constexpr int OCPR = CO_T / VO;                // 16-B chunks per pixel row of the tile
-  for (int q = tid; q < PX_T * OCPR; q += 256) {
-    const int px_l = q / OCPR, cc = q - px_l * OCPR;
-    const int p = px0 + px_l, co = co0 + cc * VO;
-    if (p < a.M && co < a.Cout) {
-      u32x4 v = *reinterpret_cast<const u32x4*>(smem + px_l * ORS + cc * 16);
-      if (a.res) {
-        const long ro = gls_pix_off(p, HoWo, a.Wo, a.r_sn, a.r_sh, a.r_sw, a.r_lin) + co;
-        v = add_chunk(v, *reinterpret_cast<const u32x4*>(a.res + ro * (long)sizeof(TO)), (TO*)nullptr, a.act_post);
+  // written in batches of EB chunks per thread: all residual loads of a batch are issued before the
+  // first add / store, so a residual layer keeps EB x 16 B per thread in flight instead of one
+  // (measured: +3...8 % on the residual 1x1 layers with 64-wide tiles; on the 128x128 tile, 8 chunks
+  // per thread, the extra live registers cost 25 % -- there the chunks go one by one)
+  constexpr int NIT = (PX_T * OCPR + 255) / 256;
+  if constexpr (NIT > 4) {
+    for (int q = tid; q < PX_T * OCPR; q += 256) {
+      const int px_l = q / OCPR, cc = q - px_l * OCPR;
+      const int p = px0 + px_l, co = co0 + cc * VO;
+      if (p < a.M && co < a.Cout) {
+        u32x4 v = *reinterpret_cast<const u32x4*>(smem + px_l * ORS + cc * 16);
+        if (a.res) {
+          const long ro = gls_pix_off(p, HoWo, a.Wo, a.r_sn, a.r_sh, a.r_sw, a.r_lin) + co;
+          v = add_chunk(v, *reinterpret_cast<const u32x4*>(a.res + ro * (long)sizeof(TO)), (TO*)nullptr, a.act_post);
+        }
+        const long yo = gls_pix_off(p, HoWo, a.Wo, a.y_sn, a.y_sh, a.y_sw, a.y_lin) + co;
+        *reinterpret_cast<u32x4*>(a.y + yo * (long)sizeof(TO)) = v;
       }
-      const long yo = gls_pix_off(p, HoWo, a.Wo, a.y_sn, a.y_sh, a.y_sw, a.y_lin) + co;
-      *reinterpret_cast<u32x4*>(a.y + yo * (long)sizeof(TO)) = v;
+    }
+    return;
+  }
+  constexpr int EB = NIT <= 4 ? NIT : 1;
+  for (int it0 = 0; it0 < NIT; it0 += EB) {
+    u32x4 rv[EB];
+    long yo[EB];
+    bool ok[EB];
+#pragma unroll
+    for (int b = 0; b < EB; ++b) {
+      const int q = tid + (it0 + b) * 256;
+      const int px_l = q / OCPR, cc = q - px_l * OCPR;
+      const int p = px0 + px_l, co = co0 + cc * VO;
+      ok[b] = q < PX_T * OCPR && p < a.M && co < a.Cout;
+      yo[b] = 0;
+      if (ok[b]) {
+        yo[b] = gls_pix_off(p, HoWo, a.Wo, a.y_sn, a.y_sh, a.y_sw, a.y_lin) + co;
+        if (a.res) {
+          const long ro = gls_pix_off(p, HoWo, a.Wo, a.r_sn, a.r_sh, a.r_sw, a.r_lin) + co;
+          rv[b] = *reinterpret_cast<const u32x4*>(a.res + ro * (long)sizeof(TO));
+        }
+      }
+    }
+#pragma unroll
+    for (int b = 0; b < EB; ++b) {
+      if (ok[b]) {
+        const int q = tid + (it0 + b) * 256;
+        const int px_l = q / OCPR, cc = q - px_l * OCPR;
+        u32x4 v = *reinterpret_cast<const u32x4*>(smem + px_l * ORS + cc * 16);
+        if (a.res) v = add_chunk(v, rv[b], (TO*)nullptr, a.act_post);
+        *reinterpret_cast<u32x4*>(a.y + yo[b] * (long)sizeof(TO)) = v;
+      }
     }
   }
 }

@@ -46,6 +46,8 @@ HINTS = {"auto": 0, "halo": 2, "ws1x1": 3, "g128x128": (128 << 16) | 128, "g64x1
 
 def main():
     args = sys.argv[1:]
+    use_res = "res" in args
+    args = [a for a in args if a != "res"]
     shapes = SHAPES
     if args and args[0] == "resnet":
         shapes, args = RESNET, args[1:]
@@ -65,13 +67,19 @@ def main():
                 out = eng.conv(x, pk, s, (k - 1) // 2, "silu", tile_hint=h)
             except GlsdetError:
                 continue
+            res = None
+            if use_res:                     # residual layer (ResNet conv3: add, then ReLU)
+                res = eng.tensor(out.n, out.h, out.w, out.c)
+                res.buf.view(torch.float16).normal_()
+            conv = lambda: eng.conv(x, pk, s, (k - 1) // 2, "relu" if use_res else "silu", out=out, tile_hint=h, res=res,
+                                    res_first=use_res)
             for _ in range(3):
-                eng.conv(x, pk, s, (k - 1) // 2, "silu", out=out, tile_hint=h)
+                conv()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             reps = 20
             for _ in range(reps):
-                eng.conv(x, pk, s, (k - 1) // 2, "silu", out=out, tile_hint=h)
+                conv()
             e1.record()
             torch.cuda.synchronize()
             us = e0.elapsed_time(e1) * 1e3 / reps
