@@ -238,7 +238,7 @@ def main():
     ap.add_argument("--max-det", type=int, default=3000)
     ap.add_argument("--nms", type=float, default=0.65)
     ap.add_argument("--no-graph", action="store_true")
-    ap.add_argument("--streams", type=int, default=2,
+    ap.add_argument("--streams", type=int, default=3,
                     help="plan instances replayed round-robin on their own HIP streams (batches in flight)")
     ap.add_argument("--no-autotune", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -296,7 +296,8 @@ def main():
                 gather_detections(buf(ci)["dets"], buf(ci)["count"])
             return
         # one batch = one graph replay on the instance's own stream (+ its gather when N>1);
-        # consecutive batches alternate instances, so two batches are in flight
+        # consecutive batches rotate over the instances, so `--streams` batches are in flight (3: +6 % over 2
+        # on the default workload, measured twice on one box; 4 is slower again)
         det.run_async(ci)
         if world > 1:
             with torch.cuda.stream(ci.graph_stream):

@@ -121,6 +121,9 @@ def _stream_ptr(stream) -> int:
     return stream.cuda_stream
 
 
+_SHARED_TUNED: dict = {}
+
+
 class Engine:
     """Owns device buffers and packed weights; emits ops (eagerly or into a Plan)."""
 
@@ -135,12 +138,14 @@ class Engine:
         self._keep: List[torch.Tensor] = []
         self.alloc_bytes = 0
         self.autotune = autotune        # measure kernel/tile variants per conv problem at build time
-        self._tuned = {}
+        # tuning results are shared by all engines of a dtype in this process: the second and third
+        # plan instance of a detector reuse the first one's measurements (and pick identical kernels)
+        self._tuned = _SHARED_TUNED.setdefault(dtype, {})
         # optional persistent tuning cache (JSON): GLSDET_TUNE_CACHE=/path/file.json
         self._tune_cache_path = os.environ.get("GLSDET_TUNE_CACHE", "")
         if self._tune_cache_path and os.path.exists(self._tune_cache_path):
             with open(self._tune_cache_path) as f:
-                self._tuned = {tuple(json.loads(k)): v for k, v in json.load(f).get(dtype, {}).items()}
+                self._tuned.update({tuple(json.loads(k)): v for k, v in json.load(f).get(dtype, {}).items()})
         self._dtype_name = dtype
 
     # ---- memory
