@@ -77,6 +77,10 @@ _SIGS = {
                                     C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_float, C.c_int32,
                                     C.c_float, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                     C.c_int64, C.c_void_p]),
+    "glsdet_pil_resize_normalize": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
+                                              C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
+                                              C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_double),
+                                              C.POINTER(C.c_double), C.c_void_p]),
     "glsdet_plan_create": (C.c_void_p, []),
     "glsdet_plan_destroy": (None, [C.c_void_p]),
     "glsdet_plan_begin": (C.c_int, [C.c_void_p]),

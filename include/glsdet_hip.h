@@ -249,6 +249,26 @@ int glsdet_gfl_detect(const glsdet_view* cls, const glsdet_view* reg, int32_t n_
                       void* ws, int64_t ws_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------
+ * Image preprocessing, drone flavour:
+ *   PIL `image.resize(size, Image.BICUBIC)` + `preprocess_input` + HWC->CHW
+ *   (drone/models/core/utils.py:21-34,46-50; yolo.py:130-134), bit-identical to Pillow:
+ *   two passes with uint8 intermediate and 22-bit fixed-point coefficients.
+ * src : device uint8 [in_h][in_w][3] (RGB);  tmp: device uint8 [in_h][out_w][3] scratch
+ * x/y bounds: device int32 [out][2] = (first source index, tap count); x/y kk: device int32
+ *   [out][ksize] coefficients * 2^22 as Pillow's precompute_coeffs + normalize_coeffs_8bpc give
+ *   them (glsdet_amd/preprocess.py computes the tables on the host)
+ * dst : device fp32 image [3][dst_h][dst_w] (one image of an NCHW batch); the resized picture
+ *   lands at (off_y, off_x) (letterbox paste), the rest of the canvas is the caller's.
+ * mean3 / std3: host double[3]; value = f32(f64(f32(v/255f)) - mean) then f32(f64(.) / std), the
+ *   mixed float32/float64 in-place arithmetic numpy performs in preprocess_input.          */
+int glsdet_pil_resize_normalize(const unsigned char* src, int32_t in_h, int32_t in_w,
+                                const int32_t* xbounds, const int32_t* xkk, int32_t xksize, int32_t out_w,
+                                const int32_t* ybounds, const int32_t* ykk, int32_t yksize, int32_t out_h,
+                                unsigned char* tmp, float* dst, int32_t dst_h, int32_t dst_w,
+                                int32_t off_y, int32_t off_x, const double* mean3, const double* std3,
+                                void* stream);
+
+/* ---------------------------------------------------------------------------------
  * Plan: a recorded sequence of the calls above, replayed without Python in the loop and
  * capturable into one hipGraph (HIP streams + graphs instead of a tracing compiler).
  * Recording: glsdet_plan_begin(plan) makes every following entry-point call on this

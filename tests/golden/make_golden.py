@@ -91,7 +91,40 @@ def attention_cases(block):
     block("att_darknet_tiny", Outs, (1, 3, 128, 160), calibrate=True)
 
 
+PRE_CASES = [  # (in_h, in_w), input_shape (H, W), letterbox   -- synth_image(seed = index)
+    ((77, 123), (64, 96), False), ((77, 123), (64, 96), True), ((150, 90), (64, 96), True),
+    ((64, 96), (64, 96), False), ((300, 500), (64, 96), False), ((31, 45), (64, 96), True),
+    ((97, 64), (96, 64), True),
+]
+
+
+def synth_image(shape, seed):
+    """Smooth colour gradients + texture + saturated patches, uint8 HWC RGB (test input data)."""
+    h, w = shape
+    rng = np.random.default_rng([seed, 0x1A6E])
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float64)
+    img = np.stack([127 + 120 * np.sin(xx / (5 + 3 * c) + seed) * np.cos(yy / (7 + 2 * c)) for c in range(3)], -1)
+    img += rng.normal(0, 25, img.shape)
+    img[: h // 5, : w // 4] = 255
+    img[-(h // 6):, -(w // 5):] = 0
+    return np.clip(img, 0, 255).astype(np.uint8)
+
+
+def preprocess_cases():
+    """Row f.3: the reference's own resize_image + preprocess_input (drone/models/core/utils.py)."""
+    from PIL import Image
+    from models.core.utils import preprocess_input, resize_image
+    out = {}
+    for i, (ishape, shape, lb) in enumerate(PRE_CASES):
+        img = Image.fromarray(synth_image(ishape, i), "RGB")
+        data = resize_image(img, (shape[1], shape[0]), lb)
+        out["pre/%d" % i] = np.expand_dims(np.transpose(preprocess_input(np.array(data, dtype="float32")), (2, 0, 1)), 0)
+    np.savez_compressed(os.path.join(HERE, "preprocess_golden.npz"), **out)
+    print("preprocess:", len(out), "cases,", os.path.getsize(os.path.join(HERE, "preprocess_golden.npz")), "bytes")
+
+
 def main():
+    preprocess_cases()
     from models.base import yolox as ref_base
     from models.base.baseConv import BaseConv, DWConv
     from models.base.darknet import Bottleneck, CSPLayer, Focus, SPPBottleneck
