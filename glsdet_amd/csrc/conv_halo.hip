@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const ConvArgs a, const 
   constexpr int TM = WT_CO / 32, TN = WT_PX / 32;
   constexpr int A_BYTES = CO_T * RS;
   constexpr int PATCH_OFF = 2 * A_BYTES;
-  static_assert(PX_T == 128 && TW == 16 && TM >= 1 && TN >= 1, "tile shape");
+  static_assert(PX_T == 128 && TW == 16 && TM >= 1 && TN >= 1 && (WCO != 4 || CO_T == 128), "tile shape");
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -71,10 +71,17 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const ConvArgs a, const 
   const int kc = tid & 7, row0 = tid >> 3;         // 8 chunks per 128-B row, 32 rows per pass
   const auto xrs = gls_make_rsrc(a.x_lo, a.x_bytes);
   const auto wrs = gls_make_rsrc(a.w, a.w_bytes);
+  // WCO == 4 ("wave-private weights"): each wave owns 32 cout rows x all 128 pixels and stages exactly
+  // the weight rows it multiplies itself -- no other wave reads them, so the per-tap workgroup barrier
+  // disappears (LDS operations of one wave execute in order); the waves meet only when the input
+  // patch is exchanged, once per 128-byte channel chunk.
+  constexpr bool WP = WCO == 4;
   unsigned wp[NA];                                  // byte offsets; GLS_OOB rows read as zeros
+  int arow[NA];                                     // LDS row of chunk i
 #pragma unroll
   for (int i = 0; i < NA; ++i) {
-    const int row = row0 + i * 32;
+    const int row = WP ? 32 * wave + (lane >> 3) + 8 * i : row0 + i * 32;
+    arow[i] = row;
     const bool ok = row < CO_T && (co0 + row) < a.cout_pad;
     wp[i] = ok ? (unsigned)(((co0 + row) * a.kpad + kc * VEC) * (int)sizeof(T)) : GLS_OOB;
   }
@@ -107,8 +114,7 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const ConvArgs a, const 
     unsigned char* sa = smem + buf * A_BYTES + kc * 16;
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
-      const int row = row0 + i * 32;
-      if (row < CO_T) *reinterpret_cast<u32x4*>(sa + row * RS) = ra[i];
+      if (CO_T % 32 == 0 || arow[i] < CO_T) *reinterpret_cast<u32x4*>(sa + arow[i] * RS) = ra[i];
     }
   };
   auto load_patch = [&](int cc) __attribute__((always_inline)) {
@@ -176,7 +182,7 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const ConvArgs a, const 
       __syncthreads();                              // every wave is done with the old patch
       store_patch();
     }
-    __syncthreads();
+    if (!WP || (last_tap && more)) __syncthreads();
     if (++ts == KS) { ts = 0; ++tr; }
     if (++tap == ntaps) { tap = 0; tr = 0; ts = 0; ++cc; }
   }
@@ -258,7 +264,7 @@ static int halo_by_ks(const ConvArgs& a, hipStream_t st) {
 // Returns 1 when the halo kernel does not apply (caller falls back to the generic kernel),
 // 0 when `op` was filled in.
 int conv_halo_try(const ConvArgs& a, int xdt, int ydt, int hint, OpRecord* op) {
-  if (hint == 1 || hint > 3) return 1;                       // hint 1 / explicit tile = the generic kernel
+  if (hint == 1 || hint == 3 || hint > 4) return 1;          // hint 1 / explicit tile = the generic kernel
   if (a.stride != 1 || a.R != a.S || (a.R != 3 && a.R != 5 && a.R != 7) || a.pad != a.R / 2) return 1;
   const int es = dtype_size(xdt);
   if ((a.Cin * es) % 128) return 1;
@@ -266,12 +272,16 @@ int conv_halo_try(const ConvArgs& a, int xdt, int ydt, int hint, OpRecord* op) {
   // wasted MFMA work on partial tiles: prefer the flat-pixel kernel when it is large
   const long tiles = (long)((a.Ho + 7) / 8) * ((a.Wo + 15) / 16);
   const double waste = (double)tiles * 128.0 / ((double)a.Ho * a.Wo);
-  if (hint != 2 && waste > 1.30) return 1;                   // hint 2 = force the halo kernel
+  if (hint != 2 && hint != 4 && waste > 1.30) return 1;      // hint 2 / 4 = force the halo kernel
   const int co_t = a.cout_pad <= 64 ? 64 : 128;
+  const bool wpriv = hint == 4;                     // wave-private weight staging (128-row cout tile only)
+  if (wpriv && co_t != 128) return 1;
   char nm[96];
-  snprintf(nm, sizeof nm, "conv_halo<%s,%dx8x16> %dx%d s1 cin%d cout%d", xdt ? "f32" : "f16", co_t, a.R, a.S, a.Cin, a.Cout);
+  snprintf(nm, sizeof nm, "conv_halo%s<%s,%dx8x16> %dx%d s1 cin%d cout%d", wpriv ? "_wp" : "", xdt ? "f32" : "f16", co_t, a.R,
+           a.S, a.Cin, a.Cout);
   op->name = nm;
-  op->launch = [a, co_t, xdt](hipStream_t st) -> int {
+  op->launch = [a, co_t, xdt, wpriv](hipStream_t st) -> int {
+    if (wpriv) return xdt == GLSDET_F16 ? halo_by_ks<f16, f16, 128, 4>(a, st) : halo_by_ks<float, float, 128, 4>(a, st);
     if (xdt == GLSDET_F16) return co_t == 128 ? halo_by_ks<f16, f16, 128, 2>(a, st) : halo_by_ks<f16, f16, 64, 2>(a, st);
     return co_t == 128 ? halo_by_ks<float, float, 128, 2>(a, st) : halo_by_ks<float, float, 64, 2>(a, st);
   };

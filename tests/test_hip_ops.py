@@ -233,12 +233,14 @@ HALO_CASES = [
 
 
 @pytest.mark.parametrize("mode", ["f32", "f16"])
-@pytest.mark.parametrize("hint", [1, 2], ids=["generic", "halo"])
+@pytest.mark.parametrize("hint", [1, 2, 4], ids=["generic", "halo", "halo_wave_private"])
 @pytest.mark.parametrize("case", HALO_CASES, ids=lambda c: "ci%d_co%d_k%d_%dx%d" % c[:5])
 def test_conv_halo_and_generic_kernels_agree_with_oracle(engines, mode, hint, case):
     """the stride-1 kxk halo kernel (hint 2) and the generic implicit GEMM (hint 1) on the
     same problems, incl. partial tiles, strided views, residual"""
     cin, cout, k, H, W, use_res, embed = case
+    if hint == 4 and cout <= 64:
+        pytest.skip("the wave-private halo variant needs the 128-row cout tile")
     eng = engines[mode]
     g = torch.Generator().manual_seed(cin + cout + k + H)
     x = torch.randn(2, cin, H, W, generator=g)
