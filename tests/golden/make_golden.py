@@ -123,7 +123,35 @@ def preprocess_cases():
     print("preprocess:", len(out), "cases,", os.path.getsize(os.path.join(HERE, "preprocess_golden.npz")), "bytes")
 
 
+def ufp_boxes(trial):
+    """Seeded coarse-detection-like xyxy boxes for one image (input data of the packing goldens)."""
+    rng = np.random.default_rng([trial, 0x0F9])
+    n = int(rng.integers(1, 60))
+    W, H = int(rng.integers(400, 2000)), int(rng.integers(300, 1200))
+    c = rng.uniform(0, 1, (n, 2)) * [W, H]
+    wh = np.exp(rng.uniform(np.log(6), np.log(220), (n, 2)))
+    b = np.concatenate([c - wh / 2, c + wh / 2], 1)
+    b[:, 0::2] = np.clip(b[:, 0::2], 0, W - 1)
+    b[:, 1::2] = np.clip(b[:, 1::2], 0, H - 1)
+    return (b.astype(np.float32) if trial % 3 == 0 else b), W, H
+
+
+def ufp_cases():
+    """Rows f.1: the reference's UnifiedForegroundPacking (ufp/UFPMP-Det-Tools/ufp, pure numpy)."""
+    sys.path.insert(0, "/root/reference/yolox-ufp/UFPMP-Det-Tools")
+    from ufp import UnifiedForegroundPacking
+    out = {}
+    for trial in range(24):
+        b, W, H = ufp_boxes(trial)
+        chips, cw, ch = UnifiedForegroundPacking(b.copy(), 1.5, input_shape=[W, H])
+        out["ufp/%d/chips" % trial] = np.asarray(chips, np.float64).reshape(-1, 7)
+        out["ufp/%d/canvas" % trial] = np.asarray([cw, ch], np.float64)
+    np.savez_compressed(os.path.join(HERE, "ufp_golden.npz"), **out)
+    print("ufp:", len(out) // 2, "cases,", os.path.getsize(os.path.join(HERE, "ufp_golden.npz")), "bytes")
+
+
 def main():
+    ufp_cases()
     preprocess_cases()
     from models.base import yolox as ref_base
     from models.base.baseConv import BaseConv, DWConv
