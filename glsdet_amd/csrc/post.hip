@@ -173,7 +173,7 @@ __global__ __launch_bounds__(256) void nms_rank_kernel(int max_cand, NmsWs ws) {
 // Stored column-block major so that the scan reads 64 consecutive rows of one column block
 // as one coalesced 512-byte wave load.  The grid is fixed; each 64-thread block walks the
 // (row block, column block) pairs of the ACTUAL candidate count (known only on the device).
-__global__ __launch_bounds__(64) void nms_mask_kernel(int max_cand, int nw, float thr, NmsWs ws) {
+__global__ __launch_bounds__(64) void nms_mask_kernel(int max_cand, int nw, float thr, NmsWs ws, float one = 0.f) {
   const int b = blockIdx.y;
   const int n = min(ws.cnt[b], max_cand);
   const int nb = (n + 63) >> 6;
@@ -195,17 +195,17 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(int max_cand, int nw, floa
     if (i < n) {
       const float4 a = ws.sbox[base + i];
       const float acls = ws.sext[base + i].z;
-      const float aarea = (a.z - a.x) * (a.w - a.y);
+      const float aarea = (a.z - a.x + one) * (a.w - a.y + one);      // one = 1: the '+1' pixel-area convention
       unsigned long long bits = 0;
       const int lim = min(64, n - cb * 64);
       for (int k = 0; k < lim; ++k) {
         const int jj = cb * 64 + k;
         if (jj <= i || ccls[k] != acls) continue;
         const float4 c = cbx[k];
-        const float w = fmaxf(0.f, fminf(a.z, c.z) - fmaxf(a.x, c.x));
-        const float h = fmaxf(0.f, fminf(a.w, c.w) - fmaxf(a.y, c.y));
+        const float w = fmaxf(0.f, fminf(a.z, c.z) - fmaxf(a.x, c.x) + one);
+        const float h = fmaxf(0.f, fminf(a.w, c.w) - fmaxf(a.y, c.y) + one);
         const float inter = w * h;
-        const float iou = inter / (aarea + (c.z - c.x) * (c.w - c.y) - inter);
+        const float iou = inter / (aarea + (c.z - c.x + one) * (c.w - c.y + one) - inter);
         if (iou > thr) bits |= 1ull << k;
       }
       ws.mask[((long)b * nw + cb) * max_cand + i] = bits;
@@ -408,6 +408,41 @@ __global__ __launch_bounds__(256) void gfl_merge_kernel(int n_levels, int max_ca
   w2.cscore[dst] = ex.w;
 }
 
+// ---------------------------------------------------------------------------- UFP back-mapping
+// ufp/ufpmp_det_eval.py:282-296: a fine detection whose box lies in a chip's mosaic rectangle
+// (intersection over the smaller area > iof_thr) is mapped back through the chip's magnification
+// and offsets.  One candidate per (chip, detection) match; canchor = -(chip * max_det + det) so that,
+// for equal scores, the later entry of the reference's list ranks first (its argsort()[::-1]).
+__global__ __launch_bounds__(256) void ufp_backmap_kernel(const float* __restrict__ dets, const int* __restrict__ count,
+                                                          int max_det, const float* __restrict__ chips, int n_chips,
+                                                          float iof_thr, int max_cand, NmsWs ws, int* status) {
+  const int nd = min(count[0], max_det);
+  const long total = (long)n_chips * nd;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int k = (int)(i / nd), j = (int)(i - (long)k * nd);
+    const float* c = chips + 7 * k;
+    const float ox = floorf(c[0]), oy = floorf(c[1]), w = floorf(c[2]), h = floorf(c[3]);
+    const float nx = floorf(c[4]), ny = floorf(c[5]), s = floorf(c[6]);
+    const float* d = dets + (long)j * 7;
+    const float rx2 = nx + w * s, ry2 = ny + h * s;
+    const float l = fmaxf(d[0], nx), t = fmaxf(d[1], ny), r = fminf(d[2], rx2), b = fminf(d[3], ry2);
+    if (l >= r || t >= b) continue;
+    const float iof = (r - l) * (b - t) / fminf((d[2] - d[0]) * (d[3] - d[1]), (rx2 - nx) * (ry2 - ny));
+    if (!(iof > iof_thr)) continue;
+    const int slot = atomicAdd(&ws.cnt[0], 1);
+    if (slot >= max_cand) {
+      atomicOr(status, 1);
+      continue;
+    }
+    const float bw = (d[2] - d[0]) / s, bh = (d[3] - d[1]) / s;
+    const float bx = (d[0] - nx) / s + ox, by = (d[1] - ny) / s + oy;
+    ws.cbox[slot] = make_float4(bx, by, bx + bw, by + bh);
+    ws.cext[slot] = make_float4(d[4], d[5], d[6], d[4]);
+    ws.canchor[slot] = -(k * max_det + j);
+    ws.cscore[slot] = d[4];
+  }
+}
+
 static inline long align_up(long v, long a) { return (v + a - 1) / a * a; }
 static long nms_layout(int n, int max_cand, NmsWs* ws, char* base, bool with_mask = true) {
   const int nw = (max_cand + 63) / 64;
@@ -579,6 +614,46 @@ extern "C" int glsdet_gfl_detect(const glsdet_view* cls, const glsdet_view* reg,
     hipLaunchKernelGGL(nms_rank_kernel, dim3((max_cand2 + 63) / 64, n), dim3(256), 0, st, max_cand2, w2);
     hipLaunchKernelGGL(nms_mask_kernel, dim3(2048, n), dim3(64), 0, st, max_cand2, nw2, iou_thr, w2);
     hipLaunchKernelGGL(nms_scan_kernel, dim3(n), dim3(1024), 0, st, max_cand2, nw2, max_det, w2, dets, count);
+    GLS_HIP(hipGetLastError());
+    return 0;
+  };
+  return submit(std::move(op), stream);
+}
+
+extern "C" int64_t glsdet_ufp_merge_workspace_bytes(int32_t max_cand) {
+  if (max_cand < 1) return 0;
+  return nms_layout(1, max_cand, nullptr, nullptr, true);
+}
+
+extern "C" int glsdet_ufp_backmap_merge(const float* dets, const int32_t* count, int32_t max_det, const float* chips,
+                                        int32_t n_chips, float iof_thr, float nms_thr, int32_t max_cand, int32_t max_out,
+                                        float* out, int32_t* out_count, int32_t* status, void* wsp, int64_t ws_bytes,
+                                        void* stream) {
+  if (!dets || !count || !out || !out_count || !status || !wsp || (n_chips > 0 && !chips))
+    GLS_FAIL(GLSDET_E_ARG, "ufp_backmap_merge: null argument");
+  if (max_det < 1 || n_chips < 0 || max_cand < 1 || max_out < 1 || max_cand > GLS_NMS_MAXW * 64)
+    GLS_FAIL(GLSDET_E_ARG, "ufp_backmap_merge: bad sizes");
+  if ((uintptr_t)wsp & 255) GLS_FAIL(GLSDET_E_ALIGN, "ufp_backmap_merge: workspace must be 256-byte aligned");
+  NmsWs ws;
+  const long need = nms_layout(1, max_cand, &ws, (char*)wsp, true);
+  if (ws_bytes < need) GLS_FAIL(GLSDET_E_CAPACITY, "ufp_backmap_merge: workspace %ld < %ld bytes", (long)ws_bytes, need);
+  const int nw = (max_cand + 63) / 64;
+  OpRecord op;
+  op.kind = 6;
+  op.flops = 0;
+  op.bytes = 28.0 * max_det * (n_chips > 0 ? n_chips : 1);
+  op.name = "ufp_backmap+merge_nms";
+  op.launch = [=](hipStream_t st) -> int {
+    hipLaunchKernelGGL(reset_counters_kernel, dim3(1), dim3(256), 0, st, ws.cnt, 1, status);
+    if (n_chips > 0) {
+      long g = ((long)n_chips * max_det + 255) / 256;
+      if (g > 4096) g = 4096;
+      hipLaunchKernelGGL(ufp_backmap_kernel, dim3((unsigned)g), dim3(256), 0, st, dets, count, max_det, chips, n_chips, iof_thr,
+                         max_cand, ws, status);
+    }
+    hipLaunchKernelGGL(nms_rank_kernel, dim3((max_cand + 63) / 64, 1), dim3(256), 0, st, max_cand, ws);
+    hipLaunchKernelGGL(nms_mask_kernel, dim3(2048, 1), dim3(64), 0, st, max_cand, nw, nms_thr, ws, 1.0f);
+    hipLaunchKernelGGL(nms_scan_kernel, dim3(1), dim3(1024), 0, st, max_cand, nw, max_out, ws, out, out_count);
     GLS_HIP(hipGetLastError());
     return 0;
   };

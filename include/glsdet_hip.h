@@ -269,6 +269,31 @@ int glsdet_pil_resize_normalize(const unsigned char* src, int32_t in_h, int32_t 
                                 void* stream);
 
 /* ---------------------------------------------------------------------------------
+ * UFPMP-Det second stage (ufp/ufpmp_det_eval.py)
+ * --------------------------------------------------------------------------------- */
+/* display_merge_result (:182-193): chips = device fp32 [n_chips][7] = src_x, src_y, w, h, canvas_x,
+ * canvas_y, magnification (floored like the reference); img: device uint8 [H][W][3] (BGR as cv2 reads
+ * it); canvas: device fp32 [ch][cw][3], zero outside the chips.  Crops are magnified with cv2.resize's
+ * uint8 INTER_LINEAR arithmetic (11-bit fixed point), restated -- cv2 is not available to pin it. */
+int glsdet_ufp_mosaic(const unsigned char* img, int32_t H, int32_t W, const float* chips, int32_t n_chips,
+                      float* canvas, int32_t ch, int32_t cw, void* stream);
+/* mmdet test pipeline on an fp32 HWC BGR image: bilinear resize to nh x nw (half-pixel centres, edge
+ * clamp), BGR->RGB, (v - mean) * (1/std), zero padding to ph x pw, HWC->CHW
+ * (mmdet/datasets/pipelines/transforms.py:30,671,572).  mean/std: host double[3], RGB order.      */
+int glsdet_resize_normalize_pad(const float* src, int32_t h, int32_t w, int32_t nh, int32_t nw, float* dst,
+                                int32_t ph, int32_t pw, const double* mean_rgb, const double* std_rgb, void* stream);
+/* back-mapping + merge NMS (:282-300): dets = the fine detector's rows [max_det][7] (x1,y1,x2,y2,
+ * score,score,label) with their count on the device; a row inside a chip's mosaic rectangle (IoF >
+ * iof_thr) is mapped to source-image coordinates; per class greedy NMS with '+1' areas, a box
+ * survives while IoU <= nms_thr (py_cpu_nms :149-178).  out: [max_out][7] in descending score
+ * order, out_count int32[2] (kept clamped / unclamped), status bit0 = more than max_cand matches. */
+int64_t glsdet_ufp_merge_workspace_bytes(int32_t max_cand);
+int glsdet_ufp_backmap_merge(const float* dets, const int32_t* count, int32_t max_det, const float* chips,
+                             int32_t n_chips, float iof_thr, float nms_thr, int32_t max_cand, int32_t max_out,
+                             float* out, int32_t* out_count, int32_t* status, void* ws, int64_t ws_bytes,
+                             void* stream);
+
+/* ---------------------------------------------------------------------------------
  * Plan: a recorded sequence of the calls above, replayed without Python in the loop and
  * capturable into one hipGraph (HIP streams + graphs instead of a tracing compiler).
  * Recording: glsdet_plan_begin(plan) makes every following entry-point call on this
