@@ -104,9 +104,7 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const ConvArgs a, const 
   const int ntaps = KS * KS;
   const int nsteps = nchunks * ntaps;
 
-  auto load_a = [&](int step) __attribute__((always_inline)) {
-    const int cc = step / ntaps, tap = step - cc * ntaps;
-    const unsigned kbyte = (unsigned)((tap * a.Cin + cc * KE) * (int)sizeof(T));
+  auto load_a = [&](unsigned kbyte) __attribute__((always_inline)) {      // kbyte: wave-uniform byte offset of the tap's weights
 #pragma unroll
     for (int i = 0; i < NA; ++i) ra[i] = gls_buf_load16(wrs, wp[i] + kbyte);
   };
@@ -151,20 +149,20 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const ConvArgs a, const 
   }
 
   load_patch(0);
-  load_a(0);
+  load_a(0u);
   store_patch();
   store_a(0);
   __syncthreads();
 
-  int tap = 0, cc = 0, tr = 0, ts = 0;             // tap = tr*KS + ts
-  for (int t = 0; t < nsteps; ++t) {
-    const int cur = t & 1;
-    const bool last_tap = tap == ntaps - 1;
-    const bool more = t + 1 < nsteps;
-    if (more) load_a(t + 1);
-    if (last_tap && more) load_patch(cc + 1);
+  // The K loop is written for a SHORT instruction stream per tap -- measured: with one wave per SIMD
+  // every scalar instruction and, above all, every branch of the loop body delays the next MFMA issue
+  // (the empty loop cost 27 % of the 7x7 layer).  Nest: channel chunk / tap; the weight offset of the
+  // next tap is the current one plus Cin elements; the last tap of a chunk -- the only place where the
+  // patch is exchanged -- is peeled, so the common body has no data-dependent branch at all.
+  const unsigned tap_stride = (unsigned)(a.Cin * (int)sizeof(T));
+  int cur = 0;
+  auto mma_tap = [&](int tap_off) __attribute__((always_inline)) {
     const unsigned char* sA = smem + cur * A_BYTES;
-    const int tap_off = (tr * PW + ts) * RS;
 #pragma unroll
     for (int kk = 0; kk < KB / 32; ++kk) {
       u32x4 af[TM], bf[TN];
@@ -177,14 +175,33 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const ConvArgs a, const 
 #pragma unroll
         for (int j = 0; j < TN; ++j) MMA<T>::run(af[i], bf[j], acc[i][j]);
     }
-    if (more) store_a(cur ^ 1);
-    if (last_tap && more) {
-      __syncthreads();                              // every wave is done with the old patch
-      store_patch();
+  };
+  for (int cc = 0; cc < nchunks; ++cc) {
+    unsigned kbyte = (unsigned)(cc * KE * (int)sizeof(T));
+    int tap_off = 0, ts = 0;
+    for (int tap = 0; tap < ntaps - 1; ++tap) {       // every tap but the chunk's last
+      kbyte += tap_stride;
+      load_a(kbyte);
+      mma_tap(tap_off);
+      store_a(cur ^ 1);
+      if (!WP) __syncthreads();
+      cur ^= 1;
+      ++ts;
+      tap_off += (ts == KS) ? (PW - KS + 1) * RS : RS;
+      ts = (ts == KS) ? 0 : ts;
     }
-    if (!WP || (last_tap && more)) __syncthreads();
-    if (++ts == KS) { ts = 0; ++tr; }
-    if (++tap == ntaps) { tap = 0; tr = 0; ts = 0; ++cc; }
+    if (cc + 1 < nchunks) {                           // last tap, another chunk follows
+      load_a((unsigned)((cc + 1) * KE * (int)sizeof(T)));
+      load_patch(cc + 1);
+      mma_tap(tap_off);
+      store_a(cur ^ 1);
+      __syncthreads();                                // every wave is done with the old patch
+      store_patch();
+      __syncthreads();
+      cur ^= 1;
+    } else {
+      mma_tap(tap_off);
+    }
   }
 
   // ---- epilogue (as conv.hip; tile-local pixel -> (oy, ox))
