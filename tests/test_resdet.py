@@ -460,3 +460,31 @@ def test_surface_call_flow_vs_oracle(cfg):
             for row in strong:
                 assert len(r[c]) and np.min(np.abs(r[c][:, :4] - row[:4]).max(1)) < 0.05, (c, row)
     assert total > 0
+
+
+@pytest.mark.gpu
+def test_two_gfl_graph_instances_in_flight_replay_bit_identically():
+    """As tests/test_hip_model.py's replay test, for the GFL post-processing (own counter reset, no
+    memset nodes): two captured plans replayed concurrently reproduce their first result every time."""
+    from glsdet_amd.resdet import HipGflDetector
+    x = O.synth_input((2, 3, 256, 320), 4)
+    sd = calibrated_resdet_sd("gfl", 5, O.synth_input((1, 3, 128, 160), 100))
+    det = HipGflDetector("gfl", sd, dtype="f16")
+    cls, _ = det.forward_raw(x.cuda())
+    p = torch.sigmoid(torch.cat([c.flatten() for c in cls]))
+    post = dict(score_thr=float(torch.topk(p, 3000).values[-1]), iou_thr=0.6, nms_pre=1000, max_per_img=100)
+    cs = [det.compile(2, 256, 320, post, use_graph=True, instance=i) for i in range(2)]
+    for c in cs:
+        c.img.copy_(x.cuda())
+    torch.cuda.synchronize()
+    ref = {}
+    for step in range(40):
+        for c in cs:
+            HipGflDetector.run_async(c)
+        torch.cuda.synchronize()
+        for i, c in enumerate(cs):
+            assert int(c.nb["status"].item()) == 0
+            cur = (c.nb["count"].clone(), c.nb["dets"].clone())
+            r = ref.setdefault(i, cur)
+            assert torch.equal(cur[0], r[0]) and torch.equal(cur[1], r[1]), "step %d instance %d differs" % (step, i)
+    assert int(ref[0][0][0]) > 0
