@@ -281,7 +281,7 @@ static int halo_by_ks(const ConvArgs& a, hipStream_t st) {
 // Returns 1 when the halo kernel does not apply (caller falls back to the generic kernel),
 // 0 when `op` was filled in.
 int conv_halo_try(const ConvArgs& a, int xdt, int ydt, int hint, OpRecord* op) {
-  if (hint == 1 || hint == 3 || hint > 4) return 1;          // hint 1 / explicit tile = the generic kernel
+  if (hint == 1 || hint == 3 || hint > 5) return 1;          // hint 1 / explicit tile = the generic kernel
   if (a.stride != 1 || a.R != a.S || (a.R != 3 && a.R != 5 && a.R != 7) || a.pad != a.R / 2) return 1;
   const int es = dtype_size(xdt);
   if ((a.Cin * es) % 128) return 1;
@@ -289,8 +289,8 @@ int conv_halo_try(const ConvArgs& a, int xdt, int ydt, int hint, OpRecord* op) {
   // wasted MFMA work on partial tiles: prefer the flat-pixel kernel when it is large
   const long tiles = (long)((a.Ho + 7) / 8) * ((a.Wo + 15) / 16);
   const double waste = (double)tiles * 128.0 / ((double)a.Ho * a.Wo);
-  if (hint != 2 && hint != 4 && waste > 1.30) return 1;      // hint 2 / 4 = force the halo kernel
-  const int co_t = a.cout_pad <= 64 ? 64 : 128;
+  if (hint != 2 && hint != 4 && hint != 5 && waste > 1.30) return 1;      // hint 2 / 4 / 5 = force the halo kernel
+  const int co_t = (a.cout_pad <= 64 || hint == 5) ? 64 : 128;     // hint 5: 64-row cout tiles also for wide layers
   const bool wpriv = hint == 4;                     // wave-private weight staging (128-row cout tile only)
   if (wpriv && co_t != 128) return 1;
   char nm[96];

@@ -83,7 +83,7 @@ typedef struct glsdet_conv_desc {
   const float* scale;
   const float* bias;
   int32_t R, S, stride, pad, act;
-  int32_t tile_hint;       /* 0 auto | 1 generic | 2 halo (s1 kxk) | 4 halo, wave-private weights | 3 weight-stationary 1x1 | co_tile<<16|px_tile */
+  int32_t tile_hint;       /* 0 auto | 1 generic | 2 halo (s1 kxk) | 4 halo, wave-private weights | 5 halo, 64-row cout tiles | 3 weight-stationary 1x1 | co_tile<<16|px_tile */
 } glsdet_conv_desc;
 
 int     glsdet_conv2d(const glsdet_conv_desc* d, void* stream);

@@ -233,7 +233,7 @@ HALO_CASES = [
 
 
 @pytest.mark.parametrize("mode", ["f32", "f16"])
-@pytest.mark.parametrize("hint", [1, 2, 4], ids=["generic", "halo", "halo_wave_private"])
+@pytest.mark.parametrize("hint", [1, 2, 4, 5], ids=["generic", "halo", "halo_wave_private", "halo_co64"])
 @pytest.mark.parametrize("case", HALO_CASES, ids=lambda c: "ci%d_co%d_k%d_%dx%d" % c[:5])
 def test_conv_halo_and_generic_kernels_agree_with_oracle(engines, mode, hint, case):
     """the stride-1 kxk halo kernel (hint 2) and the generic implicit GEMM (hint 1) on the
