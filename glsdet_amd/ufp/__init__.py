@@ -2,4 +2,4 @@
 packing of the coarse detections, mosaic compositing on the device, back-mapping and merge NMS of
 the fine detections."""
 from .packing import unified_foreground_packing  # noqa: F401
-from .stage2 import UfpSecondStage, two_stage_detect  # noqa: F401,E402
+from .stage2 import TwoStagePipeline, UfpSecondStage, two_stage_detect  # noqa: F401,E402

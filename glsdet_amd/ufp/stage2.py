@@ -119,3 +119,84 @@ def two_stage_detect(coarse, fine, img_bgr_u8, stage: UfpSecondStage, coarse_cfg
              torch.tensor(m2["scale_factor"].reshape(1, 4), device=stage.device))
     merged = stage.merge(c.nb["dets"][0], c.nb["count"], chips, fine.num_classes)
     return merged, dict(chips=chips, canvas=canvas, first=first, fine_compiled=c, meta2=m2, canvas_wh=(cw, ch))
+
+
+class TwoStagePipeline:
+    """BASELINE config 5: coarse and fine detector pipelined on separate HIP streams.  Two host
+    threads, each with its own stream: one runs preprocessing + coarse detector + packing for frame
+    i+1 while the other runs mosaic + fine detector + merge for frame i (the host waits of a stage
+    release the GIL, the recorded plans are per thread)."""
+
+    def __init__(self, coarse, fine, stage: UfpSecondStage, coarse_cfg: dict, fine_cfg: dict, expand: float = 1.5,
+                 depth: int = 2):
+        self.coarse, self.fine, self.stage = coarse, fine, stage
+        self.coarse_cfg, self.fine_cfg, self.expand, self.depth = coarse_cfg, fine_cfg, expand, depth
+
+    def _first(self, img_bgr_u8):
+        st = self.stage
+        img = torch.as_tensor(np.ascontiguousarray(img_bgr_u8)).to(st.device)
+        H, W = int(img.shape[0]), int(img.shape[1])
+        x1, m1 = st.pipeline_input(img.float().contiguous())
+        first = self.coarse.detect(x1, img_shapes=[m1["img_shape"]], scale_factors=[m1["scale_factor"]], **self.coarse_cfg)[0]
+        order = np.argsort(first[1], kind="stable")
+        boxes = first[0][order][:, :4]
+        if len(boxes) == 0:
+            return img, None
+        return img, unified_foreground_packing(boxes.copy(), self.expand, [W, H])
+
+    def _second(self, img, packed):
+        st, fine = self.stage, self.fine
+        if packed is None:
+            return [np.zeros((0, 5)) for _ in range(fine.num_classes)]
+        chips, cw, ch = packed
+        x2, m2 = st.pipeline_input(st.mosaic(img, chips, cw, ch))
+        fc = self.fine_cfg
+        post = dict(score_thr=fc["score_thr"], iou_thr=fc["iou_thr"], nms_pre=fc.get("nms_pre", 1000),
+                    max_per_img=fc.get("max_per_img", 500), rescale=True)
+        c = fine.compile(1, x2.shape[2], x2.shape[3], post)
+        fine.run(c, x2, torch.tensor([[m2["img_shape"][0], m2["img_shape"][1]]], dtype=torch.float32, device=st.device),
+                 torch.tensor(m2["scale_factor"].reshape(1, 4), device=st.device))
+        return st.merge(c.nb["dets"][0], c.nb["count"], chips, fine.num_classes)
+
+    def run(self, images: Sequence) -> List[List[np.ndarray]]:
+        import queue
+        import threading
+        q: "queue.Queue" = queue.Queue(maxsize=self.depth)
+        results: List = [None] * len(images)
+        errors: List[BaseException] = []
+        dev = self.stage.device
+
+        def producer():
+            try:
+                with torch.cuda.stream(torch.cuda.Stream(device=dev)):
+                    for i, im in enumerate(images):
+                        item = self._first(im)
+                        torch.cuda.current_stream().synchronize()
+                        q.put((i,) + item)
+            except BaseException as e:          # noqa: BLE001 - re-raised in the caller's thread
+                errors.append(e)
+            finally:
+                q.put(None)
+
+        def consumer():
+            try:
+                with torch.cuda.stream(torch.cuda.Stream(device=dev)):
+                    while True:
+                        item = q.get()
+                        if item is None:
+                            return
+                        i, img, packed = item
+                        results[i] = self._second(img, packed)
+            except BaseException as e:          # noqa: BLE001
+                errors.append(e)
+                while q.get() is not None:      # drain so that the producer can finish
+                    pass
+
+        ts = [threading.Thread(target=producer), threading.Thread(target=consumer)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        if errors:
+            raise errors[0]
+        return results

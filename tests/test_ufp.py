@@ -159,7 +159,7 @@ def test_two_stage_pipeline_runs_end_to_end():
     import torch
     from glsdet_amd.resdet import HipGflDetector
     from glsdet_amd.synth import synth_input, synth_resdet_state_dict
-    from glsdet_amd.ufp import UfpSecondStage, two_stage_detect
+    from glsdet_amd.ufp import TwoStagePipeline, UfpSecondStage, two_stage_detect
     from oracle import ufp_oracle as U
     from tests.test_preprocess import synth_image
     img = synth_image((270, 480), 2)[:, :, ::-1].copy()
@@ -195,3 +195,11 @@ def test_two_stage_pipeline_runs_end_to_end():
             np.testing.assert_allclose(merged[cc], want[cc], rtol=1e-4, atol=1e-2)
         for r in merged[cc]:
             assert -1 <= r[0] <= 480 and -1 <= r[1] <= 270
+    # the two-stream pipeline (coarse of frame i+1 beside fine of frame i) returns the same detections
+    c1 = dict(score_thr=t1, iou_thr=0.6, nms_pre=1000, max_per_img=40)
+    c2 = dict(score_thr=t2, iou_thr=0.6, nms_pre=1000, max_per_img=300)
+    frames = [img, synth_image((270, 480), 3)[:, :, ::-1].copy(), img]
+    seq = [two_stage_detect(coarse, fine, f, stage, c1, c2)[0] for f in frames]
+    par = TwoStagePipeline(coarse, fine, stage, c1, c2).run(frames)
+    for a, b in zip(seq, par):
+        assert all(np.array_equal(x, y) for x, y in zip(a, b))

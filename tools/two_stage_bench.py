@@ -8,7 +8,7 @@ import numpy as np
 import torch
 from glsdet_amd.resdet import HipGflDetector
 from glsdet_amd.synth import synth_input, synth_resdet_state_dict
-from glsdet_amd.ufp import UfpSecondStage, two_stage_detect
+from glsdet_amd.ufp import TwoStagePipeline, UfpSecondStage, two_stage_detect
 from glsdet_amd.ufp.packing import unified_foreground_packing
 from tests.test_preprocess import synth_image
 
@@ -48,3 +48,19 @@ print("two-stage, one 540x1024 frame: %.2f ms end to end (%.1f frames/s); host p
       "%d chips, mosaic %dx%d, fine input %s, %d merged detections"
       % (dt * 1e3, 1 / dt, len(boxes), tp * 1e3, len(mid["chips"]), mid["canvas"].shape[1], mid["canvas"].shape[0],
          tuple(x2.shape), sum(len(m) for m in merged)))
+
+frames = [synth_image((540, 1024), 100 + i)[:, :, ::-1].copy() for i in range(8)] * 4
+pipe = TwoStagePipeline(coarse, fine, stage, c1, c2)
+pipe.run(frames[:8])                        # warm: plans for the mosaic shapes of these frames
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+seq = [two_stage_detect(coarse, fine, f, stage, c1, c2)[0] for f in frames]
+torch.cuda.synchronize()
+t_seq = time.perf_counter() - t0
+t0 = time.perf_counter()
+out = pipe.run(frames)
+torch.cuda.synchronize()
+t_pipe = time.perf_counter() - t0
+same = all(all(np.array_equal(a, b) for a, b in zip(x, y)) for x, y in zip(seq, out))
+print("32 frames: sequential %.1f frames/s, two-stream pipeline %.1f frames/s, identical results: %s"
+      % (len(frames) / t_seq, len(frames) / t_pipe, same))
