@@ -16,6 +16,13 @@ from ..arch import state_dict_shapes
 from ..detector import HipDetector
 
 
+def _autotune() -> bool:
+    """Kernel variants are measured per conv problem when a plan is first built for an input shape (a few
+    seconds, +6 % throughput); GLSDET_AUTOTUNE=0 switches to the size heuristic."""
+    import os
+    return os.environ.get("GLSDET_AUTOTUNE", "1") != "0"
+
+
 class RawOutputs(list):
     """list of [B, 5+nc, H_l, W_l] logits (what the reference returns) that also keeps the
     native NHWC fp32 level views, so `decode_outputs` can consume them without a round trip."""
@@ -104,7 +111,7 @@ class HipYoloBody(TableModule):
         if self.training:
             raise NotImplementedError("glsdet_amd implements the inference forward only: call .eval()")
         if self._det is None:
-            self._det = HipDetector(self.kind, self.state_dict(), dtype=self.hip_dtype)
+            self._det = HipDetector(self.kind, self.state_dict(), dtype=self.hip_dtype, autotune=_autotune())
         det = self._det
         x = x.to("cuda", torch.float32)
         n, _, H, W = x.shape

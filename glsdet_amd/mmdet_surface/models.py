@@ -21,7 +21,7 @@ import torch.nn as nn
 
 from ..arch import _Table
 from ..detector import HipDetector
-from ..drone.body import TableModule
+from ..drone.body import TableModule, _autotune
 from .registry import BACKBONES, DETECTORS, HEADS, NECKS, ConfigDict, build_backbone, build_head, build_neck
 
 # ----------------------------------------------------------------------------- name map
@@ -261,7 +261,7 @@ class YOLOX(nn.Module):
     def _detector(self) -> HipDetector:
         if self._det is None:
             sd = OrderedDict((mmdet_to_drone_key(k), v) for k, v in self.state_dict().items())
-            self._det = HipDetector("gl" if getattr(self.neck, "gl", False) else "base", sd, dtype=self.hip_dtype)
+            self._det = HipDetector("gl" if getattr(self.neck, "gl", False) else "base", sd, dtype=self.hip_dtype, autotune=_autotune())
         return self._det
 
     # ---- call convention of BaseDetector.forward (ufp/mmdet/models/detectors/base.py:157-175)

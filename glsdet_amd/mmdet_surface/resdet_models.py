@@ -17,7 +17,7 @@ import torch
 import torch.nn as nn
 
 from ..arch import _Table, fpn_table, gfl_head_table, mp_head_table, resnet_table, RESNET_STAGE_BLOCKS
-from ..drone.body import TableModule
+from ..drone.body import TableModule, _autotune
 from ..resdet import HipGflDetector
 from .registry import BACKBONES, DETECTORS, HEADS, NECKS, ConfigDict, build_backbone, build_head, build_neck
 
@@ -198,7 +198,7 @@ class SingleStageDetector(nn.Module):
                        out_indices=self.backbone.out_indices)
             if kind == "mpdet":
                 cfg.update(proxies_list=tuple(h.proxies_list), gamma=float(h.gamma))
-            self._det = HipGflDetector(kind, self.state_dict(), dtype=self.hip_dtype, **cfg)
+            self._det = HipGflDetector(kind, self.state_dict(), dtype=self.hip_dtype, autotune=_autotune(), **cfg)
         return self._det
 
     def forward(self, img, img_metas, return_loss=True, **kwargs):
