@@ -1,0 +1,70 @@
+"""Randomised (fixed seed) sweep of glsdet_conv2d over shapes, strides, kernel sizes, views, residual
+modes and EVERY kernel variant that accepts the problem, against torch's CPU conv: catches
+tile-boundary / padding / variant-dispatch mistakes the hand-picked cases miss."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import glsdet_oracle as O
+from tests.test_hip_ops import TOL, _cmp, _to_view
+
+pytestmark = pytest.mark.gpu
+
+HINTS = [0, 1, 2, 3, 4, 5, (128 << 16) | 128, (64 << 16) | 128, (64 << 16) | 64, (32 << 16) | 128,
+         (64 << 16) | 64 | 0x8000, (128 << 16) | 128 | 0x8000]
+
+
+def _cases(n, seed):
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(n):
+        k = int(rng.choice([1, 1, 3, 3, 3, 5, 7]))
+        stride = int(rng.choice([1, 1, 1, 2]))
+        cin = int(rng.choice([8, 16, 24, 32, 64, 72, 128, 136]))
+        cout = int(rng.choice([8, 16, 40, 64, 96, 128, 136, 200]))
+        h, w = int(rng.integers(k, 44)), int(rng.integers(k, 44))
+        n_img = int(rng.choice([1, 2, 3]))
+        act = str(rng.choice(["silu", "relu", "lrelu", "none", "gelu", "sigmoid"]))
+        res = int(rng.choice([0, 0, 1, 2]))            # 0 none, 1 act-then-add, 2 add-then-act
+        embed = bool(rng.integers(0, 2))
+        out.append((n_img, cin, cout, k, stride, h, w, act, res, embed))
+    return out
+
+
+@pytest.fixture(scope="module")
+def engines():
+    from glsdet_amd.engine import Engine
+    return {"f32": Engine("f32"), "f16": Engine("f16")}
+
+
+@pytest.mark.parametrize("mode", ["f16", "f32"])
+@pytest.mark.parametrize("case", _cases(40, 7), ids=lambda c: "n%d_ci%d_co%d_k%d_s%d_%dx%d_%s_r%d_e%d" % c)
+def test_conv2d_random_problem_all_variants(engines, mode, case):
+    from glsdet_amd._lib import GlsdetError
+    n_img, cin, cout, k, stride, h, w, act, res, embed = case
+    eng = engines[mode]
+    import zlib
+    g = torch.Generator().manual_seed(zlib.crc32(repr(case).encode()))
+    x = torch.randn(n_img, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, k, k, generator=g) / np.sqrt(cin * k * k)
+    scale, bias = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.3
+    r = (lambda t: t.half().float()) if mode == "f16" else (lambda t: t)
+    pre = F.conv2d(r(x), r(wt), None, stride, k // 2) * scale[None, :, None, None] + bias[None, :, None, None]
+    act_fn = lambda t: F.gelu(t) if act == "gelu" else (torch.sigmoid(t) if act == "sigmoid" else O._act(t, act))
+    rt = torch.randn(pre.shape, generator=g) if res else None
+    ref = act_fn(pre) if res == 0 else (act_fn(pre) + r(rt) if res == 1 else act_fn(pre + r(rt)))
+    pk = eng.pack_conv([(wt, scale, bias)], cin)
+    ran = 0
+    for hint in HINTS:
+        xv = _to_view(eng, x, embed=(cin + 16, 8) if embed else None)
+        rv = _to_view(eng, rt) if res else None
+        try:
+            out = eng.conv(xv, pk, stride, k // 2, act, res=rv, tile_hint=hint, res_first=(res == 2))
+        except GlsdetError:
+            assert hint != 0 and hint != 1, "the automatic choice and the generic kernel must accept every problem"
+            continue
+        torch.cuda.synchronize()
+        _cmp(out.to_nchw(cout), ref, TOL[mode] * (2 if act in ("gelu", "sigmoid") else 1), "hint %x" % hint)
+        ran += 1
+    assert ran >= 2
