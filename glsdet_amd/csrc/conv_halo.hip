@@ -204,6 +204,10 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const ConvArgs a, const 
     }
   }
 
+  // the epilogue stages the output tile in the LDS bytes the weight tiles and the patch occupy: no wave may
+  // start it while another still reads its last fragments (without the per-tap barrier of the shared-weight
+  // form nothing else orders them)
+  __syncthreads();
   // ---- epilogue (as conv.hip; tile-local pixel -> (oy, ox))
   constexpr int ORS = CO_T * (int)sizeof(TO) + 16;
 #pragma unroll

@@ -215,6 +215,12 @@ class Engine:
                 self._tuned[key] = best.value
                 self._tune_dirty = True
             d.tile_hint = self._tuned[key]
+        forced = os.environ.get("GLSDET_FORCE_HINT")          # verification runs (tools/variant_check.py): every conv
+        if forced and tile_hint == 0:                          # uses this variant wherever it accepts the problem
+            d.tile_hint = int(forced, 0)
+            if self.lib.glsdet_conv2d(C.byref(d), _stream_ptr(self.stream)) == 0:
+                return out
+            d.tile_hint = 0
         check(self.lib.glsdet_conv2d(C.byref(d), _stream_ptr(self.stream)), "conv2d")
         return out
 
@@ -237,6 +243,12 @@ class Engine:
             d.res = ress[i].as_c() if ress[i] is not None else View()
             d.w, d.scale, d.bias = wdev.data_ptr(), sdev.data_ptr(), bdev.data_ptr()
             d.R, d.S, d.stride, d.pad, d.act, d.tile_hint = R, S, stride, pad, ACT[act], tile_hint
+        forced = os.environ.get("GLSDET_FORCE_MULTI_HINT")
+        if forced and tile_hint == 0:
+            arr[0].tile_hint = int(forced, 0)
+            if self.lib.glsdet_conv2d_multi(arr, n, _stream_ptr(self.stream)) == 0:
+                return outs
+            arr[0].tile_hint = 0
         check(self.lib.glsdet_conv2d_multi(arr, n, _stream_ptr(self.stream)), "conv2d_multi")
         return outs
 

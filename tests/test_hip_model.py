@@ -332,3 +332,20 @@ def test_two_graph_instances_in_flight_replay_bit_identically(golden, shapes):
             r = ref.setdefault(i, cur)
             assert torch.equal(cur[0], r[0]) and torch.equal(cur[1], r[1]), "step %d instance %d differs" % (step, i)
     assert int(ref[0][0][:4].sum()) > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("workload", ["yolox_s_glfusion_1344x800_bs8", "mp_det_res50_1344x800_bs8"])
+def test_every_conv_variant_agrees_on_the_benchmark_shapes(workload):
+    """Each kernel variant forced over every conv of the benchmark detector that it accepts, at the
+    benchmark's own size: the logits stay within fp16 rounding of the default selection.  (Regression: the
+    wave-private halo kernel entered its LDS-staged epilogue without a barrier -- wrong only on the long
+    5x5 / 7x7 loops of the GL-fusion neck at full size, where the free-running waves drift far apart.)"""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location(
+        "variant_check", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "variant_check.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    lines = []
+    assert mod.check([workload], lines.append) == 0, "\n".join(lines)
