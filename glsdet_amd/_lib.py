@@ -9,7 +9,7 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "lib", "libglsdet_hip.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 F16, F32 = 0, 1
 ACT = {"none": 0, "silu": 1, "relu": 2, "lrelu": 3, "gelu": 4, "sigmoid": 5}
@@ -89,6 +89,10 @@ _SIGS = {
     "glsdet_ufp_backmap_merge": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_float, C.c_float,
                                            C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                            C.c_void_p]),
+    "glsdet_coco_match": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                    C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32,
+                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                    C.c_void_p]),
     "glsdet_plan_create": (C.c_void_p, []),
     "glsdet_plan_destroy": (None, [C.c_void_p]),
     "glsdet_plan_begin": (C.c_int, [C.c_void_p]),

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GLSDET_ABI_VERSION 3
+#define GLSDET_ABI_VERSION 4
 
 enum { GLSDET_F16 = 0, GLSDET_F32 = 1 };
 enum { GLSDET_ACT_NONE = 0, GLSDET_ACT_SILU = 1, GLSDET_ACT_RELU = 2, GLSDET_ACT_LRELU = 3,
@@ -292,6 +292,31 @@ int glsdet_ufp_backmap_merge(const float* dets, const int32_t* count, int32_t ma
                              int32_t n_chips, float iof_thr, float nms_thr, int32_t max_cand, int32_t max_out,
                              float* out, int32_t* out_count, int32_t* status, void* ws, int64_t ws_bytes,
                              void* stream);
+
+/* ---------------------------------------------------------------------------------
+ * bbox COCOeval: COCOeval.computeIoU + evaluateImg
+ * (drone/models/core/cocoeval.py:163-190, 235-313; the protocol ufp/ufpmp_det_eval.py:333-338 runs
+ * through pycocotools) for n_pairs (image, category) pairs in one call, all in fp64.
+ *   dt_box [n_dt][4] x,y,w,h / dt_area [n_dt]: the pair's detections contiguous, in descending
+ *       score order (stable), cut to the largest maxDets; dt_off int32 [n_pairs+1]
+ *   gt_box [n_gt][4] / gt_area [n_gt] / gt_flags u8 [n_gt] (bit0 iscrowd, bit1 ignore, bit2 the
+ *       annotation id is 0 -- the reference tests `dtm == 0` on stored ids); gt_off [n_pairs+1]
+ *   iou_off int64 [n_pairs+1]: start of the pair's [D][G] block in `ious` (cumulative D*G)
+ *   area_rng fp64 [n_area][2]; iou_thr fp64 [n_thr]
+ * out (device, caller allocated; nothing needs clearing):
+ *   ious       fp64 [iou_off[n_pairs]]   IoU, ground truths in annotation order (computeIoU)
+ *   gt_order   int32 [n_area][n_gt]      position -> index inside the pair, ignored last (stable)
+ *   gt_ignore  u8    [n_area][n_gt]      gtIgnore by position
+ *   n_regular  int32 [n_area][n_pairs]   ground truths not ignored
+ *   dt_match   int32 [n_area][n_thr][n_dt]  index inside the pair of the matched ground truth, -1
+ *   dt_ignore  u8    [n_area][n_thr][n_dt]  dtIgnore (match ignored, or unmatched outside the range)
+ *   gt_match   int32 [n_area][n_thr][n_gt]  by position: index of the matching detection, -1 */
+int glsdet_coco_match(const double* dt_box, const double* dt_area, const int32_t* dt_off, const double* gt_box,
+                      const double* gt_area, const unsigned char* gt_flags, const int32_t* gt_off,
+                      const int64_t* iou_off, int32_t n_pairs, int32_t n_dt, int32_t n_gt,
+                      const double* area_rng, int32_t n_area, const double* iou_thr, int32_t n_thr,
+                      double* ious, int32_t* gt_order, unsigned char* gt_ignore, int32_t* n_regular,
+                      int32_t* dt_match, unsigned char* dt_ignore, int32_t* gt_match, void* stream);
 
 /* ---------------------------------------------------------------------------------
  * Plan: a recorded sequence of the calls above, replayed without Python in the loop and
