@@ -17,6 +17,8 @@
 // written (and the residual read) as full 16-byte channel chunks per pixel.
 #include <stdlib.h>
 
+#include <vector>
+
 #include "conv_common.h"
 
 namespace glsdet {
@@ -621,37 +623,67 @@ extern "C" int glsdet_conv2d_multi(const glsdet_conv_desc* d, int32_t n, void* s
   return submit(std::move(op), stream);
 }
 
+// Times every candidate on the device and reports the fastest.  Each candidate: one warm launch
+// (module load, function attributes), then TRIALS rounds over ALL candidates of REPS back-to-back
+// launches; a candidate's time is the MINIMUM over its rounds.  (One round of five launches per
+// candidate let a single hiccup -- a 20 us kernel measured at 2 ms now and then -- decide the variant
+// for the life of the plan; interleaving the rounds also spreads clock drift over all candidates.)
+static int time_variants(std::vector<OpRecord>& ops, const std::vector<int>& ids, hipStream_t st, int* best_id,
+                         float* best_us, int* any) {
+  constexpr int TRIALS = 3, REPS = 5;
+  hipEvent_t e0, e1;
+  GLS_HIP(hipEventCreate(&e0));
+  GLS_HIP(hipEventCreate(&e1));
+  std::vector<float> us(ops.size(), 1e30f);
+  std::vector<char> dead(ops.size(), 0);
+  for (size_t i = 0; i < ops.size(); ++i)
+    if (ops[i].launch(st)) dead[i] = 1;
+  for (int t = 0; t < TRIALS; ++t) {
+    for (size_t i = 0; i < ops.size(); ++i) {
+      if (dead[i]) continue;
+      int rc = 0;
+      (void)hipEventRecord(e0, st);
+      for (int r = 0; r < REPS && !rc; ++r) rc = ops[i].launch(st);
+      (void)hipEventRecord(e1, st);
+      if (hipEventSynchronize(e1) != hipSuccess || rc) { dead[i] = 1; continue; }
+      float ms = 0.f;
+      (void)hipEventElapsedTime(&ms, e0, e1);
+      const float u = ms * 1000.f / REPS;
+      if (u < us[i]) us[i] = u;
+    }
+  }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  *any = 0;
+  for (size_t i = 0; i < ops.size(); ++i) {
+    if (dead[i]) continue;
+    *any = 1;
+    if (us[i] < *best_us) { *best_us = us[i]; *best_id = ids[i]; }
+  }
+  return 0;
+}
+
 extern "C" int glsdet_conv2d_multi_tune(const glsdet_conv_desc* d, int32_t n, void* stream, int32_t* best_hint,
                                         float* best_us) {
   if (!d || !best_hint) GLS_FAIL(GLSDET_E_ARG, "conv2d_multi_tune: null argument");
   hipStream_t st = (hipStream_t)stream;
   const int hints[] = {(128 << 16) | 128, (64 << 16) | 128, (64 << 16) | 64, (64 << 16) | 64 | 0x8000,
                        (64 << 16) | 128 | 0x8000, (128 << 16) | 128 | 0x8000};
-  hipEvent_t e0, e1;
-  GLS_HIP(hipEventCreate(&e0));
-  GLS_HIP(hipEventCreate(&e1));
-  float best = 1e30f;
-  int bh = 0, any = 0;
+  std::vector<OpRecord> ops;
+  std::vector<int> ids;
   for (int h : hints) {
     OpRecord op;
     if (build_conv_multi_op(d, n, h, op)) continue;
-    int rc = op.launch(st);
-    if (rc) continue;
-    const int reps = 5;
-    (void)hipEventRecord(e0, st);
-    for (int r = 0; r < reps && !rc; ++r) rc = op.launch(st);
-    (void)hipEventRecord(e1, st);
-    if (hipEventSynchronize(e1) != hipSuccess || rc) continue;
-    float ms = 0.f;
-    (void)hipEventElapsedTime(&ms, e0, e1);
-    any = 1;
-    if (ms < best) { best = ms; bh = h; }
+    ops.push_back(std::move(op));
+    ids.push_back(h);
   }
-  (void)hipEventDestroy(e0);
-  (void)hipEventDestroy(e1);
+  float best = 1e30f;
+  int bh = 0, any = 0;
+  int rc = time_variants(ops, ids, st, &bh, &best, &any);
+  if (rc) return rc;
   if (!any) GLS_FAIL(GLSDET_E_ARG, "conv2d_multi_tune: no variant applies");
   *best_hint = bh;
-  if (best_us) *best_us = best * 1000.f / 5.f;
+  if (best_us) *best_us = best;
   set_error("");
   return 0;
 }
@@ -672,32 +704,22 @@ extern "C" int glsdet_conv2d_tune(const glsdet_conv_desc* d, void* stream, int32
   hipStream_t st = (hipStream_t)stream;
   const int hints[] = {2, 4, 5, 3, (128 << 16) | 128, (64 << 16) | 128, (64 << 16) | 64, (32 << 16) | 128,
                        (64 << 16) | 64 | 0x8000, (64 << 16) | 128 | 0x8000, (128 << 16) | 128 | 0x8000};
-  hipEvent_t e0, e1;
-  GLS_HIP(hipEventCreate(&e0));
-  GLS_HIP(hipEventCreate(&e1));
-  float best = 1e30f;
-  int bh = 0, any = 0;
+  std::vector<OpRecord> ops;
+  std::vector<int> ids;
   for (int h : hints) {
     OpRecord op;
     if (build_conv_op(d, h, op)) continue;             // variant does not apply
     if ((h >> 16) == 32 && d->y.c > 32) continue;
-    int rc = op.launch(st);                             // warm (module load, attributes)
-    if (rc) continue;
-    const int reps = 5;
-    (void)hipEventRecord(e0, st);
-    for (int r = 0; r < reps && !rc; ++r) rc = op.launch(st);
-    (void)hipEventRecord(e1, st);
-    if (hipEventSynchronize(e1) != hipSuccess || rc) continue;
-    float ms = 0.f;
-    (void)hipEventElapsedTime(&ms, e0, e1);
-    any = 1;
-    if (ms < best) { best = ms; bh = h; }
+    ops.push_back(std::move(op));
+    ids.push_back(h);
   }
-  (void)hipEventDestroy(e0);
-  (void)hipEventDestroy(e1);
+  float best = 1e30f;
+  int bh = 0, any = 0;
+  int rc = time_variants(ops, ids, st, &bh, &best, &any);
+  if (rc) return rc;
   if (!any) GLS_FAIL(GLSDET_E_ARG, "conv2d_tune: no variant applies");
   *best_hint = bh;
-  if (best_us) *best_us = best * 1000.f / 5.f;
+  if (best_us) *best_us = best;
   set_error("");
   return 0;
 }
