@@ -238,6 +238,9 @@ def main():
     ap.add_argument("--max-det", type=int, default=3000)
     ap.add_argument("--nms", type=float, default=0.65)
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--from-host", action="store_true",
+                    help="diagnostic: every step first copies its fp32 batch from pinned host memory (the "
+                         "PCIe-inclusive rate quoted in DESIGN.md; never the headline value)")
     ap.add_argument("--streams", type=int, default=3,
                     help="plan instances replayed round-robin on their own HIP streams (batches in flight)")
     ap.add_argument("--no-autotune", action="store_true")
@@ -284,6 +287,7 @@ def main():
     for ci in cs:
         ci.img.copy_(img)                                        # resident in HBM before timing
     c = cs[0]
+    host_img = img.cpu().pin_memory() if args.from_host else None
     torch.cuda.synchronize()
     turn = [0]
 
@@ -298,6 +302,9 @@ def main():
         # one batch = one graph replay on the instance's own stream (+ its gather when N>1);
         # consecutive batches rotate over the instances, so `--streams` batches are in flight (3: +6 % over 2
         # on the default workload, measured twice on one box; 4 is slower again)
+        if host_img is not None:
+            with torch.cuda.stream(ci.graph_stream):
+                ci.img.copy_(host_img, non_blocking=True)
         det.run_async(ci)
         if world > 1:
             with torch.cuda.stream(ci.graph_stream):
@@ -390,7 +397,7 @@ def main():
                                     "mpdet": "MPDet ResNet-50 + FPN + MPHead"}[kind],
                        "input": [bs, 3, H, W], "images_per_gpu": bs, "global_batch": bs * world, "num_classes": 10,
                        "post": post, "hip_graph": not args.no_graph,
-                       "batches_in_flight": nstreams,
+                       "batches_in_flight": nstreams, "input_from_host_each_step": bool(args.from_host),
                        "detections_per_image_rank0": [int(len(d)) for d in dets],
                        "candidates_per_image_rank0": cand_counts,
                        "parallelism": "image-sharded dp%d, one all_gather of detections per step" % world},
