@@ -243,6 +243,9 @@ def main():
                          "PCIe-inclusive rate quoted in DESIGN.md; never the headline value)")
     ap.add_argument("--streams", type=int, default=3,
                     help="plan instances replayed round-robin on their own HIP streams (batches in flight)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend; gloo is for rehearsing the N>1 control flow on a box with fewer "
+                         "GPUs than ranks (ranks then share devices round-robin) -- never for a reported number")
     ap.add_argument("--no-autotune", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--op-table", default="", help="write the per-op timing table (tsv) here")
@@ -254,12 +257,17 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             sys.exit("--gpus %d needs a torch.distributed.run launch (WORLD_SIZE=%d)" % (args.gpus, world))
+    if args.backend == "gloo":
+        local_rank %= max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     dev = "cuda:%d" % local_rank
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device(dev))
+        if args.backend == "gloo":
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device(dev))
 
     from glsdet_amd.detector import HipDetector
     from glsdet_amd.dist import gather_detections
