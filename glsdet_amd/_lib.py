@@ -85,6 +85,8 @@ _SIGS = {
                                     C.c_void_p]),
     "glsdet_resize_normalize_pad": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32,
                                               C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_void_p]),
+    "glsdet_resize_normalize_pad_u8": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32,
+                                                 C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_void_p]),
     "glsdet_ufp_merge_workspace_bytes": (C.c_int64, [C.c_int32]),
     "glsdet_ufp_backmap_merge": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_float, C.c_float,
                                            C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,

@@ -102,6 +102,44 @@ __global__ __launch_bounds__(256) void resize_norm_pad_kernel(const float* __res
   }
 }
 
+// The same pipeline on a uint8 source (the FIRST stage: `cv2.imread` frame -> mmcv.imresize): cv2.resize
+// works in 11-bit fixed point on uint8 and rounds to uint8 before Normalize sees the pixel.
+__global__ __launch_bounds__(256) void resize_norm_pad_u8_kernel(const unsigned char* __restrict__ src, int h, int w, int nh,
+                                                                 int nw, float* __restrict__ dst, int ph, int pw,
+                                                                 const NormArgs3 na) {
+  const long total = (long)ph * pw;
+  const bool same = nh == h && nw == w;                            // cv2.resize returns a copy
+  for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += (long)gridDim.x * blockDim.x) {
+    const int x = (int)(p % pw), y = (int)(p / pw);
+    float v[3] = {0.f, 0.f, 0.f};
+    if (x < nw && y < nh) {
+      LinTap tx, ty;
+      if (!same) {
+        tx = lin_tap_u8(x, nw, w);
+        ty = lin_tap_u8(y, nh, h);
+      }
+#pragma unroll
+      for (int e = 0; e < 3; ++e) {
+        int q;
+        if (same) {
+          q = src[((long)y * w + x) * 3 + e];
+        } else {
+          const int r0 = src[((long)ty.i0 * w + tx.i0) * 3 + e] * tx.c0 + src[((long)ty.i0 * w + tx.i1) * 3 + e] * tx.c1;
+          const int r1 = src[((long)ty.i1 * w + tx.i0) * 3 + e] * tx.c0 + src[((long)ty.i1 * w + tx.i1) * 3 + e] * tx.c1;
+          q = (((ty.c0 * (r0 >> 4)) >> 16) + ((ty.c1 * (r1 >> 4)) >> 16) + 2) >> 2;
+          q = q < 0 ? 0 : (q > 255 ? 255 : q);
+        }
+        const int c = 2 - e;                                      // BGR -> RGB
+        float f = (float)((double)(float)q - na.mean[c]);
+        f = (float)((double)f * na.stdinv[c]);
+        v[c] = f;
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) dst[(long)c * ph * pw + p] = v[c];
+  }
+}
+
 }  // namespace glsdet
 
 using namespace glsdet;
@@ -144,6 +182,31 @@ extern "C" int glsdet_resize_normalize_pad(const float* src, int32_t h, int32_t 
     long g = ((long)ph * pw + 255) / 256;
     if (g > 65535) g = 65535;
     hipLaunchKernelGGL(resize_norm_pad_kernel, dim3((unsigned)g), dim3(256), 0, st, src, h, w, nh, nw, dst, ph, pw, na);
+    GLS_HIP(hipGetLastError());
+    return 0;
+  };
+  return submit(std::move(op), stream);
+}
+
+extern "C" int glsdet_resize_normalize_pad_u8(const unsigned char* src, int32_t h, int32_t w, int32_t nh, int32_t nw,
+                                              float* dst, int32_t ph, int32_t pw, const double* mean_rgb,
+                                              const double* std_rgb, void* stream) {
+  if (!src || !dst || !mean_rgb || !std_rgb) GLS_FAIL(GLSDET_E_ARG, "resize_normalize_pad_u8: null argument");
+  if (h < 1 || w < 1 || nh < 1 || nw < 1 || ph < nh || pw < nw) GLS_FAIL(GLSDET_E_ARG, "resize_normalize_pad_u8: bad sizes");
+  NormArgs3 na;
+  for (int c = 0; c < 3; ++c) {
+    na.mean[c] = mean_rgb[c];
+    na.stdinv[c] = 1.0 / std_rgb[c];
+  }
+  OpRecord op;
+  op.kind = 1;
+  op.flops = 0;
+  op.bytes = 3.0 * h * w + 12.0 * ph * pw;
+  op.name = "resize_normalize_pad_u8";
+  op.launch = [=](hipStream_t st) -> int {
+    long g = ((long)ph * pw + 255) / 256;
+    if (g > 65535) g = 65535;
+    hipLaunchKernelGGL(resize_norm_pad_u8_kernel, dim3((unsigned)g), dim3(256), 0, st, src, h, w, nh, nw, dst, ph, pw, na);
     GLS_HIP(hipGetLastError());
     return 0;
   };

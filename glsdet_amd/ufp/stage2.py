@@ -58,15 +58,18 @@ class UfpSecondStage:
         return canvas
 
     # ---- Resize(keep_ratio) -> Normalize(to_rgb) -> Pad -> ImageToTensor
-    def pipeline_input(self, img_bgr_f32: torch.Tensor):
-        """fp32 HWC BGR image on the device -> (fp32 [1,3,ph,pw], meta dict as mmdet's img_metas)."""
-        assert img_bgr_f32.dtype == torch.float32 and img_bgr_f32.is_contiguous()
-        h, w = int(img_bgr_f32.shape[0]), int(img_bgr_f32.shape[1])
+    def pipeline_input(self, img_bgr: torch.Tensor):
+        """HWC BGR image on the device -> (fp32 [1,3,ph,pw], meta dict as mmdet's img_metas).
+        uint8 (a decoded frame, the first stage): cv2's uint8 fixed-point resize, rounded to uint8 before
+        Normalize; float32 (the mosaic, a float array in the reference): float bilinear."""
+        assert img_bgr.dtype in (torch.float32, torch.uint8) and img_bgr.is_contiguous() and img_bgr.dim() == 3
+        h, w = int(img_bgr.shape[0]), int(img_bgr.shape[1])
         nw, nh = rescale_size((w, h), self.img_scale)
         ph, pw = int(math.ceil(nh / self.div)) * self.div, int(math.ceil(nw / self.div)) * self.div
         out = torch.empty(1, 3, ph, pw, dtype=torch.float32, device=self.device)
-        _lib.check(self.lib.glsdet_resize_normalize_pad(img_bgr_f32.data_ptr(), h, w, nh, nw, out.data_ptr(), ph, pw,
-                                                        self._mean, self._std, self._stream()), "resize_normalize_pad")
+        fn = self.lib.glsdet_resize_normalize_pad if img_bgr.dtype == torch.float32 else self.lib.glsdet_resize_normalize_pad_u8
+        _lib.check(fn(img_bgr.data_ptr(), h, w, nh, nw, out.data_ptr(), ph, pw, self._mean, self._std, self._stream()),
+                   "resize_normalize_pad")
         torch.cuda.current_stream().synchronize()
         sf = np.array([nw / w, nh / h, nw / w, nh / h], dtype=np.float32)
         return out, dict(img_shape=(nh, nw, 3), pad_shape=(ph, pw, 3), ori_shape=(h, w, 3), scale_factor=sf, flip=False)
@@ -103,7 +106,7 @@ def two_stage_detect(coarse, fine, img_bgr_u8, stage: UfpSecondStage, coarse_cfg
     -> (per class ndarray (k,5) in source-image coordinates, intermediates dict)."""
     img = torch.as_tensor(np.ascontiguousarray(img_bgr_u8)).to(stage.device)
     H, W = int(img.shape[0]), int(img.shape[1])
-    x1, m1 = stage.pipeline_input(img.float().contiguous())
+    x1, m1 = stage.pipeline_input(img)                                # uint8 frame: cv2 uint8 resize
     first = coarse.detect(x1, img_shapes=[m1["img_shape"]], scale_factors=[m1["scale_factor"]], **coarse_cfg)[0]
     order = np.argsort(first[1], kind="stable")                     # np.concatenate(first_results): class-major
     boxes = first[0][order][:, :4]
@@ -136,7 +139,7 @@ class TwoStagePipeline:
         st = self.stage
         img = torch.as_tensor(np.ascontiguousarray(img_bgr_u8)).to(st.device)
         H, W = int(img.shape[0]), int(img.shape[1])
-        x1, m1 = st.pipeline_input(img.float().contiguous())
+        x1, m1 = st.pipeline_input(img)
         first = self.coarse.detect(x1, img_shapes=[m1["img_shape"]], scale_factors=[m1["scale_factor"]], **self.coarse_cfg)[0]
         order = np.argsort(first[1], kind="stable")
         boxes = first[0][order][:, :4]

@@ -282,6 +282,12 @@ int glsdet_ufp_mosaic(const unsigned char* img, int32_t H, int32_t W, const floa
  * (mmdet/datasets/pipelines/transforms.py:30,671,572).  mean/std: host double[3], RGB order.      */
 int glsdet_resize_normalize_pad(const float* src, int32_t h, int32_t w, int32_t nh, int32_t nw, float* dst,
                                 int32_t ph, int32_t pw, const double* mean_rgb, const double* std_rgb, void* stream);
+/* the same on a uint8 HWC BGR frame (the first stage: cv2.imread -> mmcv.imresize): cv2.resize's uint8
+ * INTER_LINEAR (11-bit fixed point, rounded to uint8) before Normalize.  An exact 2x downscale, which
+ * OpenCV silently turns into INTER_AREA, is NOT special-cased. */
+int glsdet_resize_normalize_pad_u8(const unsigned char* src, int32_t h, int32_t w, int32_t nh, int32_t nw, float* dst,
+                                   int32_t ph, int32_t pw, const double* mean_rgb, const double* std_rgb,
+                                   void* stream);
 /* back-mapping + merge NMS (:282-300): dets = the fine detector's rows [max_det][7] (x1,y1,x2,y2,
  * score,score,label) with their count on the device; a row inside a chip's mosaic rectangle (IoF >
  * iof_thr) is mapped to source-image coordinates; per class greedy NMS with '+1' areas, a box

@@ -98,10 +98,14 @@ STD = np.array([58.395, 57.12, 57.375])
 
 def mmdet_test_pipeline(img_bgr: np.ndarray, img_scale=(1333, 800), size_divisor: int = 32):
     """Resize(keep_ratio) -> Normalize(mean, std, to_rgb=True) -> Pad(size_divisor) -> CHW float32.
+    (An exact 2x downscale, which OpenCV silently runs as INTER_AREA, is not special-cased.)
     -> (tensor [1,3,H,W], meta dict(img_shape, pad_shape, scale_factor))."""
     h, w = img_bgr.shape[:2]
     (nw, nh), _ = rescale_size((w, h), img_scale)
-    img = resize_linear_f(img_bgr.astype(np.float64), nw, nh)
+    if img_bgr.dtype == np.uint8:        # a decoded frame: cv2's uint8 resize, rounded to uint8 before Normalize
+        img = cv2_resize_linear_u8(img_bgr, nw, nh).astype(np.float64)
+    else:                                # the mosaic is a float array in the reference: float bilinear
+        img = resize_linear_f(img_bgr.astype(np.float64), nw, nh)
     scale_factor = np.array([nw / w, nh / h, nw / w, nh / h], dtype=np.float32)
     rgb = img[:, :, ::-1].astype(np.float32)
     rgb = (rgb.astype(np.float64) - MEAN).astype(np.float32)

@@ -108,6 +108,21 @@ def test_hip_mosaic_equals_the_restatement(trial):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("hw", [(270, 480), (765, 1360), (1080, 1920), (750, 1333), (97, 131)])
+def test_hip_pipeline_input_uint8_frame_is_exact(hw):
+    """First stage: a decoded uint8 frame goes through cv2's fixed-point resize (integer arithmetic: exact
+    against the restatement), then the float normalisation (same operations: exact as well)."""
+    import torch
+    from glsdet_amd.ufp import UfpSecondStage
+    from oracle import ufp_oracle as U
+    img = np.random.default_rng(hw[0]).integers(0, 256, (hw[0], hw[1], 3), dtype=np.uint8)
+    want, meta = U.mmdet_test_pipeline(img)
+    got, m = UfpSecondStage().pipeline_input(torch.from_numpy(img).cuda())
+    assert tuple(got.shape) == want.shape and m["img_shape"] == meta["img_shape"] and m["pad_shape"] == meta["pad_shape"]
+    assert np.array_equal(got.cpu().numpy(), want)
+
+
+@pytest.mark.gpu
 def test_hip_pipeline_input_vs_restatement():
     import torch
     from glsdet_amd.ufp import UfpSecondStage
@@ -173,7 +188,7 @@ def test_two_stage_pipeline_runs_end_to_end():
         cls, _ = det.forward_raw(x)
         p = torch.sigmoid(torch.cat([c.flatten() for c in cls]))
         return float(torch.topk(p, keep).values[-1])
-    x1, _ = stage.pipeline_input(torch.from_numpy(img).cuda().float().contiguous())
+    x1, _ = stage.pipeline_input(torch.from_numpy(img).cuda().contiguous())
     t1 = thr_for(coarse, x1, 60)
     merged, mid = two_stage_detect(coarse, fine, img, stage, dict(score_thr=t1, iou_thr=0.6, nms_pre=1000, max_per_img=40),
                                    dict(score_thr=0.999, iou_thr=0.6, nms_pre=1000, max_per_img=300))

@@ -25,7 +25,7 @@ def thr_for(det, x, keep):
     return float(torch.topk(p, keep).values[-1])
 
 
-x1, _ = stage.pipeline_input(torch.from_numpy(img).cuda().float().contiguous())
+x1, _ = stage.pipeline_input(torch.from_numpy(img).cuda().contiguous())
 c1 = dict(score_thr=thr_for(coarse, x1, 80), iou_thr=0.6, nms_pre=1000, max_per_img=100)
 _, mid = two_stage_detect(coarse, fine, img, stage, c1, dict(score_thr=0.9999, iou_thr=0.6))
 x2, _ = stage.pipeline_input(mid["canvas"])
