@@ -520,7 +520,7 @@ static int make_conv_args(const glsdet_conv_desc* d, int hint, ConvArgs& a, doub
   a.R = d->R; a.S = d->S; a.stride = d->stride; a.pad = d->pad;
   a.act = d->act & 0xff;
   a.act_post = 0;
-  a.dbg = hint > 5 ? (hint >> 8) & 7 : 0;
+  a.dbg = hint >= 0x10000 ? (hint >> 8) & 7 : 0;
   if ((d->act & GLSDET_ACT_RES_FIRST) && has_res) { a.act_post = a.act; a.act = GLSDET_ACT_NONE; }
   a.kreal = d->R * d->S * x.c;
   a.kpad = glsdet_conv_kpad(d->R, d->S, x.c, x.dtype);
@@ -556,17 +556,22 @@ static int build_conv_op(const glsdet_conv_desc* d, int hint, OpRecord& op) {
   const int xdt = x.dtype, ydt = y.dtype;
   // tile_hint: 0 auto, 1 generic kernel, 2 halo kernel, 4 halo kernel with wave-private weight staging,
   // 5 halo kernel with 64-row cout tiles also for wide layers,
-  // 3 weight-stationary 1x1 kernel, else co<<16|px (generic)
+  // 6 / 7 halo kernel with LDS-DMA staging (64- / 128-row cout tiles), 3 weight-stationary 1x1 kernel,
+  // else co<<16|px (generic)
   if (hint == 3) {
     if (conv1x1_ws_try(a, xdt, ydt, &op) == 0) return 0;
     GLS_FAIL(GLSDET_E_ARG, "conv2d: the weight-stationary 1x1 kernel does not apply to this problem");
+  }
+  if (hint == 6 || hint == 7) {
+    if (conv_halo_dma_try(a, xdt, ydt, hint, &op) == 0) return 0;
+    GLS_FAIL(GLSDET_E_ARG, "conv2d: the LDS-DMA halo kernel does not apply to this problem");
   }
   if (conv_halo_try(a, xdt, ydt, hint, &op) == 0) return 0;
   if (hint == 2 || hint == 4 || hint == 5) GLS_FAIL(GLSDET_E_ARG, "conv2d: the halo kernel does not apply to this problem");
 
   int co_t, px_t, kb;
-  pick_tile(a, dtype_size(x.dtype), hint > 5 ? hint : 0, &co_t, &px_t, &kb);
-  if (hint > 5 && co_t > 32 && a.cout_pad <= co_t / 2) GLS_FAIL(GLSDET_E_ARG, "conv2d: tile %dx%d is mostly padding here", co_t, px_t);
+  pick_tile(a, dtype_size(x.dtype), hint >= 0x10000 ? hint : 0, &co_t, &px_t, &kb);
+  if (hint >= 0x10000 && co_t > 32 && a.cout_pad <= co_t / 2) GLS_FAIL(GLSDET_E_ARG, "conv2d: tile %dx%d is mostly padding here", co_t, px_t);
   char nm[96];
   snprintf(nm, sizeof nm, "conv_igemm<%s,%s,%dx%d,kb%d> %dx%d s%d cin%d cout%d", xdt ? "f32" : "f16",
            ydt ? "f32" : "f16", co_t, px_t, kb, d->R, d->S, d->stride, x.c, y.c);
@@ -601,7 +606,7 @@ static int build_conv_multi_op(const glsdet_conv_desc* d, int32_t n, int hint, O
   int co_t, px_t, kb;
   ConvArgs probe = m.p[0];
   probe.M = (int)(Mtot > 0x7fffffffL ? 0x7fffffffL : Mtot);
-  pick_tile(probe, dtype_size(d[0].x.dtype), hint > 5 ? hint : 0, &co_t, &px_t, &kb);
+  pick_tile(probe, dtype_size(d[0].x.dtype), hint >= 0x10000 ? hint : 0, &co_t, &px_t, &kb);
   if (co_t == 32) { co_t = 64; px_t = 64; }
   const int xdt = d[0].x.dtype, ydt = d[0].y.dtype;
   char nm[112];
@@ -702,7 +707,7 @@ extern "C" int glsdet_conv2d(const glsdet_conv_desc* d, void* stream) {
 extern "C" int glsdet_conv2d_tune(const glsdet_conv_desc* d, void* stream, int32_t* best_hint, float* best_us) {
   if (!d || !best_hint) GLS_FAIL(GLSDET_E_ARG, "conv2d_tune: null argument");
   hipStream_t st = (hipStream_t)stream;
-  const int hints[] = {2, 4, 5, 3, (128 << 16) | 128, (64 << 16) | 128, (64 << 16) | 64, (32 << 16) | 128,
+  const int hints[] = {2, 4, 5, 6, 7, 3, (128 << 16) | 128, (64 << 16) | 128, (64 << 16) | 64, (32 << 16) | 128,
                        (64 << 16) | 64 | 0x8000, (64 << 16) | 128 | 0x8000, (128 << 16) | 128 | 0x8000};
   std::vector<OpRecord> ops;
   std::vector<int> ids;

@@ -118,8 +118,24 @@ __device__ __forceinline__ u32x4 add_chunk(u32x4 a, u32x4 b, float*, int act_pos
 }
 
 
+// Tile-local pixel index -> (oy, ox) for 16-pixel-wide tiles.  A 32-lane MFMA subtile covers
+// two pixel rows; the patch row pitch PW is not a multiple of 16 rows-of-144-bytes, so the
+// second row would land on the bank sets of the first (2-way conflicts on ds_read_b128).
+// Rotating the odd rows' pixel order by (-PW mod 16) makes lane m of either row hit bank
+// set m: conflict free at no LDS cost.  The epilogue decodes with the same function.
+template <int PW>
+__device__ __forceinline__ void pix_to_xy16(int pix, int& oy, int& ox) {
+  oy = pix >> 4;
+  const int m = pix & 15;
+  constexpr int ROT = (16 - (PW & 15)) & 15;
+  ox = (oy & 1) ? ((m + ROT) & 15) : m;
+}
+
+
 // host-side dispatch of the halo kernel (conv_halo.hip); returns 1 if it does not apply
 int conv_halo_try(const ConvArgs& a, int xdt, int ydt, int hint, OpRecord* op);
+// the same problem class with LDS-DMA staging (conv_halo_dma.hip), tile_hint 6 / 7; returns 1 if it does not apply
+int conv_halo_dma_try(const ConvArgs& a, int xdt, int ydt, int hint, OpRecord* op);
 // weight-stationary persistent 1x1 kernel (conv1x1.hip), tile_hint 3; returns 1 if it does not apply
 int conv1x1_ws_try(const ConvArgs& a, int xdt, int ydt, OpRecord* op);
 

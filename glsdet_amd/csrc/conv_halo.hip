@@ -16,19 +16,6 @@
 namespace glsdet {
 
 
-// Tile-local pixel index -> (oy, ox) for 16-pixel-wide tiles.  A 32-lane MFMA subtile covers
-// two pixel rows; the patch row pitch PW is not a multiple of 16 rows-of-144-bytes, so the
-// second row would land on the bank sets of the first (2-way conflicts on ds_read_b128).
-// Rotating the odd rows' pixel order by (-PW mod 16) makes lane m of either row hit bank
-// set m: conflict free at no LDS cost.  The epilogue decodes with the same function.
-template <int PW>
-__device__ __forceinline__ void pix_to_xy16(int pix, int& oy, int& ox) {
-  oy = pix >> 4;
-  const int m = pix & 15;
-  constexpr int ROT = (16 - (PW & 15)) & 15;
-  ox = (oy & 1) ? ((m + ROT) & 15) : m;
-}
-
 template <int KS, int TH, int TW>
 struct HaloGeom {
   static constexpr int PH = TH + KS - 1, PW = TW + KS - 1;
