@@ -1,4 +1,5 @@
 // Probe: buffer_load_dwordx4 ... lds on gfx950 -- destination order and what out-of-range lanes write.
+// build: hipcc --offload-arch=gfx950 -O2 tools/probe/glds_probe.hip -o tools/probe/glds_probe ; run on the GPU box
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 __global__ void k(const void* p, unsigned bytes, unsigned* out) {
