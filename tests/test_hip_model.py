@@ -349,3 +349,48 @@ def test_every_conv_variant_agrees_on_the_benchmark_shapes(workload):
     spec.loader.exec_module(mod)
     lines = []
     assert mod.check([workload], lines.append) == 0, "\n".join(lines)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["f32", "f16"])
+@pytest.mark.parametrize("tag", ["gl_s_seed0", "base_s_seed0"])
+def test_detections_scored_against_the_reference_detections_with_cocoeval(golden, shapes, tag, mode):
+    """End to end in the metric the reference reports: the REFERENCE's detections (its golden decode output
+    through the oracle NMS) are the ground truth, the HIP path's detections on the same input are the
+    results, bbox COCOeval (on the device too) gives AP.  Identical detections score 1; a box that moved
+    costs the high-IoU thresholds, a detection that crossed the confidence threshold costs recall or
+    precision.  Measured round 1 (random-weight nets, which amplify rounding ~100x end to end -- see
+    test_model_f16_close_to_reference): f32 AP 0.987-1.000, AP50 1.000; f16 AP 0.79-0.88, AP50 0.92-0.96,
+    the same NUMBER of detections in every case.  north_star's mAP +-0.1 is a statement about trained weights
+    on VisDrone (neither is available here); this is the closest measurable stand-in and a much harsher one."""
+    from glsdet_amd.detector import HipDetector
+    from glsdet_amd.eval import COCO, COCOeval
+    meta, sd, x, outs, decoded = model_case(golden, shapes, tag)
+    H, W = meta["in_shape"][2:]
+    conf, thr = 0.05, 0.65
+    ref = _nms_ref(decoded, 10, conf, thr)
+    det = HipDetector(meta["model"], sd, dtype=mode)
+    _, got = det.detect(x.cuda(), conf, thr, max_det=2000)
+    scale = np.array([W, H, W, H], np.float64)               # decode_outputs leaves boxes normalised to the input
+    anns, res = [], []
+    for i, (r, g) in enumerate(zip(ref, got)):
+        for row in r:
+            b = row[:4].astype(np.float64) * scale
+            anns.append(dict(id=len(anns) + 1, image_id=i, category_id=int(row[6]), iscrowd=0,
+                             bbox=[b[0], b[1], b[2] - b[0], b[3] - b[1]], area=float((b[2] - b[0]) * (b[3] - b[1]))))
+        for row in (g if g is not None else []):
+            b = row[:4].astype(np.float64) * scale
+            res.append(dict(image_id=i, category_id=int(row[6]), score=float(row[4] * row[5]),
+                            bbox=[b[0], b[1], b[2] - b[0], b[3] - b[1]]))
+    assert len(anns) >= 20, "too few reference detections for a meaningful score"
+    gt = COCO(dict(images=[dict(id=i) for i in range(len(ref))], categories=[dict(id=c) for c in range(10)], annotations=anns))
+    E = COCOeval(gt, gt.loadRes(res), "bbox")
+    E.params.maxDets = [10, 100, 2000]
+    E.evaluate(); E.accumulate(); E.summarize()
+    print("%s %s: %d reference / %d HIP detections, AP %.4f AP50 %.4f AP75 %.4f AR %.4f"
+          % (tag, mode, len(anns), len(res), E.stats[0], E.stats[1], E.stats[2], E.stats[8]))
+    ap = E.eval["precision"][:, :, :, 0, 2]
+    ap = float(np.mean(ap[ap > -1]))                           # AP@[.5:.95] at the largest maxDets
+    assert ap >= (0.98 if mode == "f32" else 0.70)
+    assert E.stats[1] >= (0.995 if mode == "f32" else 0.88)
+    assert abs(len(res) - len(anns)) <= max(2, len(anns) // 50)
