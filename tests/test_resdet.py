@@ -380,6 +380,39 @@ def test_detector_f16_vs_oracle_and_graph(kind):
         assert np.array_equal(a, b) and np.array_equal(la, lb)      # graph replay is bit-identical to eager
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["f32", "f16"])
+@pytest.mark.parametrize("kind", ["gfl", "mpdet"])
+def test_detections_scored_against_the_restatement_with_cocoeval(kind, mode):
+    """The restatement's detections as ground truth, the HIP path's as results, bbox COCOeval on the device
+    (the metric ufpmp_det_eval.py reports).  Measured round 1 on random-weight nets: f32 AP >= 0.99; f16 see the
+    printed line (the asserts leave room for the ~100x noise amplification of untrained weights)."""
+    from glsdet_amd.eval import COCO, COCOeval
+    from glsdet_amd.resdet import HipGflDetector
+    x = O.synth_input((2, 3, 128, 160), 21)
+    sd = calibrated_resdet_sd(kind, 4, x)
+    wc, wr = M.gfl_forward(sd, x) if kind == "gfl" else M.mpdet_forward(sd, x, HipGflDetector.DEFAULTS["proxies_list"])
+    shapes_ = [(120, 150, 3), (128, 160, 3)]
+    want = M.gfl_get_bboxes(wc, wr, [8, 16, 32, 64, 128], shapes_, 0.3, 1000, 0.6, 100)
+    got = HipGflDetector(kind, sd, dtype=mode).detect(x.cuda(), score_thr=0.3, iou_thr=0.6, nms_pre=1000, max_per_img=100,
+                                                      img_shapes=shapes_)
+    anns, res = [], []
+    for i, ((wb, wl), (gb, gl)) in enumerate(zip(want, got)):
+        for b, l in zip(np.asarray(wb, np.float64), np.asarray(wl)):
+            anns.append(dict(id=len(anns) + 1, image_id=i, category_id=int(l), iscrowd=0,
+                             bbox=[b[0], b[1], b[2] - b[0], b[3] - b[1]], area=float((b[2] - b[0]) * (b[3] - b[1]))))
+        for b, l in zip(np.asarray(gb, np.float64), np.asarray(gl)):
+            res.append(dict(image_id=i, category_id=int(l), score=float(b[4]), bbox=[b[0], b[1], b[2] - b[0], b[3] - b[1]]))
+    assert len(anns) >= 20
+    gt = COCO(dict(images=[dict(id=0), dict(id=1)], categories=[dict(id=c) for c in range(10)], annotations=anns))
+    E = COCOeval(gt, gt.loadRes(res), "bbox")
+    E.params.maxDets = [10, 100, 500]
+    E.evaluate(); E.accumulate(); E.summarize()
+    print("%s %s: %d restatement / %d HIP detections, AP %.4f AP50 %.4f AP75 %.4f AR %.4f"
+          % (kind, mode, len(anns), len(res), E.stats[0], E.stats[1], E.stats[2], E.stats[8]))
+    assert E.stats[0] >= (0.97 if mode == "f32" else 0.6) and E.stats[1] >= (0.99 if mode == "f32" else 0.8)
+
+
 # ------------------------------------------------------------------------------- mmdet surface
 import os  # noqa: E402
 
