@@ -228,8 +228,8 @@ def calibrate_objectness(sd, kind, img, args, dev):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="yolox_s_glfusion_1344x800_bs8", choices=sorted(WORKLOADS))
     ap.add_argument("--dtype", default="f16", choices=["f16", "f32"])
     ap.add_argument("--conf", type=float, default=0.25)
