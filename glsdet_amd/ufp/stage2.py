@@ -100,14 +100,14 @@ class UfpSecondStage:
 
 
 def two_stage_detect(coarse, fine, img_bgr_u8, stage: UfpSecondStage, coarse_cfg: dict, fine_cfg: dict,
-                     expand: float = 1.5):
+                     expand: float = 1.5, use_graph: bool = False):
     """One image through coarse -> UFP -> mosaic -> fine -> merge (ufpmp_det_eval.py:253-300).
     coarse / fine: glsdet_amd.resdet.HipGflDetector; *_cfg: dict(score_thr, iou_thr, nms_pre, max_per_img).
     -> (per class ndarray (k,5) in source-image coordinates, intermediates dict)."""
     img = torch.as_tensor(np.ascontiguousarray(img_bgr_u8)).to(stage.device)
     H, W = int(img.shape[0]), int(img.shape[1])
     x1, m1 = stage.pipeline_input(img)                                # uint8 frame: cv2 uint8 resize
-    first = coarse.detect(x1, img_shapes=[m1["img_shape"]], scale_factors=[m1["scale_factor"]], **coarse_cfg)[0]
+    first = coarse.detect(x1, img_shapes=[m1["img_shape"]], scale_factors=[m1["scale_factor"]], use_graph=use_graph, **coarse_cfg)[0]
     order = np.argsort(first[1], kind="stable")                     # np.concatenate(first_results): class-major
     boxes = first[0][order][:, :4]
     if len(boxes) == 0:
@@ -117,7 +117,7 @@ def two_stage_detect(coarse, fine, img_bgr_u8, stage: UfpSecondStage, coarse_cfg
     x2, m2 = stage.pipeline_input(canvas)
     post = dict(score_thr=fine_cfg["score_thr"], iou_thr=fine_cfg["iou_thr"], nms_pre=fine_cfg.get("nms_pre", 1000),
                 max_per_img=fine_cfg.get("max_per_img", 500), rescale=True)
-    c = fine.compile(1, x2.shape[2], x2.shape[3], post)
+    c = fine.compile(1, x2.shape[2], x2.shape[3], post, use_graph=use_graph)
     fine.run(c, x2, torch.tensor([[m2["img_shape"][0], m2["img_shape"][1]]], dtype=torch.float32, device=stage.device),
              torch.tensor(m2["scale_factor"].reshape(1, 4), device=stage.device))
     merged = stage.merge(c.nb["dets"][0], c.nb["count"], chips, fine.num_classes)
@@ -131,16 +131,21 @@ class TwoStagePipeline:
     release the GIL, the recorded plans are per thread)."""
 
     def __init__(self, coarse, fine, stage: UfpSecondStage, coarse_cfg: dict, fine_cfg: dict, expand: float = 1.5,
-                 depth: int = 2):
+                 depth: int = 2, use_graph: bool = False):
         self.coarse, self.fine, self.stage = coarse, fine, stage
         self.coarse_cfg, self.fine_cfg, self.expand, self.depth = coarse_cfg, fine_cfg, expand, depth
+        # use_graph: one captured plan per input shape.  Measured (tools/two_stage_bench.py, 540x1024 frames): at batch 1
+        # the stages are GPU bound, graph replay gains nothing sequentially (180 frames/s either way) and LOSES the
+        # overlap of the two threads (185 vs 280 frames/s with eager plans), so it is off by default.
+        self.use_graph = use_graph
 
     def _first(self, img_bgr_u8):
         st = self.stage
         img = torch.as_tensor(np.ascontiguousarray(img_bgr_u8)).to(st.device)
         H, W = int(img.shape[0]), int(img.shape[1])
         x1, m1 = st.pipeline_input(img)
-        first = self.coarse.detect(x1, img_shapes=[m1["img_shape"]], scale_factors=[m1["scale_factor"]], **self.coarse_cfg)[0]
+        first = self.coarse.detect(x1, img_shapes=[m1["img_shape"]], scale_factors=[m1["scale_factor"]], use_graph=self.use_graph,
+                                   **self.coarse_cfg)[0]
         order = np.argsort(first[1], kind="stable")
         boxes = first[0][order][:, :4]
         if len(boxes) == 0:
@@ -156,7 +161,7 @@ class TwoStagePipeline:
         fc = self.fine_cfg
         post = dict(score_thr=fc["score_thr"], iou_thr=fc["iou_thr"], nms_pre=fc.get("nms_pre", 1000),
                     max_per_img=fc.get("max_per_img", 500), rescale=True)
-        c = fine.compile(1, x2.shape[2], x2.shape[3], post)
+        c = fine.compile(1, x2.shape[2], x2.shape[3], post, use_graph=self.use_graph)
         fine.run(c, x2, torch.tensor([[m2["img_shape"][0], m2["img_shape"][1]]], dtype=torch.float32, device=st.device),
                  torch.tensor(m2["scale_factor"].reshape(1, 4), device=st.device))
         return st.merge(c.nb["dets"][0], c.nb["count"], chips, fine.num_classes)

@@ -50,17 +50,24 @@ print("two-stage, one 540x1024 frame: %.2f ms end to end (%.1f frames/s); host p
          tuple(x2.shape), sum(len(m) for m in merged)))
 
 frames = [synth_image((540, 1024), 100 + i)[:, :, ::-1].copy() for i in range(8)] * 4
-pipe = TwoStagePipeline(coarse, fine, stage, c1, c2)
-pipe.run(frames[:8])                        # warm: plans for the mosaic shapes of these frames
+pipes = {g: TwoStagePipeline(coarse, fine, stage, c1, c2, use_graph=g) for g in (False, True)}
+for g in (False, True):                     # warm: plans (and graphs) for the mosaic shapes of these frames
+    for f in frames[:8]:
+        two_stage_detect(coarse, fine, f, stage, c1, c2, use_graph=g)
+    pipes[g].run(frames[:8])
 torch.cuda.synchronize()
-t0 = time.perf_counter()
-seq = [two_stage_detect(coarse, fine, f, stage, c1, c2)[0] for f in frames]
-torch.cuda.synchronize()
-t_seq = time.perf_counter() - t0
-t0 = time.perf_counter()
-out = pipe.run(frames)
-torch.cuda.synchronize()
-t_pipe = time.perf_counter() - t0
-same = all(all(np.array_equal(a, b) for a, b in zip(x, y)) for x, y in zip(seq, out))
-print("32 frames: sequential %.1f frames/s, two-stream pipeline %.1f frames/s, identical results: %s"
-      % (len(frames) / t_seq, len(frames) / t_pipe, same))
+ref = None
+for rep in range(2):
+    line = []
+    for name, fn in (("sequential eager", lambda: [two_stage_detect(coarse, fine, f, stage, c1, c2)[0] for f in frames]),
+                     ("sequential graph replay", lambda: [two_stage_detect(coarse, fine, f, stage, c1, c2, use_graph=True)[0] for f in frames]),
+                     ("two-stream pipeline eager", lambda: pipes[False].run(frames)),
+                     ("two-stream pipeline graph replay", lambda: pipes[True].run(frames))):
+        t0 = time.perf_counter()
+        out = fn()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        ref = out if ref is None else ref
+        same = all(all(np.array_equal(a, b) for a, b in zip(x, y)) for x, y in zip(ref, out))
+        line.append("%s %.1f%s" % (name, len(frames) / dt, "" if same else " (RESULTS DIFFER)"))
+    print("32 frames, frames/s: " + "; ".join(line))
