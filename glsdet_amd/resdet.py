@@ -300,7 +300,7 @@ class HipGflDetector:
         return [l.to_nchw(self.num_classes) for l in c.cls], [l.to_nchw(bins) for l in c.reg]
 
     def detect(self, img: torch.Tensor, score_thr: float = 0.05, iou_thr: float = 0.6, nms_pre: int = 1000,
-               max_per_img: int = 100, img_shapes=None, scale_factors=None, use_graph: bool = False):
+               max_per_img: int = 100, img_shapes=None, scale_factors=None, use_graph: bool = False, instance: int = 0):
         """-> list per image of (dets ndarray(k,5) x1,y1,x2,y2,score ; labels ndarray(k) int64).
         use_graph: replay a hipGraph captured for this (batch, H, W, thresholds) -- one plan per input shape
         stays resident (the fine stage of UFPMP-Det sees a few dozen padded mosaic shapes; at ~0.5 GB of
@@ -308,7 +308,7 @@ class HipGflDetector:
         n, _, H, W = img.shape
         post = dict(score_thr=score_thr, iou_thr=iou_thr, nms_pre=nms_pre, max_per_img=max_per_img,
                     rescale=scale_factors is not None)
-        c = self.compile(n, H, W, post, use_graph=use_graph)
+        c = self.compile(n, H, W, post, use_graph=use_graph, instance=instance)   # instance: private buffers per caller thread
         hw = None if img_shapes is None else torch.tensor([[s[0], s[1]] for s in img_shapes], dtype=torch.float32)
         sf = None if scale_factors is None else torch.tensor(np.asarray(scale_factors, np.float32).reshape(n, 4))
         self.run(c, img.to(c.img.device, torch.float32), None if hw is None else hw.to(c.img.device),

@@ -125,34 +125,38 @@ def two_stage_detect(coarse, fine, img_bgr_u8, stage: UfpSecondStage, coarse_cfg
 
 
 class TwoStagePipeline:
-    """BASELINE config 5: coarse and fine detector pipelined on separate HIP streams.  Two host
-    threads, each with its own stream: one runs preprocessing + coarse detector + packing for frame
-    i+1 while the other runs mosaic + fine detector + merge for frame i (the host waits of a stage
-    release the GIL, the recorded plans are per thread)."""
+    """BASELINE config 5: coarse and fine detector pipelined on separate HIP streams.  `workers` lanes,
+    each a pair of host threads with their own streams and their own plan instances (private activation
+    buffers): one thread runs preprocessing + coarse detector + packing for its next frame while the other
+    runs mosaic + fine detector + merge for its previous one (the host waits of a stage release the GIL,
+    the recorded plans are per thread).  Frame i goes to lane i % workers; results come back in order.
+    At batch 1 neither detector fills the chip, so several frames in flight is where the throughput is
+    (tools/two_stage_bench.py)."""
 
     def __init__(self, coarse, fine, stage: UfpSecondStage, coarse_cfg: dict, fine_cfg: dict, expand: float = 1.5,
-                 depth: int = 2, use_graph: bool = False):
+                 depth: int = 2, use_graph: bool = False, workers: int = 1):
         self.coarse, self.fine, self.stage = coarse, fine, stage
         self.coarse_cfg, self.fine_cfg, self.expand, self.depth = coarse_cfg, fine_cfg, expand, depth
         # use_graph: one captured plan per input shape.  Measured (tools/two_stage_bench.py, 540x1024 frames): at batch 1
         # the stages are GPU bound, graph replay gains nothing sequentially (180 frames/s either way) and LOSES the
         # overlap of the two threads (185 vs 280 frames/s with eager plans), so it is off by default.
         self.use_graph = use_graph
+        self.workers = max(1, int(workers))
 
-    def _first(self, img_bgr_u8):
+    def _first(self, img_bgr_u8, lane: int = 0):
         st = self.stage
         img = torch.as_tensor(np.ascontiguousarray(img_bgr_u8)).to(st.device)
         H, W = int(img.shape[0]), int(img.shape[1])
         x1, m1 = st.pipeline_input(img)
         first = self.coarse.detect(x1, img_shapes=[m1["img_shape"]], scale_factors=[m1["scale_factor"]], use_graph=self.use_graph,
-                                   **self.coarse_cfg)[0]
+                                   instance=lane, **self.coarse_cfg)[0]
         order = np.argsort(first[1], kind="stable")
         boxes = first[0][order][:, :4]
         if len(boxes) == 0:
             return img, None
         return img, unified_foreground_packing(boxes.copy(), self.expand, [W, H])
 
-    def _second(self, img, packed):
+    def _second(self, img, packed, lane: int = 0):
         st, fine = self.stage, self.fine
         if packed is None:
             return [np.zeros((0, 5)) for _ in range(fine.num_classes)]
@@ -161,7 +165,7 @@ class TwoStagePipeline:
         fc = self.fine_cfg
         post = dict(score_thr=fc["score_thr"], iou_thr=fc["iou_thr"], nms_pre=fc.get("nms_pre", 1000),
                     max_per_img=fc.get("max_per_img", 500), rescale=True)
-        c = fine.compile(1, x2.shape[2], x2.shape[3], post, use_graph=self.use_graph)
+        c = fine.compile(1, x2.shape[2], x2.shape[3], post, use_graph=self.use_graph, instance=lane)
         fine.run(c, x2, torch.tensor([[m2["img_shape"][0], m2["img_shape"][1]]], dtype=torch.float32, device=st.device),
                  torch.tensor(m2["scale_factor"].reshape(1, 4), device=st.device))
         return st.merge(c.nb["dets"][0], c.nb["count"], chips, fine.num_classes)
@@ -169,16 +173,15 @@ class TwoStagePipeline:
     def run(self, images: Sequence) -> List[List[np.ndarray]]:
         import queue
         import threading
-        q: "queue.Queue" = queue.Queue(maxsize=self.depth)
         results: List = [None] * len(images)
         errors: List[BaseException] = []
         dev = self.stage.device
 
-        def producer():
+        def producer(lane, q):
             try:
                 with torch.cuda.stream(torch.cuda.Stream(device=dev)):
-                    for i, im in enumerate(images):
-                        item = self._first(im)
+                    for i in range(lane, len(images), self.workers):
+                        item = self._first(images[i], lane)
                         torch.cuda.current_stream().synchronize()
                         q.put((i,) + item)
             except BaseException as e:          # noqa: BLE001 - re-raised in the caller's thread
@@ -186,7 +189,7 @@ class TwoStagePipeline:
             finally:
                 q.put(None)
 
-        def consumer():
+        def consumer(lane, q):
             try:
                 with torch.cuda.stream(torch.cuda.Stream(device=dev)):
                     while True:
@@ -194,13 +197,16 @@ class TwoStagePipeline:
                         if item is None:
                             return
                         i, img, packed = item
-                        results[i] = self._second(img, packed)
+                        results[i] = self._second(img, packed, lane)
             except BaseException as e:          # noqa: BLE001
                 errors.append(e)
                 while q.get() is not None:      # drain so that the producer can finish
                     pass
 
-        ts = [threading.Thread(target=producer), threading.Thread(target=consumer)]
+        ts = []
+        for lane in range(self.workers):
+            q: "queue.Queue" = queue.Queue(maxsize=self.depth)
+            ts += [threading.Thread(target=producer, args=(lane, q)), threading.Thread(target=consumer, args=(lane, q))]
         for t in ts:
             t.start()
         for t in ts:

@@ -218,3 +218,8 @@ def test_two_stage_pipeline_runs_end_to_end():
     par = TwoStagePipeline(coarse, fine, stage, c1, c2).run(frames)
     for a, b in zip(seq, par):
         assert all(np.array_equal(x, y) for x, y in zip(a, b))
+    # several lanes (each with private plan instances), and graph replay per input shape: same detections, in order
+    for kw in (dict(workers=2), dict(workers=3, use_graph=True)):
+        par = TwoStagePipeline(coarse, fine, stage, c1, c2, **kw).run(frames + frames)
+        for a, b in zip(seq + seq, par):
+            assert all(np.array_equal(x, y) for x, y in zip(a, b)), kw

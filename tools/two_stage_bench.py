@@ -55,6 +55,9 @@ for g in (False, True):                     # warm: plans (and graphs) for the m
     for f in frames[:8]:
         two_stage_detect(coarse, fine, f, stage, c1, c2, use_graph=g)
     pipes[g].run(frames[:8])
+lanes = {w: TwoStagePipeline(coarse, fine, stage, c1, c2, workers=w) for w in (2, 3, 4)}
+for w, pl in lanes.items():
+    pl.run(frames[:8] * w)                  # every lane sees every shape once
 torch.cuda.synchronize()
 ref = None
 for rep in range(2):
@@ -62,7 +65,9 @@ for rep in range(2):
     for name, fn in (("sequential eager", lambda: [two_stage_detect(coarse, fine, f, stage, c1, c2)[0] for f in frames]),
                      ("sequential graph replay", lambda: [two_stage_detect(coarse, fine, f, stage, c1, c2, use_graph=True)[0] for f in frames]),
                      ("two-stream pipeline eager", lambda: pipes[False].run(frames)),
-                     ("two-stream pipeline graph replay", lambda: pipes[True].run(frames))):
+                     ("two-stream pipeline graph replay", lambda: pipes[True].run(frames)),
+                     ("2 lanes", lambda: lanes[2].run(frames)), ("3 lanes", lambda: lanes[3].run(frames)),
+                     ("4 lanes", lambda: lanes[4].run(frames))):
         t0 = time.perf_counter()
         out = fn()
         torch.cuda.synchronize()
