@@ -5,11 +5,13 @@ object is missing or was built for another ABI version, importing anything that 
 it raises ``GlsdetLibraryError``.
 """
 import ctypes as C
+import threading
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "lib", "libglsdet_hip.so")
 ABI_VERSION = 4
+CAPTURE_LOCK = threading.RLock()        # hipGraph captures are serialised across host threads
 
 F16, F32 = 0, 1
 ACT = {"none": 0, "silu": 1, "relu": 2, "lrelu": 3, "gelu": 4, "sigmoid": 5}

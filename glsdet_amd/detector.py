@@ -7,6 +7,7 @@ from typing import Dict, List, Optional, Tuple
 import numpy as np
 import torch
 
+from . import _lib
 from .engine import Engine, Plan, TView
 from .nets import build_forward
 
@@ -58,12 +59,16 @@ class HipDetector:
         eng.save_tune_cache()
         c.graph_stream = None
         if use_graph:
-            c.plan.run()                         # warm-up outside capture (lazy module load, attributes)
-            torch.cuda.synchronize()
-            c.graph_stream = torch.cuda.Stream(device=eng.device)
-            with torch.cuda.stream(c.graph_stream):
-                c.plan.capture(c.graph_stream)
-            torch.cuda.synchronize()
+            # one capture at a time, and no device-wide synchronisation around it: another host thread (a lane of
+            # the two-stage pipeline) may be capturing or launching -- a hipDeviceSynchronize issued while any
+            # stream captures invalidates that capture
+            with _lib.CAPTURE_LOCK:
+                c.plan.run()                     # warm-up outside capture (lazy module load, attributes)
+                torch.cuda.current_stream(eng.device).synchronize()
+                c.graph_stream = torch.cuda.Stream(device=eng.device)
+                with torch.cuda.stream(c.graph_stream):
+                    c.plan.capture(c.graph_stream)
+                c.graph_stream.synchronize()
         self._compiled[key] = c
         return c
 

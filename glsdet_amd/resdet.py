@@ -22,6 +22,7 @@ from typing import Dict, List, Optional, Sequence, Tuple
 import numpy as np
 import torch
 
+from . import _lib
 from .engine import Engine, F32, TView, fold_bn
 
 RESNET_BN_EPS = 1e-5
@@ -256,12 +257,16 @@ class HipGflDetector:
         eng.save_tune_cache()
         c.graph_stream = None
         if use_graph:
-            c.plan.run()
-            torch.cuda.synchronize()
-            c.graph_stream = torch.cuda.Stream(device=eng.device)
-            with torch.cuda.stream(c.graph_stream):
-                c.plan.capture(c.graph_stream)
-            torch.cuda.synchronize()
+            # one capture at a time, and no device-wide synchronisation around it: another host thread (a lane of
+            # the two-stage pipeline) may be capturing or launching -- a hipDeviceSynchronize issued while any
+            # stream captures invalidates that capture
+            with _lib.CAPTURE_LOCK:
+                c.plan.run()                     # warm-up outside capture (lazy module load, attributes)
+                torch.cuda.current_stream(eng.device).synchronize()
+                c.graph_stream = torch.cuda.Stream(device=eng.device)
+                with torch.cuda.stream(c.graph_stream):
+                    c.plan.capture(c.graph_stream)
+                c.graph_stream.synchronize()
         self._compiled[key] = c
         return c
 
