@@ -358,10 +358,10 @@ def main():
     all_ms = float(ms.sum())
     achieved = conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
     # HBM traffic per conv launch: PMC counters cannot be read from inside the benchmark; the
-    # newest committed rocprofv3 --pmc summary of this same command (tools/profile_round.sh ->
+    # latest committed rocprofv3 --pmc summary of this same command (tools/profile_round.sh ->
     # profiles/*/traffic.json, FETCH_SIZE doubled per the gfx950 correction) is reported.
     traffic = None
-    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "traffic.json")), key=os.path.getmtime)
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "traffic.json")))      # round tags sort by name: r01_b < ... < r01_h
     for cand in reversed(cands):
         with open(cand) as f:
             tj = json.load(f)
