@@ -237,6 +237,255 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const ConvArgs a, const 
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The same kernel with the weight tiles staged by LDS-DMA into a ring of RING taps (tile hints 8 / 9).
+// PMC of the register-staged form on a 3x3 128->128 layer: a workgroup lives 15 us for 1.9 us of MFMAs per
+// wave -- each tap (256 MFMA cycles) waits ~2000 cycles because the next tap's weight tile is requested one tap
+// ahead of an L2 round trip that takes several, and hipcc turns any deeper REGISTER ring into vmcnt(0) waits.
+// A `buffer_load ... lds` has no register destination: the wait is ours to count.  The tile of tap g+RING-1 is
+// requested when tap g starts (`s_waitcnt vmcnt(NI*(RING-2))` + raw `s_barrier`); rows are 128 bytes, unpadded
+// (a DMA writes 1 KiB of consecutive LDS), with the XOR swizzle slot = chunk ^ ((row >> 1) & 7) applied on the
+// source address and in the fragment read.  The patch keeps its register-staged, padded form.
+template <int N>
+__device__ __forceinline__ void halo_wait_vm_barrier() {
+  asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
+}
+__device__ __forceinline__ void halo_lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");       // never __syncthreads(): it would drain the ring (vmcnt(0))
+}
+
+template <typename T, typename TO, int CO_T, int KS, int RING>
+__global__ __launch_bounds__(256) void conv_halo_ring_kernel(const ConvArgs a, const int tiles_x, const int tiles_y) {
+  constexpr int TH = 8, TW = 16, WCO = 2;
+  constexpr int KB = 128, RS = KB + 16;
+  constexpr int VEC = 16 / (int)sizeof(T);
+  constexpr int KE = KB / (int)sizeof(T);
+  constexpr int PX_T = TH * TW;
+  constexpr int PH = HaloGeom<KS, TH, TW>::PH, PW = HaloGeom<KS, TH, TW>::PW;
+  constexpr int NP = HaloGeom<KS, TH, TW>::NP;
+  constexpr int WPX = 4 / WCO;
+  constexpr int WT_CO = CO_T / WCO, WT_PX = PX_T / WPX;
+  constexpr int TM = WT_CO / 32, TN = WT_PX / 32;
+  constexpr int A_BYTES = CO_T * KB;               // one tap's weight tile, unpadded rows
+  constexpr int NI = CO_T / 32;                    // DMA instructions per wave and tap (8 rows each)
+  constexpr int PATCH_OFF = RING * A_BYTES;
+  static_assert(RING >= 3 && TM >= 1 && TN >= 1, "ring");
+
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int tile;
+  {
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, local = bid >> 3;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+  }
+  const int co0 = (tile % a.n_co_tiles) * CO_T;
+  int rest = tile / a.n_co_tiles;
+  const int tx0 = (rest % tiles_x) * TW;
+  rest /= tiles_x;
+  const int ty0 = (rest % tiles_y) * TH;
+  const int img = rest / tiles_y;
+
+  const int kc = tid & 7;
+  const auto xrs = gls_make_rsrc(a.x_lo, a.x_bytes);
+  const auto wrs = gls_make_rsrc(a.w, a.w_bytes);
+  // DMA source offsets: instruction q of this wave fills rows 8 * (wave + 4q) .. +7; lane -> (row, slot)
+  unsigned wd[NI];
+#pragma unroll
+  for (int q = 0; q < NI; ++q) {
+    const int row = 8 * (wave + 4 * q) + (lane >> 3);
+    const int ch = (lane & 7) ^ ((row >> 1) & 7);
+    const bool ok = (co0 + row) < a.cout_pad;
+    wd[q] = ok ? (unsigned)(((co0 + row) * a.kpad + ch * VEC) * (int)sizeof(T)) : GLS_OOB;
+  }
+  unsigned poff[NP];
+  constexpr int pad = KS / 2;
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    const int q = tid + i * 256;
+    const int pp = q >> 3;
+    const int py = pp / PW, px = pp - py * PW;
+    const int hi = ty0 - pad + py, wi = tx0 - pad + px;
+    const bool ok = pp < PH * PW && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
+    poff[i] = ok ? a.x_off + (unsigned)(((long)img * a.x_sn + (long)hi * a.x_sh + (long)wi * a.x_sw + kc * VEC) * (long)sizeof(T))
+                 : GLS_OOB;
+  }
+  u32x4 rp[NP];
+  const int nchunks = a.Cin / KE;
+  constexpr int ntaps = KS * KS;
+  const int nsteps = nchunks * ntaps;
+
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  // weight tile of global tap g (chunk g / ntaps, tap g % ntaps) -> ring slot g % RING; beyond the end: zeros
+  int dg = 0, dcc = 0, dtap = 0;                   // DMA cursor
+  auto dma_next = [&]() __attribute__((always_inline)) {
+    const bool live = dg < nsteps;
+    const unsigned add = (unsigned)((dcc * KE + dtap * a.Cin) * (int)sizeof(T));
+    unsigned char* dst = smem + (dg % RING) * A_BYTES + wave * 1024;
+#pragma unroll
+    for (int q = 0; q < NI; ++q) {
+      const unsigned v = (live && wd[q] != GLS_OOB) ? wd[q] + add : GLS_OOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lds_ptr)(dst + q * 4096), 16, (int)v, 0, 0, 0);
+    }
+    ++dg;
+    if (++dtap == ntaps) { dtap = 0; ++dcc; }
+  };
+  auto load_patch = [&](int cc) __attribute__((always_inline)) {
+    const unsigned coff = (unsigned)(cc * KE * (int)sizeof(T));
+#pragma unroll
+    for (int i = 0; i < NP; ++i) rp[i] = gls_buf_load16(xrs, poff[i] + coff);
+  };
+  auto store_patch = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const int q = tid + i * 256;
+      if (q < PH * PW * 8) *reinterpret_cast<u32x4*>(smem + PATCH_OFF + (q >> 3) * RS + (q & 7) * 16) = rp[i];
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+  const int wco = wave % WCO, wpx = wave / WCO;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int a_row = (wco * WT_CO + l31) * KB;      // + i * 32 * KB: the swizzle term (row >> 1) & 7 depends on l31 only
+  int a_sw[KB / 32];
+#pragma unroll
+  for (int kk = 0; kk < KB / 32; ++kk) a_sw[kk] = ((2 * kk + lh) ^ ((l31 >> 1) & 7)) << 4;
+  int b_off[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int pix = wpx * WT_PX + j * 32 + l31;
+    int oy, ox;
+    pix_to_xy16<PW>(pix, oy, ox);
+    b_off[j] = PATCH_OFF + (oy * PW + ox) * RS + lh * 16;
+  }
+
+  load_patch(0);
+#pragma unroll
+  for (int g = 0; g < RING - 1; ++g) dma_next();
+  store_patch();                                   // (the compiler waits for the patch registers here)
+
+  int g = 0;                                       // global tap on the compute side
+  auto mma_tap = [&](int tap_off) __attribute__((always_inline)) {
+    const unsigned char* sA = smem + (g % RING) * A_BYTES + a_row;
+#pragma unroll
+    for (int kk = 0; kk < KB / 32; ++kk) {
+      u32x4 af[TM], bf[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const u32x4*>(sA + i * 32 * KB + a_sw[kk]);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const u32x4*>(smem + b_off[j] + tap_off + kk * 32);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) MMA<T>::run(af[i], bf[j], acc[i][j]);
+    }
+  };
+  for (int cc = 0; cc < nchunks; ++cc) {
+    int tap_off = 0, ts = 0;
+    for (int tap = 0; tap < ntaps - 1; ++tap) {     // every tap but the chunk's last
+      halo_wait_vm_barrier<NI * (RING - 2)>();      // tap g landed in every wave (at tap 0 also: the patch is visible); slot g-1 is free
+      dma_next();
+      mma_tap(tap_off);
+      ++g;
+      ++ts;
+      tap_off += (ts == KS) ? (PW - KS + 1) * RS : RS;
+      ts = (ts == KS) ? 0 : ts;
+    }
+    halo_wait_vm_barrier<NI * (RING - 2)>();
+    dma_next();
+    const bool more = cc + 1 < nchunks;             // last tap of the chunk; another chunk follows: exchange the patch
+    if (more) load_patch(cc + 1);
+    mma_tap(tap_off);                               // (ONE instance of the MFMA block for both cases: no accumulator copies)
+    ++g;
+    if (more) {
+      halo_lds_barrier();                           // every wave is done with the old patch
+      store_patch();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the next tap's barrier publishes it
+    }
+  }
+  halo_wait_vm_barrier<0>();                        // the zero fills of the tail have landed; all waves done reading
+
+  constexpr int ORS = CO_T * (int)sizeof(TO) + 16;
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) {
+      const int co_l = wco * WT_CO + i * 32 + 8 * gq + 4 * lh;
+      f32x4 sc = {0.f, 0.f, 0.f, 0.f}, bi = {0.f, 0.f, 0.f, 0.f};
+      if (co0 + co_l < a.cout_pad) {
+        sc = *reinterpret_cast<const f32x4*>(a.scale + co0 + co_l);
+        bi = *reinterpret_cast<const f32x4*>(a.bias + co0 + co_l);
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int px_l = wpx * WT_PX + j * 32 + l31;
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = apply_act<T>(acc[i][j][4 * gq + e] * sc[e] + bi[e], a.act);
+        store4(smem + px_l * ORS + co_l * (int)sizeof(TO), v, (TO*)nullptr);
+      }
+    }
+  }
+  __syncthreads();
+  constexpr int VO = 16 / (int)sizeof(TO);
+  constexpr int OCPR = CO_T / VO;
+  for (int q = tid; q < PX_T * OCPR; q += 256) {
+    const int px_l = q / OCPR, cq = q - px_l * OCPR;
+    int oy, ox;
+    pix_to_xy16<PW>(px_l, oy, ox);
+    const int ho = ty0 + oy, wo = tx0 + ox, co = co0 + cq * VO;
+    if (ho < a.Ho && wo < a.Wo && co < a.Cout) {
+      u32x4 v = *reinterpret_cast<const u32x4*>(smem + px_l * ORS + cq * 16);
+      if (a.res) {
+        const long ro = (long)img * a.r_sn + (long)ho * a.r_sh + (long)wo * a.r_sw + co;
+        v = add_chunk(v, *reinterpret_cast<const u32x4*>(a.res + ro * (long)sizeof(TO)), (TO*)nullptr, a.act_post);
+      }
+      const long yo = (long)img * a.y_sn + (long)ho * a.y_sh + (long)wo * a.y_sw + co;
+      *reinterpret_cast<u32x4*>(a.y + yo * (long)sizeof(TO)) = v;
+    }
+  }
+}
+
+template <typename T, typename TO, int CO_T, int KS, int RING>
+static int launch_halo_ring(const ConvArgs& a, hipStream_t st) {
+  constexpr int PH = 8 + KS - 1, PW = 16 + KS - 1;
+  constexpr int stage = RING * CO_T * 128 + PH * PW * 144;
+  constexpr int epi = 128 * (CO_T * (int)sizeof(TO) + 16);
+  constexpr int lds = stage > epi ? stage : epi;
+  auto kern = conv_halo_ring_kernel<T, TO, CO_T, KS, RING>;
+  static bool attr_set = false;
+  if (!attr_set && lds > 64 * 1024) {
+    GLS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    attr_set = true;
+  }
+  ConvArgs b = a;
+  b.n_co_tiles = (a.Cout + CO_T - 1) / CO_T;
+  const int tiles_x = (a.Wo + 15) / 16, tiles_y = (a.Ho + 7) / 8;
+  const long grid = (long)b.n_co_tiles * tiles_x * tiles_y * a.N;
+  if (grid <= 0 || grid > 0x7fffffffL) GLS_FAIL(GLSDET_E_ARG, "conv2d(halo ring): grid %ld out of range", grid);
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, st, b, tiles_x, tiles_y);
+  GLS_HIP(hipGetLastError());
+  return 0;
+}
+
+template <typename T, typename TO, int CO_T>
+static int halo_ring_by_ks(const ConvArgs& a, hipStream_t st) {
+  switch (a.R) {
+    case 3: return launch_halo_ring<T, TO, CO_T, 3, 3>(a, st);
+    case 5: return launch_halo_ring<T, TO, CO_T, 5, 3>(a, st);
+    case 7: return launch_halo_ring<T, TO, CO_T, 7, 3>(a, st);
+  }
+  GLS_FAIL(GLSDET_E_ARG, "conv2d(halo ring): unsupported kernel size %d", a.R);
+}
+
 template <typename T, typename TO, int CO_T, int WCO, int KS, int TH, int TW>
 static int launch_halo(const ConvArgs& a, hipStream_t st) {
   constexpr int PH = TH + KS - 1, PW = TW + KS - 1;
@@ -272,7 +521,7 @@ static int halo_by_ks(const ConvArgs& a, hipStream_t st) {
 // Returns 1 when the halo kernel does not apply (caller falls back to the generic kernel),
 // 0 when `op` was filled in.
 int conv_halo_try(const ConvArgs& a, int xdt, int ydt, int hint, OpRecord* op) {
-  if (hint == 1 || hint == 3 || hint > 5) return 1;          // hint 1 / explicit tile = the generic kernel
+  if (hint == 1 || hint == 3 || (hint > 5 && hint != 8 && hint != 9)) return 1;          // hint 1 / explicit tile = the generic kernel
   if (a.stride != 1 || a.R != a.S || (a.R != 3 && a.R != 5 && a.R != 7) || a.pad != a.R / 2) return 1;
   const int es = dtype_size(xdt);
   if ((a.Cin * es) % 128) return 1;
@@ -280,15 +529,21 @@ int conv_halo_try(const ConvArgs& a, int xdt, int ydt, int hint, OpRecord* op) {
   // wasted MFMA work on partial tiles: prefer the flat-pixel kernel when it is large
   const long tiles = (long)((a.Ho + 7) / 8) * ((a.Wo + 15) / 16);
   const double waste = (double)tiles * 128.0 / ((double)a.Ho * a.Wo);
-  if (hint != 2 && hint != 4 && hint != 5 && waste > 1.30) return 1;      // hint 2 / 4 / 5 = force the halo kernel
-  const int co_t = (a.cout_pad <= 64 || hint == 5) ? 64 : 128;     // hint 5: 64-row cout tiles also for wide layers
+  if (hint != 2 && hint != 4 && hint != 5 && hint != 8 && hint != 9 && waste > 1.30) return 1;      // a hint forces the halo kernel
+  const bool ring = hint == 8 || hint == 9;        // weight tiles by LDS-DMA into a ring: 8 = 64-row, 9 = 128-row cout tiles
+  if (hint == 9 && a.cout_pad <= 64) return 1;
+  const int co_t = (a.cout_pad <= 64 || hint == 5 || hint == 8) ? 64 : 128;     // hint 5 / 8: 64-row cout tiles also for wide layers
   const bool wpriv = hint == 4;                     // wave-private weight staging (128-row cout tile only)
   if (wpriv && co_t != 128) return 1;
   char nm[96];
-  snprintf(nm, sizeof nm, "conv_halo%s<%s,%dx8x16> %dx%d s1 cin%d cout%d", wpriv ? "_wp" : "", xdt ? "f32" : "f16", co_t, a.R,
+  snprintf(nm, sizeof nm, "conv_halo%s<%s,%dx8x16> %dx%d s1 cin%d cout%d", wpriv ? "_wp" : (ring ? "_ring" : ""), xdt ? "f32" : "f16", co_t, a.R,
            a.S, a.Cin, a.Cout);
   op->name = nm;
-  op->launch = [a, co_t, xdt, wpriv](hipStream_t st) -> int {
+  op->launch = [a, co_t, xdt, wpriv, ring](hipStream_t st) -> int {
+    if (ring) {
+      if (xdt == GLSDET_F16) return co_t == 128 ? halo_ring_by_ks<f16, f16, 128>(a, st) : halo_ring_by_ks<f16, f16, 64>(a, st);
+      return co_t == 128 ? halo_ring_by_ks<float, float, 128>(a, st) : halo_ring_by_ks<float, float, 64>(a, st);
+    }
     if (wpriv) return xdt == GLSDET_F16 ? halo_by_ks<f16, f16, 128, 4>(a, st) : halo_by_ks<float, float, 128, 4>(a, st);
     if (xdt == GLSDET_F16) return co_t == 128 ? halo_by_ks<f16, f16, 128, 2>(a, st) : halo_by_ks<f16, f16, 64, 2>(a, st);
     return co_t == 128 ? halo_by_ks<float, float, 128, 2>(a, st) : halo_by_ks<float, float, 64, 2>(a, st);
