@@ -480,8 +480,8 @@ template <typename T, typename TO, int CO_T>
 static int halo_ring_by_ks(const ConvArgs& a, hipStream_t st) {
   switch (a.R) {
     case 3: return launch_halo_ring<T, TO, CO_T, 3, 3>(a, st);
-    case 5: return launch_halo_ring<T, TO, CO_T, 5, 3>(a, st);
-    case 7: return launch_halo_ring<T, TO, CO_T, 7, 3>(a, st);
+    case 5: return launch_halo_ring<T, TO, CO_T, 5, CO_T == 64 ? 4 : 3>(a, st);   // 64 rows: a fourth slot costs no workgroup per CU
+    case 7: return launch_halo_ring<T, TO, CO_T, 7, CO_T == 64 ? 4 : 3>(a, st);
   }
   GLS_FAIL(GLSDET_E_ARG, "conv2d(halo ring): unsupported kernel size %d", a.R);
 }
