@@ -248,7 +248,8 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const ConvArgs a, const 
 // source address and in the fragment read.  The patch keeps its register-staged, padded form.
 template <int N>
 __device__ __forceinline__ void halo_wait_vm_barrier() {
-  asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
+  // lgkmcnt(0): this wave's own LDS writes (the patch it just stored) are done before it signals the barrier
+  asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
 }
 __device__ __forceinline__ void halo_lds_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");       // never __syncthreads(): it would drain the ring (vmcnt(0))
