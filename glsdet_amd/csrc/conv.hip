@@ -556,7 +556,8 @@ static int build_conv_op(const glsdet_conv_desc* d, int hint, OpRecord& op) {
   const int xdt = x.dtype, ydt = y.dtype;
   // tile_hint: 0 auto, 1 generic kernel, 2 halo kernel, 4 halo kernel with wave-private weight staging,
   // 5 halo kernel with 64-row cout tiles also for wide layers,
-  // 6 / 7 halo kernel with LDS-DMA staging (64- / 128-row cout tiles), 3 weight-stationary 1x1 kernel,
+  // 8 / 9 halo kernel with the weight tiles in an LDS-DMA ring, 6 / 7 persistent LDS-DMA halo kernel (64- / 128-row
+  // cout tiles), 3 weight-stationary 1x1 kernel,
   // else co<<16|px (generic)
   if (hint == 3) {
     if (conv1x1_ws_try(a, xdt, ydt, &op) == 0) return 0;
