@@ -38,9 +38,7 @@ def engines():
     return {"f32": Engine("f32"), "f16": Engine("f16")}
 
 
-@pytest.mark.parametrize("mode", ["f16", "f32"])
-@pytest.mark.parametrize("case", _cases(40, 7), ids=lambda c: "n%d_ci%d_co%d_k%d_s%d_%dx%d_%s_r%d_e%d" % c)
-def test_conv2d_random_problem_all_variants(engines, mode, case):
+def _run_case(engines, mode, case, hints):
     from glsdet_amd._lib import GlsdetError
     n_img, cin, cout, k, stride, h, w, act, res, embed = case
     eng = engines[mode]
@@ -56,7 +54,7 @@ def test_conv2d_random_problem_all_variants(engines, mode, case):
     ref = act_fn(pre) if res == 0 else (act_fn(pre) + r(rt) if res == 1 else act_fn(pre + r(rt)))
     pk = eng.pack_conv([(wt, scale, bias)], cin)
     ran = 0
-    for hint in HINTS:
+    for hint in hints:
         xv = _to_view(eng, x, embed=(cin + 16, 8) if embed else None)
         rv = _to_view(eng, rt) if res else None
         try:
@@ -68,3 +66,33 @@ def test_conv2d_random_problem_all_variants(engines, mode, case):
         _cmp(out.to_nchw(cout), ref, TOL[mode] * (2 if act in ("gelu", "sigmoid") else 1), "hint %x" % hint)
         ran += 1
     assert ran >= 2
+
+
+@pytest.mark.parametrize("mode", ["f16", "f32"])
+@pytest.mark.parametrize("case", _cases(40, 7), ids=lambda c: "n%d_ci%d_co%d_k%d_s%d_%dx%d_%s_r%d_e%d" % c)
+def test_conv2d_random_problem_all_variants(engines, mode, case):
+    _run_case(engines, mode, case, HINTS)
+
+
+def _kxk_cases(n, seed):
+    """stride-1 k x k problems with several channel chunks, several tiles per image and ragged borders: the
+    territory of the halo kernels (register-staged, wave-private, LDS-DMA persistent, LDS-DMA weight ring)"""
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(n):
+        k = int(rng.choice([3, 3, 3, 5, 7]))
+        cin = int(rng.choice([64, 128, 192, 256, 320]))
+        cout = int(rng.choice([32, 64, 72, 128, 136, 256, 264]))
+        h, w = int(rng.integers(9, 70)), int(rng.integers(17, 90))
+        n_img = int(rng.choice([1, 2, 4]))
+        act = str(rng.choice(["silu", "relu", "none"]))
+        res = int(rng.choice([0, 1, 2]))
+        embed = bool(rng.integers(0, 2))
+        out.append((n_img, cin, cout, k, 1, h, w, act, res, embed))
+    return out
+
+
+@pytest.mark.parametrize("mode", ["f16", "f32"])
+@pytest.mark.parametrize("case", _kxk_cases(16, 11), ids=lambda c: "n%d_ci%d_co%d_k%d_s%d_%dx%d_%s_r%d_e%d" % c)
+def test_conv2d_random_kxk_problem_halo_family(engines, mode, case):
+    _run_case(engines, mode, case, [0, 1, 2, 4, 5, 6, 7, 8, 9])
