@@ -319,18 +319,25 @@ __global__ __launch_bounds__(256) void conv_halo_ring_kernel(const ConvArgs a, c
 
   typedef __attribute__((address_space(3))) void* lds_ptr;
   // weight tile of global tap g (chunk g / ntaps, tap g % ntaps) -> ring slot g % RING; beyond the end: zeros
-  int dg = 0, dcc = 0, dtap = 0;                   // DMA cursor
+  // DMA cursor, all scalar: ring slot, tap inside the chunk, byte offset of the tap's weights.  Beyond the last tap the
+  // offset becomes 2^31: valid rows then read out of range (zeros); rows that are out of range themselves wrap to a
+  // small offset and fetch garbage into weight rows >= cout_pad, whose outputs are never stored -- no select, no branch.
+  int dg = 0, dtap = 0, dslot = 0;
+  unsigned dadd = 0;
+  const unsigned tap_bytes = (unsigned)(a.Cin * (int)sizeof(T));
+  const unsigned chunk_fix = (unsigned)(KE * (int)sizeof(T)) - (unsigned)ntaps * tap_bytes;   // (mod 2^32)
   auto dma_next = [&]() __attribute__((always_inline)) {
-    const bool live = dg < nsteps;
-    const unsigned add = (unsigned)((dcc * KE + dtap * a.Cin) * (int)sizeof(T));
-    unsigned char* dst = smem + (dg % RING) * A_BYTES + wave * 1024;
+    unsigned char* dst = smem + dslot * A_BYTES + wave * 1024;
 #pragma unroll
-    for (int q = 0; q < NI; ++q) {
-      const unsigned v = (live && wd[q] != GLS_OOB) ? wd[q] + add : GLS_OOB;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lds_ptr)(dst + q * 4096), 16, (int)v, 0, 0, 0);
+    for (int q = 0; q < NI; ++q)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lds_ptr)(dst + q * 4096), 16, (int)(wd[q] + dadd), 0, 0, 0);
+    dslot = dslot + 1 == RING ? 0 : dslot + 1;
+    dadd += tap_bytes;
+    if (++dtap == ntaps) {
+      dtap = 0;
+      dadd += chunk_fix;
     }
-    ++dg;
-    if (++dtap == ntaps) { dtap = 0; ++dcc; }
+    if (++dg >= nsteps) dadd = GLS_OOB;
   };
   auto load_patch = [&](int cc) __attribute__((always_inline)) {
     const unsigned coff = (unsigned)(cc * KE * (int)sizeof(T));
@@ -373,9 +380,9 @@ __global__ __launch_bounds__(256) void conv_halo_ring_kernel(const ConvArgs a, c
   for (int g = 0; g < RING - 1; ++g) dma_next();
   store_patch();                                   // (the compiler waits for the patch registers here)
 
-  int g = 0;                                       // global tap on the compute side
+  int g = 0;                                       // ring slot of the tap being multiplied
   auto mma_tap = [&](int tap_off) __attribute__((always_inline)) {
-    const unsigned char* sA = smem + (g % RING) * A_BYTES + a_row;
+    const unsigned char* sA = smem + g * A_BYTES + a_row;
 #pragma unroll
     for (int kk = 0; kk < KB / 32; ++kk) {
       u32x4 af[TM], bf[TN];
@@ -395,7 +402,7 @@ __global__ __launch_bounds__(256) void conv_halo_ring_kernel(const ConvArgs a, c
       halo_wait_vm_barrier<NI * (RING - 2)>();      // tap g landed in every wave (at tap 0 also: the patch is visible); slot g-1 is free
       dma_next();
       mma_tap(tap_off);
-      ++g;
+      g = g + 1 == RING ? 0 : g + 1;
       ++ts;
       tap_off += (ts == KS) ? (PW - KS + 1) * RS : RS;
       ts = (ts == KS) ? 0 : ts;
@@ -405,7 +412,7 @@ __global__ __launch_bounds__(256) void conv_halo_ring_kernel(const ConvArgs a, c
     const bool more = cc + 1 < nchunks;             // last tap of the chunk; another chunk follows: exchange the patch
     if (more) load_patch(cc + 1);
     mma_tap(tap_off);                               // (ONE instance of the MFMA block for both cases: no accumulator copies)
-    ++g;
+    g = g + 1 == RING ? 0 : g + 1;
     if (more) {
       halo_lds_barrier();                           // every wave is done with the old patch
       store_patch();
