@@ -144,12 +144,11 @@ __global__ __launch_bounds__(256) void conv1x1_ws_kernel(const ConvArgs a, const
         for (int g = 0; g < 4; ++g) {
           const int co_l = wco * WT_CO + i * 32 + 8 * g + 4 * lh;
           const f32x4 sc = scv[i][g], bi = biv[i][g];
-          float v[4];
+          const f32x4 xv = {acc[i][4 * g], acc[i][4 * g + 1], acc[i][4 * g + 2], acc[i][4 * g + 3]};
+          const f32x4 yv = scale_bias_act4<T>(xv, sc, bi, a.act);
+          const float v[4] = {yv[0], yv[1], yv[2], yv[3]};
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            v[e] = apply_act<T>(acc[i][4 * g + e] * sc[e] + bi[e], a.act);
-            acc[i][4 * g + e] = 0.0f;
-          }
+          for (int e = 0; e < 4; ++e) acc[i][4 * g + e] = 0.0f;
           store4(sE + (wpx * 32 + l31) * ORS + co_l * (int)sizeof(T), v, (T*)nullptr);
         }
       }

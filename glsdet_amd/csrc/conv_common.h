@@ -87,6 +87,29 @@ __device__ __forceinline__ float apply_act(float v, int act) {
   return v;
 }
 
+// four outputs at once: scale, bias and activation on 4-vectors, so that hipcc can use the packed fp32 ALU
+// (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32: two lanes of work per instruction).  Same operations in the same
+// order as apply_act per element: results are bit-identical.
+template <typename T>
+__device__ __forceinline__ f32x4 scale_bias_act4(f32x4 x, f32x4 sc, f32x4 bi, int act) {
+  x = x * sc + bi;
+  if (act == GLSDET_ACT_SILU && sizeof(T) == 2) {
+    const f32x4 t = x * -1.44269504088896340736f;              // exp(-v) = exp2(-v * log2 e), as __expf does
+    f32x4 e = {__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1]), __builtin_amdgcn_exp2f(t[2]), __builtin_amdgcn_exp2f(t[3])};
+    e = e + 1.0f;
+    const f32x4 r = {__builtin_amdgcn_rcpf(e[0]), __builtin_amdgcn_rcpf(e[1]), __builtin_amdgcn_rcpf(e[2]), __builtin_amdgcn_rcpf(e[3])};
+    return x * r;
+  }
+  if (act == GLSDET_ACT_RELU) {
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    return __builtin_elementwise_max(x, z);
+  }
+  if (act == GLSDET_ACT_NONE) return x;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) x[e] = apply_act<T>(x[e], act);
+  return x;
+}
+
 // pack 4 fp32 -> 4 TO, stored at p (8 B for f16, 16 B for f32)
 __device__ __forceinline__ void store4(unsigned char* p, const float (&v)[4], f16*) {
   f16x4 h = {(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};

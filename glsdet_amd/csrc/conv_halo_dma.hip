@@ -277,12 +277,11 @@ __global__ __launch_bounds__(64 * NWV) void conv_halo_dma_kernel(const ConvArgs 
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
           const int px_l = wpx * WT_PX + j * 32 + l31;
-          float v[4];
+          const f32x4 xv = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+          const f32x4 yv = scale_bias_act4<T>(xv, sc, bi, a.act);
+          const float v[4] = {yv[0], yv[1], yv[2], yv[3]};
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            v[e] = apply_act<T>(acc[i][j][4 * g + e] * sc[e] + bi[e], a.act);
-            acc[i][j][4 * g + e] = 0.0f;
-          }
+          for (int e = 0; e < 4; ++e) acc[i][j][4 * g + e] = 0.0f;
           store4(sE + px_l * ORS + co_l * (int)sizeof(TO), v, (TO*)nullptr);
         }
       }
