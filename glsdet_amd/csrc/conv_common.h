@@ -155,6 +155,65 @@ __device__ __forceinline__ void pix_to_xy16(int pix, int& oy, int& ox) {
 }
 
 
+// Store phase of the 8 x 16 pixel-tile kernels: the staged tile (rows of ORS bytes in LDS) -> global, 16-byte chunks,
+// optional residual.  A thread's chunks are 256 / OCPR pixels apart -- one or two tile rows -- so its addresses advance
+// by a constant: the 64-bit offsets are built once and stepped with one add per chunk (the per-chunk multiplies were
+// ~10 vector instructions each in kernels that PMC shows issue bound), and the loop is fully unrolled.
+template <typename TO, int CO_T, int PW>
+__device__ __forceinline__ void halo_store_tile(const unsigned char* stile, const ConvArgs& a, int img, int ty0, int tx0, int co0,
+                                                int tid) {
+  constexpr int PX_T = 128, ORS = CO_T * (int)sizeof(TO) + 16;
+  constexpr int VO = 16 / (int)sizeof(TO);
+  constexpr int OCPR = CO_T / VO;                 // chunks per pixel
+  constexpr int PXS = 256 / OCPR;                 // pixels between two chunks of one thread (a multiple of 16)
+  if constexpr (PXS % 16 != 0) {                  // fp32 output with 128-row tiles: 8 pixels apart, plain form
+    for (int q = tid; q < PX_T * OCPR; q += 256) {
+      const int px_l = q / OCPR, cq = q - px_l * OCPR;
+      int oy, ox;
+      pix_to_xy16<PW>(px_l, oy, ox);
+      const int ho = ty0 + oy, wo = tx0 + ox, co = co0 + cq * VO;
+      if (ho < a.Ho && wo < a.Wo && co < a.Cout) {
+        u32x4 v = *reinterpret_cast<const u32x4*>(stile + px_l * ORS + cq * 16);
+        if (a.res) {
+          const long ro = (long)img * a.r_sn + (long)ho * a.r_sh + (long)wo * a.r_sw + co;
+          v = add_chunk(v, *reinterpret_cast<const u32x4*>(a.res + ro * (long)sizeof(TO)), (TO*)nullptr, a.act_post);
+        }
+        const long yo = (long)img * a.y_sn + (long)ho * a.y_sh + (long)wo * a.y_sw + co;
+        *reinterpret_cast<u32x4*>(a.y + yo * (long)sizeof(TO)) = v;
+      }
+    }
+    return;
+  }
+  constexpr int NCH = PX_T / (PXS > 0 ? PXS : 1); // chunks per thread
+  constexpr int RSTEP = PXS / 16;                 // tile rows between them
+  const int cq = tid % OCPR, pxl0 = tid / OCPR;   // first pixel of this thread: pxl0 < PXS
+  const int co = co0 + cq * VO;
+  const int m = pxl0 & 15, oy0 = pxl0 >> 4;
+  constexpr int ROT = (16 - (PW & 15)) & 15;      // pix_to_xy16: odd rows are rotated
+  const int ox_e = m, ox_o = (m + ROT) & 15;
+  const bool cok = co < a.Cout;
+  const long ybase = (long)img * a.y_sn + (long)(ty0 + oy0) * a.y_sh + (long)tx0 * a.y_sw + co;
+  const long rbase = a.res ? (long)img * a.r_sn + (long)(ty0 + oy0) * a.r_sh + (long)tx0 * a.r_sw + co : 0;
+  const long y_e = ybase + (long)ox_e * a.y_sw, y_o = ybase + (long)ox_o * a.y_sw;
+  const long r_e = rbase + (long)ox_e * a.r_sw, r_o = rbase + (long)ox_o * a.r_sw;
+  const long ystep = (long)RSTEP * a.y_sh, rstep = (long)RSTEP * a.r_sh;
+#pragma unroll
+  for (int k = 0; k < NCH; ++k) {
+    const int oy = oy0 + k * RSTEP;
+    const bool odd = ((oy0 + k * RSTEP) & 1) != 0;            // RSTEP even: the parity never changes
+    const int ox = odd ? ox_o : ox_e;
+    if (ty0 + oy < a.Ho && tx0 + ox < a.Wo && cok) {
+      u32x4 v = *reinterpret_cast<const u32x4*>(stile + (pxl0 + k * PXS) * ORS + cq * 16);
+      if (a.res) {
+        const long ro = (odd ? r_o : r_e) + k * rstep;
+        v = add_chunk(v, *reinterpret_cast<const u32x4*>(a.res + ro * (long)sizeof(TO)), (TO*)nullptr, a.act_post);
+      }
+      const long yo = (odd ? y_o : y_e) + k * ystep;
+      *reinterpret_cast<u32x4*>(a.y + yo * (long)sizeof(TO)) = v;
+    }
+  }
+}
+
 // host-side dispatch of the halo kernel (conv_halo.hip); returns 1 if it does not apply
 int conv_halo_try(const ConvArgs& a, int xdt, int ydt, int hint, OpRecord* op);
 // the same problem class with LDS-DMA staging (conv_halo_dma.hip), tile_hint 6 / 7; returns 1 if it does not apply

@@ -218,23 +218,7 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const ConvArgs a, const 
     }
   }
   __syncthreads();
-  constexpr int VO = 16 / (int)sizeof(TO);
-  constexpr int OCPR = CO_T / VO;
-  for (int q = tid; q < PX_T * OCPR; q += 256) {
-    const int px_l = q / OCPR, cq = q - px_l * OCPR;
-    int oy, ox;
-    pix_to_xy16<PW>(px_l, oy, ox);
-    const int ho = ty0 + oy, wo = tx0 + ox, co = co0 + cq * VO;
-    if (ho < a.Ho && wo < a.Wo && co < a.Cout) {
-      u32x4 v = *reinterpret_cast<const u32x4*>(smem + px_l * ORS + cq * 16);
-      if (a.res) {
-        const long ro = (long)img * a.r_sn + (long)ho * a.r_sh + (long)wo * a.r_sw + co;
-        v = add_chunk(v, *reinterpret_cast<const u32x4*>(a.res + ro * (long)sizeof(TO)), (TO*)nullptr, a.act_post);
-      }
-      const long yo = (long)img * a.y_sn + (long)ho * a.y_sh + (long)wo * a.y_sw + co;
-      *reinterpret_cast<u32x4*>(a.y + yo * (long)sizeof(TO)) = v;
-    }
-  }
+  halo_store_tile<TO, CO_T, PW>(smem, a, img, ty0, tx0, co0, tid);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -443,23 +427,7 @@ __global__ __launch_bounds__(256) void conv_halo_ring_kernel(const ConvArgs a, c
     }
   }
   __syncthreads();
-  constexpr int VO = 16 / (int)sizeof(TO);
-  constexpr int OCPR = CO_T / VO;
-  for (int q = tid; q < PX_T * OCPR; q += 256) {
-    const int px_l = q / OCPR, cq = q - px_l * OCPR;
-    int oy, ox;
-    pix_to_xy16<PW>(px_l, oy, ox);
-    const int ho = ty0 + oy, wo = tx0 + ox, co = co0 + cq * VO;
-    if (ho < a.Ho && wo < a.Wo && co < a.Cout) {
-      u32x4 v = *reinterpret_cast<const u32x4*>(smem + px_l * ORS + cq * 16);
-      if (a.res) {
-        const long ro = (long)img * a.r_sn + (long)ho * a.r_sh + (long)wo * a.r_sw + co;
-        v = add_chunk(v, *reinterpret_cast<const u32x4*>(a.res + ro * (long)sizeof(TO)), (TO*)nullptr, a.act_post);
-      }
-      const long yo = (long)img * a.y_sn + (long)ho * a.y_sh + (long)wo * a.y_sw + co;
-      *reinterpret_cast<u32x4*>(a.y + yo * (long)sizeof(TO)) = v;
-    }
-  }
+  halo_store_tile<TO, CO_T, PW>(smem, a, img, ty0, tx0, co0, tid);
 }
 
 template <typename T, typename TO, int CO_T, int KS, int RING>
