@@ -91,8 +91,8 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
       hi0[i] = wi0[i] = 0;
       boff[i] = (int)((long)pp * a.x_sw);
     } else {
-      const int n = pp / HoWo, rem = pp - n * HoWo;
-      const int ho = rem / a.Wo, wo = rem - ho * a.Wo;
+      const int n = gls_div(pp, a.howo_mul, a.howo_sh), rem = pp - n * HoWo;
+      const int ho = gls_div(rem, a.wo_mul, a.wo_sh), wo = rem - ho * a.Wo;
       hi0[i] = ho * a.stride - a.pad;
       wi0[i] = wo * a.stride - a.pad;
       boff[i] = (int)((long)n * a.x_sn + (long)hi0[i] * a.x_sh + (long)wi0[i] * a.x_sw);
@@ -287,10 +287,10 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
       if (p < a.M && co < a.Cout) {
         u32x4 v = *reinterpret_cast<const u32x4*>(smem + px_l * ORS + cc * 16);
         if (a.res) {
-          const long ro = gls_pix_off(p, HoWo, a.Wo, a.r_sn, a.r_sh, a.r_sw, a.r_lin) + co;
+          const long ro = gls_pix_off(p, HoWo, a.Wo, a.r_sn, a.r_sh, a.r_sw, a.r_lin, a) + co;
           v = add_chunk(v, *reinterpret_cast<const u32x4*>(a.res + ro * (long)sizeof(TO)), (TO*)nullptr, a.act_post);
         }
-        const long yo = gls_pix_off(p, HoWo, a.Wo, a.y_sn, a.y_sh, a.y_sw, a.y_lin) + co;
+        const long yo = gls_pix_off(p, HoWo, a.Wo, a.y_sn, a.y_sh, a.y_sw, a.y_lin, a) + co;
         *reinterpret_cast<u32x4*>(a.y + yo * (long)sizeof(TO)) = v;
       }
     }
@@ -309,9 +309,9 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
       ok[b] = q < PX_T * OCPR && p < a.M && co < a.Cout;
       yo[b] = 0;
       if (ok[b]) {
-        yo[b] = gls_pix_off(p, HoWo, a.Wo, a.y_sn, a.y_sh, a.y_sw, a.y_lin) + co;
+        yo[b] = gls_pix_off(p, HoWo, a.Wo, a.y_sn, a.y_sh, a.y_sw, a.y_lin, a) + co;
         if (a.res) {
-          const long ro = gls_pix_off(p, HoWo, a.Wo, a.r_sn, a.r_sh, a.r_sw, a.r_lin) + co;
+          const long ro = gls_pix_off(p, HoWo, a.Wo, a.r_sn, a.r_sh, a.r_sw, a.r_lin, a) + co;
           rv[b] = *reinterpret_cast<const u32x4*>(a.res + ro * (long)sizeof(TO));
         }
       }
@@ -525,6 +525,8 @@ static int make_conv_args(const glsdet_conv_desc* d, int hint, ConvArgs& a, doub
   a.kreal = d->R * d->S * x.c;
   a.kpad = glsdet_conv_kpad(d->R, d->S, x.c, x.dtype);
   a.M = (int)M;
+  gls_fastdiv(Ho * Wo, &a.howo_mul, &a.howo_sh);
+  gls_fastdiv(Wo, &a.wo_mul, &a.wo_sh);
   a.n_co_tiles = a.n_px_tiles = 0;
   const int64_t xalloc = (const char*)x.alloc_hi - (const char*)x.alloc_lo;
   const int64_t wbytes = (int64_t)a.cout_pad * a.kpad * dtype_size(x.dtype);

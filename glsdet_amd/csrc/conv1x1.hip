@@ -57,8 +57,8 @@ __global__ __launch_bounds__(256) void conv1x1_ws_kernel(const ConvArgs a, const
     for (int i = 0; i < NB; ++i) {
       const int p = it_tile * PX_T + row0 + i * 32;
       if (it_tile < n_px_tiles && p < a.M) {
-        const int n = p / HoWo, rem = p - n * HoWo;
-        const int ho = rem / a.Wo, wo = rem - ho * a.Wo;
+        const int n = gls_div(p, a.howo_mul, a.howo_sh), rem = p - n * HoWo;
+        const int ho = gls_div(rem, a.wo_mul, a.wo_sh), wo = rem - ho * a.Wo;
         it_off[i] = a.x_off + (unsigned)(((long)n * a.x_sn + (long)ho * a.x_sh + (long)wo * a.x_sw + kc * VEC) * (long)sizeof(T));
       } else {
         it_off[i] = GLS_OOB;
@@ -160,10 +160,10 @@ __global__ __launch_bounds__(256) void conv1x1_ws_kernel(const ConvArgs a, const
         if (p < a.M && co < a.Cout) {
           u32x4 v = *reinterpret_cast<const u32x4*>(sE + px_l * ORS + cq * 16);
           if (a.res) {
-            const long ro = gls_pix_off(p, HoWo, a.Wo, a.r_sn, a.r_sh, a.r_sw, a.r_lin) + co;
+            const long ro = gls_pix_off(p, HoWo, a.Wo, a.r_sn, a.r_sh, a.r_sw, a.r_lin, a) + co;
             v = add_chunk(v, *reinterpret_cast<const u32x4*>(a.res + ro * (long)sizeof(T)), (T*)nullptr, a.act_post);
           }
-          const long yo = gls_pix_off(p, HoWo, a.Wo, a.y_sn, a.y_sh, a.y_sw, a.y_lin) + co;
+          const long yo = gls_pix_off(p, HoWo, a.Wo, a.y_sn, a.y_sh, a.y_sw, a.y_lin, a) + co;
           *reinterpret_cast<u32x4*>(a.y + yo * (long)sizeof(T)) = v;
         }
       }

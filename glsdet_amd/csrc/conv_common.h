@@ -33,13 +33,29 @@ struct ConvArgs {
   // the epilogue then needs no integer division per 16-byte chunk
   int y_lin, r_lin;
   int x_lin;                  // 1x1 / s1 / p0 conv on a pixel-linear input view
+  // p / (Ho*Wo) and r / Wo without the ~25-instruction division sequence: q = umulhi(n, mul) >> sh, exact for
+  // 0 <= n < 2^31 (host: gls_fastdiv); sh < 0 marks a divisor of 1
+  unsigned howo_mul, wo_mul;
+  int howo_sh, wo_sh;
 };
 
+// host: mul, sh with floor(n / d) == umulhi(n, mul) >> sh for 0 <= n < 2^31, 2 <= d < 2^31; d == 1 -> sh = -1
+inline void gls_fastdiv(int d, unsigned* mul, int* sh) {
+  if (d <= 1) { *mul = 0; *sh = -1; return; }
+  int l = 0;
+  while ((1ll << l) < d) ++l;                                   // 2^l >= d
+  *mul = (unsigned)(((1ull << (31 + l)) / (unsigned long long)d) + 1ull);   // < 2^32 because 2^l / d < 2
+  *sh = l - 1;
+}
+__device__ __forceinline__ int gls_div(int n, unsigned mul, int sh) {
+  return sh < 0 ? n : (int)(__umulhi((unsigned)n, mul) >> sh);
+}
+
 // element offset of flat output pixel p (+ channel) in a view
-__device__ __forceinline__ long gls_pix_off(int p, int HoWo, int Wo, long sn, long sh, long sw, int lin) {
+__device__ __forceinline__ long gls_pix_off(int p, int HoWo, int Wo, long sn, long sh, long sw, int lin, const ConvArgs& a) {
   if (lin) return (long)p * sw;
-  const int n = p / HoWo, rem = p - n * HoWo;
-  const int ho = rem / Wo, wo = rem - ho * Wo;
+  const int n = gls_div(p, a.howo_mul, a.howo_sh), rem = p - n * HoWo;
+  const int ho = gls_div(rem, a.wo_mul, a.wo_sh), wo = rem - ho * Wo;
   return (long)n * sn + (long)ho * sh + (long)wo * sw;
 }
 
