@@ -59,8 +59,9 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, local = bid >> 3;
     tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
   }
-  const int co0 = (tile % a.n_co_tiles) * CO_T;
-  const int px0 = (tile / a.n_co_tiles) * PX_T;
+  const int ptile = gls_div(tile, a.nco_mul, a.nco_sh);
+  const int co0 = (tile - ptile * a.n_co_tiles) * CO_T;
+  const int px0 = ptile * PX_T;
 
   const int kc = tid % CPR;
   const int row0 = tid / CPR;                    // row of chunk i is row0 + i*(256/CPR)
@@ -368,6 +369,7 @@ static int launch_conv(const ConvArgs& a, hipStream_t st) {
   b.n_co_tiles = (a.cout_pad + CO_T - 1) / CO_T;
   // tiles that would only cover the zero padding of cout_pad are never created
   if ((b.n_co_tiles - 1) * CO_T >= a.Cout) b.n_co_tiles = (a.Cout + CO_T - 1) / CO_T;
+  gls_fastdiv(b.n_co_tiles, &b.nco_mul, &b.nco_sh);
   b.n_px_tiles = (a.M + PX_T - 1) / PX_T;
   const long grid = (long)b.n_co_tiles * b.n_px_tiles;
   if (grid <= 0 || grid > 0x7fffffffL) GLS_FAIL(GLSDET_E_ARG, "conv2d: grid %ld out of range", grid);
@@ -392,6 +394,7 @@ static int launch_conv_multi(const ConvArgsN& m0, hipStream_t st) {
     ConvArgs& b = m.p[i];
     b.n_co_tiles = (b.cout_pad + CO_T - 1) / CO_T;
     if ((b.n_co_tiles - 1) * CO_T >= b.Cout) b.n_co_tiles = (b.Cout + CO_T - 1) / CO_T;
+    gls_fastdiv(b.n_co_tiles, &b.nco_mul, &b.nco_sh);
     b.n_px_tiles = (b.M + PX_T - 1) / PX_T;
     m.start[i] = (int)grid;
     grid += (long)b.n_co_tiles * b.n_px_tiles;

@@ -37,6 +37,10 @@ struct ConvArgs {
   // 0 <= n < 2^31 (host: gls_fastdiv); sh < 0 marks a divisor of 1
   unsigned howo_mul, wo_mul;
   int howo_sh, wo_sh;
+  // the same for the tile decode of a workgroup (scalar, but ~25 SALU per division at the head of every workgroup):
+  // n_co_tiles, and tiles_x / tiles_y of the pixel-tile kernels
+  unsigned nco_mul, tx_mul, ty_mul;
+  int nco_sh, tx_sh, ty_sh;
 };
 
 // host: mul, sh with floor(n / d) == umulhi(n, mul) >> sh for 0 <= n < 2^31, 2 <= d < 2^31; d == 1 -> sh = -1

@@ -48,12 +48,12 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const ConvArgs a, const 
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, local = bid >> 3;
     tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
   }
-  const int co0 = (tile % a.n_co_tiles) * CO_T;
-  int rest = tile / a.n_co_tiles;
-  const int tx0 = (rest % tiles_x) * TW;
-  rest /= tiles_x;
-  const int ty0 = (rest % tiles_y) * TH;
-  const int img = rest / tiles_y;
+  int rest = gls_div(tile, a.nco_mul, a.nco_sh);
+  const int co0 = (tile - rest * a.n_co_tiles) * CO_T;
+  const int r1 = gls_div(rest, a.tx_mul, a.tx_sh);
+  const int tx0 = (rest - r1 * tiles_x) * TW;
+  const int img = gls_div(r1, a.ty_mul, a.ty_sh);
+  const int ty0 = (r1 - img * tiles_y) * TH;
 
   const int kc = tid & 7, row0 = tid >> 3;         // 8 chunks per 128-B row, 32 rows per pass
   const auto xrs = gls_make_rsrc(a.x_lo, a.x_bytes);
@@ -265,12 +265,12 @@ __global__ __launch_bounds__(256) void conv_halo_ring_kernel(const ConvArgs a, c
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, local = bid >> 3;
     tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
   }
-  const int co0 = (tile % a.n_co_tiles) * CO_T;
-  int rest = tile / a.n_co_tiles;
-  const int tx0 = (rest % tiles_x) * TW;
-  rest /= tiles_x;
-  const int ty0 = (rest % tiles_y) * TH;
-  const int img = rest / tiles_y;
+  int rest = gls_div(tile, a.nco_mul, a.nco_sh);
+  const int co0 = (tile - rest * a.n_co_tiles) * CO_T;
+  const int r1 = gls_div(rest, a.tx_mul, a.tx_sh);
+  const int tx0 = (rest - r1 * tiles_x) * TW;
+  const int img = gls_div(r1, a.ty_mul, a.ty_sh);
+  const int ty0 = (r1 - img * tiles_y) * TH;
 
   const int kc = tid & 7;
   const auto xrs = gls_make_rsrc(a.x_lo, a.x_bytes);
@@ -445,6 +445,9 @@ static int launch_halo_ring(const ConvArgs& a, hipStream_t st) {
   ConvArgs b = a;
   b.n_co_tiles = (a.Cout + CO_T - 1) / CO_T;
   const int tiles_x = (a.Wo + 15) / 16, tiles_y = (a.Ho + 7) / 8;
+  gls_fastdiv(b.n_co_tiles, &b.nco_mul, &b.nco_sh);
+  gls_fastdiv(tiles_x, &b.tx_mul, &b.tx_sh);
+  gls_fastdiv(tiles_y, &b.ty_mul, &b.ty_sh);
   const long grid = (long)b.n_co_tiles * tiles_x * tiles_y * a.N;
   if (grid <= 0 || grid > 0x7fffffffL) GLS_FAIL(GLSDET_E_ARG, "conv2d(halo ring): grid %ld out of range", grid);
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, st, b, tiles_x, tiles_y);
@@ -477,6 +480,9 @@ static int launch_halo(const ConvArgs& a, hipStream_t st) {
   ConvArgs b = a;
   b.n_co_tiles = (a.Cout + CO_T - 1) / CO_T;
   const int tiles_x = (a.Wo + TW - 1) / TW, tiles_y = (a.Ho + TH - 1) / TH;
+  gls_fastdiv(b.n_co_tiles, &b.nco_mul, &b.nco_sh);
+  gls_fastdiv(tiles_x, &b.tx_mul, &b.tx_sh);
+  gls_fastdiv(tiles_y, &b.ty_mul, &b.ty_sh);
   const long grid = (long)b.n_co_tiles * tiles_x * tiles_y * a.N;
   if (grid <= 0 || grid > 0x7fffffffL) GLS_FAIL(GLSDET_E_ARG, "conv2d(halo): grid %ld out of range", grid);
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, st, b, tiles_x, tiles_y);
