@@ -239,20 +239,25 @@ __device__ __forceinline__ void halo_lds_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");       // never __syncthreads(): it would drain the ring (vmcnt(0))
 }
 
-template <typename T, typename TO, int CO_T, int KS, int RING>
+// KB = bytes of channels per chunk: 128, or 64 (half the LDS per workgroup: more workgroups per CU, a barrier every 4 MFMAs)
+template <typename T, typename TO, int CO_T, int KS, int RING, int KB = 128>
 __global__ __launch_bounds__(256) void conv_halo_ring_kernel(const ConvArgs a, const int tiles_x, const int tiles_y) {
   constexpr int TH = 8, TW = 16, WCO = 2;
-  constexpr int KB = 128, RS = KB + 16;
+  constexpr int RS = KB + 16;
+  constexpr int CPRW = KB / 16;                    // 16-byte chunks per row
+  constexpr int RPL = 256 / KB;                    // rows per 256 bytes: the swizzle is f(row) = (row / RPL) % CPRW
   constexpr int VEC = 16 / (int)sizeof(T);
   constexpr int KE = KB / (int)sizeof(T);
   constexpr int PX_T = TH * TW;
   constexpr int PH = HaloGeom<KS, TH, TW>::PH, PW = HaloGeom<KS, TH, TW>::PW;
-  constexpr int NP = HaloGeom<KS, TH, TW>::NP;
+  constexpr int NP = (PH * PW * CPRW + 255) / 256;
   constexpr int WPX = 4 / WCO;
   constexpr int WT_CO = CO_T / WCO, WT_PX = PX_T / WPX;
   constexpr int TM = WT_CO / 32, TN = WT_PX / 32;
   constexpr int A_BYTES = CO_T * KB;               // one tap's weight tile, unpadded rows
-  constexpr int NI = CO_T / 32;                    // DMA instructions per wave and tap (8 rows each)
+  constexpr int RPI = 64 / CPRW;                   // rows one DMA instruction fills
+  constexpr int NI = CO_T / RPI / 4;               // DMA instructions per wave and tap
+  static_assert(CO_T % (RPI * 4) == 0, "whole DMA pieces");
   constexpr int PATCH_OFF = RING * A_BYTES;
   static_assert(RING >= 3 && TM >= 1 && TN >= 1, "ring");
 
@@ -272,15 +277,15 @@ __global__ __launch_bounds__(256) void conv_halo_ring_kernel(const ConvArgs a, c
   const int img = gls_div(r1, a.ty_mul, a.ty_sh);
   const int ty0 = (r1 - img * tiles_y) * TH;
 
-  const int kc = tid & 7;
+  const int kc = tid % CPRW;
   const auto xrs = gls_make_rsrc(a.x_lo, a.x_bytes);
   const auto wrs = gls_make_rsrc(a.w, a.w_bytes);
   // DMA source offsets: instruction q of this wave fills rows 8 * (wave + 4q) .. +7; lane -> (row, slot)
   unsigned wd[NI];
 #pragma unroll
   for (int q = 0; q < NI; ++q) {
-    const int row = 8 * (wave + 4 * q) + (lane >> 3);
-    const int ch = (lane & 7) ^ ((row >> 1) & 7);
+    const int row = RPI * (wave + 4 * q) + lane / CPRW;
+    const int ch = (lane % CPRW) ^ ((row / RPL) & (CPRW - 1));
     const bool ok = (co0 + row) < a.cout_pad;
     wd[q] = ok ? (unsigned)(((co0 + row) * a.kpad + ch * VEC) * (int)sizeof(T)) : GLS_OOB;
   }
@@ -289,7 +294,7 @@ __global__ __launch_bounds__(256) void conv_halo_ring_kernel(const ConvArgs a, c
 #pragma unroll
   for (int i = 0; i < NP; ++i) {
     const int q = tid + i * 256;
-    const int pp = q >> 3;
+    const int pp = q / CPRW;
     const int py = pp / PW, px = pp - py * PW;
     const int hi = ty0 - pad + py, wi = tx0 - pad + px;
     const bool ok = pp < PH * PW && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
@@ -332,7 +337,7 @@ __global__ __launch_bounds__(256) void conv_halo_ring_kernel(const ConvArgs a, c
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
       const int q = tid + i * 256;
-      if (q < PH * PW * 8) *reinterpret_cast<u32x4*>(smem + PATCH_OFF + (q >> 3) * RS + (q & 7) * 16) = rp[i];
+      if (q < PH * PW * CPRW) *reinterpret_cast<u32x4*>(smem + PATCH_OFF + (q / CPRW) * RS + (q % CPRW) * 16) = rp[i];
     }
   };
 
@@ -349,7 +354,7 @@ __global__ __launch_bounds__(256) void conv_halo_ring_kernel(const ConvArgs a, c
   const int a_row = (wco * WT_CO + l31) * KB;      // + i * 32 * KB: the swizzle term (row >> 1) & 7 depends on l31 only
   int a_sw[KB / 32];
 #pragma unroll
-  for (int kk = 0; kk < KB / 32; ++kk) a_sw[kk] = ((2 * kk + lh) ^ ((l31 >> 1) & 7)) << 4;
+  for (int kk = 0; kk < KB / 32; ++kk) a_sw[kk] = ((2 * kk + lh) ^ ((l31 / RPL) & (CPRW - 1))) << 4;
   int b_off[TN];
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
@@ -430,13 +435,13 @@ __global__ __launch_bounds__(256) void conv_halo_ring_kernel(const ConvArgs a, c
   halo_store_tile<TO, CO_T, PW>(smem, a, img, ty0, tx0, co0, tid);
 }
 
-template <typename T, typename TO, int CO_T, int KS, int RING>
+template <typename T, typename TO, int CO_T, int KS, int RING, int KB = 128>
 static int launch_halo_ring(const ConvArgs& a, hipStream_t st) {
   constexpr int PH = 8 + KS - 1, PW = 16 + KS - 1;
-  constexpr int stage = RING * CO_T * 128 + PH * PW * 144;
+  constexpr int stage = RING * CO_T * KB + PH * PW * (KB + 16);
   constexpr int epi = 128 * (CO_T * (int)sizeof(TO) + 16);
   constexpr int lds = stage > epi ? stage : epi;
-  auto kern = conv_halo_ring_kernel<T, TO, CO_T, KS, RING>;
+  auto kern = conv_halo_ring_kernel<T, TO, CO_T, KS, RING, KB>;
   static bool attr_set = false;
   if (!attr_set && lds > 64 * 1024) {
     GLS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
@@ -503,7 +508,7 @@ static int halo_by_ks(const ConvArgs& a, hipStream_t st) {
 // Returns 1 when the halo kernel does not apply (caller falls back to the generic kernel),
 // 0 when `op` was filled in.
 int conv_halo_try(const ConvArgs& a, int xdt, int ydt, int hint, OpRecord* op) {
-  if (hint == 1 || hint == 3 || (hint > 5 && hint != 8 && hint != 9)) return 1;          // hint 1 / explicit tile = the generic kernel
+  if (hint == 1 || hint == 3 || (hint > 5 && hint != 8 && hint != 9 && hint != 10)) return 1;          // hint 1 / explicit tile = the generic kernel
   if (a.stride != 1 || a.R != a.S || (a.R != 3 && a.R != 5 && a.R != 7) || a.pad != a.R / 2) return 1;
   const int es = dtype_size(xdt);
   if ((a.Cin * es) % 128) return 1;
@@ -511,17 +516,23 @@ int conv_halo_try(const ConvArgs& a, int xdt, int ydt, int hint, OpRecord* op) {
   // wasted MFMA work on partial tiles: prefer the flat-pixel kernel when it is large
   const long tiles = (long)((a.Ho + 7) / 8) * ((a.Wo + 15) / 16);
   const double waste = (double)tiles * 128.0 / ((double)a.Ho * a.Wo);
-  if (hint != 2 && hint != 4 && hint != 5 && hint != 8 && hint != 9 && waste > 1.30) return 1;      // a hint forces the halo kernel
-  const bool ring = hint == 8 || hint == 9;        // weight tiles by LDS-DMA into a ring: 8 = 64-row, 9 = 128-row cout tiles
+  if (hint != 2 && hint != 4 && hint != 5 && hint != 8 && hint != 9 && hint != 10 && waste > 1.30) return 1;      // a hint forces the halo kernel
+  const bool ring = hint == 8 || hint == 9 || hint == 10;   // weight tiles by LDS-DMA into a ring: 8 = 64-row, 9 = 128-row cout tiles,
+  const bool ring_k64 = hint == 10;                          // 10 = 64-row tiles with 64-byte channel chunks (3x3 / 5x5)
   if (hint == 9 && a.cout_pad <= 64) return 1;
-  const int co_t = (a.cout_pad <= 64 || hint == 5 || hint == 8) ? 64 : 128;     // hint 5 / 8: 64-row cout tiles also for wide layers
+  if (ring_k64 && a.R == 7) return 1;
+  const int co_t = (a.cout_pad <= 64 || hint == 5 || hint == 8 || hint == 10) ? 64 : 128;     // hint 5 / 8 / 10: 64-row cout tiles also for wide layers
   const bool wpriv = hint == 4;                     // wave-private weight staging (128-row cout tile only)
   if (wpriv && co_t != 128) return 1;
   char nm[96];
-  snprintf(nm, sizeof nm, "conv_halo%s<%s,%dx8x16> %dx%d s1 cin%d cout%d", wpriv ? "_wp" : (ring ? "_ring" : ""), xdt ? "f32" : "f16", co_t, a.R,
+  snprintf(nm, sizeof nm, "conv_halo%s<%s,%dx8x16> %dx%d s1 cin%d cout%d", wpriv ? "_wp" : (ring ? (ring_k64 ? "_ring_k64" : "_ring") : ""), xdt ? "f32" : "f16", co_t, a.R,
            a.S, a.Cin, a.Cout);
   op->name = nm;
-  op->launch = [a, co_t, xdt, wpriv, ring](hipStream_t st) -> int {
+  op->launch = [a, co_t, xdt, wpriv, ring, ring_k64](hipStream_t st) -> int {
+    if (ring_k64) {
+      if (xdt == GLSDET_F16) return a.R == 3 ? launch_halo_ring<f16, f16, 64, 3, 4, 64>(a, st) : launch_halo_ring<f16, f16, 64, 5, 4, 64>(a, st);
+      return a.R == 3 ? launch_halo_ring<float, float, 64, 3, 4, 64>(a, st) : launch_halo_ring<float, float, 64, 5, 4, 64>(a, st);
+    }
     if (ring) {
       if (xdt == GLSDET_F16) return co_t == 128 ? halo_ring_by_ks<f16, f16, 128>(a, st) : halo_ring_by_ks<f16, f16, 64>(a, st);
       return co_t == 128 ? halo_ring_by_ks<float, float, 128>(a, st) : halo_ring_by_ks<float, float, 64>(a, st);
