@@ -511,7 +511,7 @@ int conv_halo_try(const ConvArgs& a, int xdt, int ydt, int hint, OpRecord* op) {
   if (hint == 1 || hint == 3 || (hint > 5 && hint != 8 && hint != 9 && hint != 10)) return 1;          // hint 1 / explicit tile = the generic kernel
   if (a.stride != 1 || a.R != a.S || (a.R != 3 && a.R != 5 && a.R != 7) || a.pad != a.R / 2) return 1;
   const int es = dtype_size(xdt);
-  if ((a.Cin * es) % 128) return 1;
+  if ((a.Cin * es) % (hint == 10 ? 64 : 128)) return 1;      // whole channel chunks (hint 10 works on 64-byte chunks)
   if (xdt != ydt) return 1;
   // wasted MFMA work on partial tiles: prefer the flat-pixel kernel when it is large
   const long tiles = (long)((a.Ho + 7) / 8) * ((a.Wo + 15) / 16);

@@ -25,6 +25,7 @@ SHAPES = [  # n, H, W, cin, cout, k, stride
     (8, 50, 84, 768, 256, 1, 1),
     (8, 200, 336, 64, 128, 3, 2),
     (8, 400, 672, 16, 32, 3, 1),
+    (8, 200, 336, 32, 32, 3, 1),
 ]
 RESNET = [  # ResNet-50 / FPN / head layers at 8 x 800 x 1344
     (8, 50, 84, 1024, 256, 1, 1),
