@@ -505,22 +505,31 @@ static int halo_by_ks(const ConvArgs& a, hipStream_t st) {
   GLS_FAIL(GLSDET_E_ARG, "conv2d(halo): unsupported kernel size %d", a.R);
 }
 
+template <typename T, typename TO, int CO_T>
+static int halo_ring_k64_by_ks(const ConvArgs& a, hipStream_t st) {
+  switch (a.R) {
+    case 3: return launch_halo_ring<T, TO, CO_T, 3, 4, 64>(a, st);
+    case 5: return launch_halo_ring<T, TO, CO_T, 5, 4, 64>(a, st);
+    case 7: return launch_halo_ring<T, TO, CO_T, 7, 4, 64>(a, st);
+  }
+  GLS_FAIL(GLSDET_E_ARG, "conv2d(halo ring): unsupported kernel size %d", a.R);
+}
+
 // Returns 1 when the halo kernel does not apply (caller falls back to the generic kernel),
 // 0 when `op` was filled in.
 int conv_halo_try(const ConvArgs& a, int xdt, int ydt, int hint, OpRecord* op) {
-  if (hint == 1 || hint == 3 || (hint > 5 && hint != 8 && hint != 9 && hint != 10)) return 1;          // hint 1 / explicit tile = the generic kernel
+  if (hint == 1 || hint == 3 || (hint > 5 && hint != 8 && hint != 9 && hint != 10 && hint != 11)) return 1;          // hint 1 / explicit tile = the generic kernel
   if (a.stride != 1 || a.R != a.S || (a.R != 3 && a.R != 5 && a.R != 7) || a.pad != a.R / 2) return 1;
   const int es = dtype_size(xdt);
-  if ((a.Cin * es) % (hint == 10 ? 64 : 128)) return 1;      // whole channel chunks (hint 10 works on 64-byte chunks)
+  if ((a.Cin * es) % ((hint == 10 || hint == 11) ? 64 : 128)) return 1;      // whole channel chunks (hint 10 works on 64-byte chunks)
   if (xdt != ydt) return 1;
   // wasted MFMA work on partial tiles: prefer the flat-pixel kernel when it is large
   const long tiles = (long)((a.Ho + 7) / 8) * ((a.Wo + 15) / 16);
   const double waste = (double)tiles * 128.0 / ((double)a.Ho * a.Wo);
-  if (hint != 2 && hint != 4 && hint != 5 && hint != 8 && hint != 9 && hint != 10 && waste > 1.30) return 1;      // a hint forces the halo kernel
-  const bool ring = hint == 8 || hint == 9 || hint == 10;   // weight tiles by LDS-DMA into a ring: 8 = 64-row, 9 = 128-row cout tiles,
-  const bool ring_k64 = hint == 10;                          // 10 = 64-row tiles with 64-byte channel chunks (3x3 / 5x5)
-  if (hint == 9 && a.cout_pad <= 64) return 1;
-  if (ring_k64 && a.R == 7) return 1;
+  if (hint != 2 && hint != 4 && hint != 5 && (hint < 8 || hint > 11) && waste > 1.30) return 1;      // a hint forces the halo kernel
+  const bool ring = hint >= 8 && hint <= 11;       // weight tiles by LDS-DMA into a ring: 8 = 64-row, 9 = 128-row cout tiles,
+  const bool ring_k64 = hint == 10 || hint == 11;  // 10 / 11 = 64- / 128-row tiles with 64-byte channel chunks
+  if ((hint == 9 || hint == 11) && a.cout_pad <= 64) return 1;
   const int co_t = (a.cout_pad <= 64 || hint == 5 || hint == 8 || hint == 10) ? 64 : 128;     // hint 5 / 8 / 10: 64-row cout tiles also for wide layers
   const bool wpriv = hint == 4;                     // wave-private weight staging (128-row cout tile only)
   if (wpriv && co_t != 128) return 1;
@@ -530,8 +539,8 @@ int conv_halo_try(const ConvArgs& a, int xdt, int ydt, int hint, OpRecord* op) {
   op->name = nm;
   op->launch = [a, co_t, xdt, wpriv, ring, ring_k64](hipStream_t st) -> int {
     if (ring_k64) {
-      if (xdt == GLSDET_F16) return a.R == 3 ? launch_halo_ring<f16, f16, 64, 3, 4, 64>(a, st) : launch_halo_ring<f16, f16, 64, 5, 4, 64>(a, st);
-      return a.R == 3 ? launch_halo_ring<float, float, 64, 3, 4, 64>(a, st) : launch_halo_ring<float, float, 64, 5, 4, 64>(a, st);
+      if (xdt == GLSDET_F16) return co_t == 128 ? halo_ring_k64_by_ks<f16, f16, 128>(a, st) : halo_ring_k64_by_ks<f16, f16, 64>(a, st);
+      return co_t == 128 ? halo_ring_k64_by_ks<float, float, 128>(a, st) : halo_ring_k64_by_ks<float, float, 64>(a, st);
     }
     if (ring) {
       if (xdt == GLSDET_F16) return co_t == 128 ? halo_ring_by_ks<f16, f16, 128>(a, st) : halo_ring_by_ks<f16, f16, 64>(a, st);

@@ -84,8 +84,8 @@ typedef struct glsdet_conv_desc {
   const float* bias;
   int32_t R, S, stride, pad, act;
   int32_t tile_hint;       /* 0 auto | 1 generic | 2 halo (s1 kxk) | 4 halo, wave-private weights | 5 halo, 64-row cout tiles |
-                            * 8 / 9 halo with the weight tiles in an LDS-DMA ring (64- / 128-row cout tiles) | 10 the same, 64 rows,
-                            *   64-byte channel chunks (3x3, 5x5) |
+                            * 8 / 9 halo with the weight tiles in an LDS-DMA ring (64- / 128-row cout tiles) | 10 / 11 the same with
+                            *   64-byte channel chunks (64 / 128 rows) |
                             * 6 / 7 persistent LDS-DMA halo (64- / 128-row cout tiles, fp16) | 3 weight-stationary 1x1 |
                             * co_tile<<16|px_tile (|0x8000: 64-byte K steps) */
 } glsdet_conv_desc;
