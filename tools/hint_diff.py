@@ -8,10 +8,10 @@ import torch
 from glsdet_amd.engine import Engine
 
 hints = [int(h) for h in sys.argv[1:]] or [2, 5, 8, 9, 10]
-eng = Engine("f32")
+eng = Engine(os.environ.get("HINT_DIFF_DTYPE", "f32"))
 for (n, H, W, cin, cout, k) in [(8, 100, 168, 128, 256, 3), (8, 50, 84, 256, 256, 5), (8, 100, 168, 128, 128, 3), (4, 37, 53, 320, 136, 3)]:
     x = eng.tensor(n, H, W, cin)
-    x.buf.view(torch.float32)[: n * H * W * cin].normal_()
+    (x.buf.view(torch.float32)[: n * H * W * cin] if eng.dt else x.buf.view(torch.float16)[: n * H * W * cin]).normal_()
     w = torch.randn(cout, cin, k, k) / (cin * k * k) ** 0.5
     pk = eng.pack_conv([(w, torch.rand(cout) + 0.5, torch.randn(cout) * 0.3)], cin)
     ref = eng.conv(x, pk, 1, k // 2, "silu", tile_hint=1).to_nchw(cout).clone()
