@@ -3,23 +3,32 @@
 -> decoupled head -> decode -> batched NMS) on MI355X, synthetic input, random-init weights.
 
     python bench.py --gpus N --steps K --warmup W
-    (N>1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+
+N>1 without a launcher (no WORLD_SIZE in the environment): this process starts N fresh child
+processes -- one rank per GPU, before it has made any GPU call itself -- and rank 0 prints the line.
+Under `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` it is one of the ranks.
 
 Workload (BASELINE.json: metric quoted at 1333x800 bs=8): YOLOX-s + GL-fusion neck
 (`models.block.non_local.yolo_patch_nonlocal_plus`, the only GL-fusion detector the
 reference wires up), nc=10, 8 images of 800x1344 (1333x800 keep-ratio, padded to /32) per
 GPU, fp16 storage / fp32 accumulate.  A step = one batch through the captured hipGraph
-(input already resident in HBM) + the all_gather of detections when N>1.  Weak scaling:
-8 images per GPU, image i of the global batch on rank i % N.
+(input already resident in HBM; detection counts read back to the host for every batch) + the
+all_gather of the exchange record when N>1.  Weak scaling: 8 images per GPU, image i of the
+global batch on rank i % N.
 
 Prints ONE JSON line (rank 0).  Extra objects: `roofline` for the dominant kernel family
-(conv_igemm, per-launch numbers from HIP events around every op of an eager replay on the
-launch stream) and `cpu_baseline` (the CPU oracle, bounded sample, rank 0 at N=1 only).
+(conv family, per-launch numbers from HIP events around every op of an eager replay on the
+launch stream; `frac` = that single-stream figure, `frac_end_to_end` = the same FLOPs over the
+wall clock of the timed loop with all batches in flight), `cpu_baseline` (the CPU oracle, bounded
+sample, rank 0 at N=1 only) and `secondary` = BASELINE config 3 (`mp_det_res50`: ResNet-50 + GL-fusion
+plug-in + FPN + MPHead at 8 x 800 x 1344) measured the same way in the same run.
 """
 import argparse
 import glob
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -30,6 +39,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_F16_TFLOPS = 2500.0      # MI355X dense fp16 MFMA (MI355X_MICROARCH.md, chip-level parameters)
+PEAK_F32_TFLOPS = 157.3       # exact-f32 MFMA (same table)
 PEAK_HBM_GBS = 8000.0
 
 # algorithmic GMAC per image (forward hooks on the imported reference):
@@ -46,19 +56,27 @@ WORKLOADS = {
     "yolox_s_glfusion_1344x800_bs8": ("gl", "gl_s_seed0", 800, 1344, 8),
     "yolox_s_glfusion_640x640_bs8": ("gl", "gl_s_seed0", 640, 640, 8),
     "yolox_s_base_640x640_bs8": ("base", "base_s_seed0", 640, 640, 8),
-    # UFPMP-Det detectors (configs/UFPMP-Det/*.py): ResNet-50 + FPN + GFLHead / MPHead
+    # UFPMP-Det detectors (configs/UFPMP-Det/*.py): ResNet-50 (+ GL-fusion plug-in) + FPN + GFLHead / MPHead
+    "mp_det_res50_gl_1344x800_bs8": ("mpdet_gl", None, 800, 1344, 8),
     "mp_det_res50_1344x800_bs8": ("mpdet", None, 800, 1344, 8),
     "coarse_det_1344x800_bs8": ("gfl", None, 800, 1344, 8),
 }
-RESDET = ("gfl", "mpdet")
+RESDET = ("gfl", "mpdet", "mpdet_gl")
+DETECTOR_NAME = {"gl": "YOLOX-s + GL-fusion neck", "base": "YOLOX-s", "gfl": "GFL ResNet-50 + FPN",
+                 "mpdet": "MPDet ResNet-50 + FPN + MPHead",
+                 "mpdet_gl": "MPDet ResNet-50 + GL-fusion (x + Patch_Conv_NonLocal_new(x) on C3-C5) + FPN + MPHead"}
+SECONDARY = "mp_det_res50_gl_1344x800_bs8"      # BASELINE config 3 as named
 
 
 def resdet_algorithmic(kind, H, W, nc=10, proxies=42):
-    """Algorithmic (GMAC conv, GMAC matmul, HBM bytes fp16) per image of ResNet-50 + FPN(start 1,
+    """Algorithmic (GMAC conv, GMAC matmul, HBM bytes fp16) per image of ResNet-50 (+ GL plug-in) + FPN(start 1,
     5 outs, extra on_output) + GFLHead/MPHead by SURVEY 8d's rule: conv MACs = out elems x Cin x k^2
-    with the REAL channel counts; bytes = each conv reads its input once and writes its output once."""
+    with the REAL channel counts; bytes = each conv reads its input once and writes its output once;
+    matmul MACs = the two batched products of every Non_local_Block as the reference evaluates them
+    (N x C x N each, Identity_Conv.py:162-167)."""
     mac = [0.0]
     byt = [0.0]
+    mm = [0.0]
 
     def conv(h, w, cin, cout, k, s=1, pad=None):
         pad = k // 2 if pad is None else pad
@@ -80,6 +98,16 @@ def resdet_algorithmic(kind, H, W, nc=10, proxies=42):
             conv(ho, wo, planes, planes * 4, 1)
             h, w, cin = ho, wo, planes * 4
         sizes.append((h, w, cin))
+    if kind == "mpdet_gl":          # GLFusionPlugin on C3..C5: 4 quadrant non-local blocks (inter = C/2) + 1x1 channel_conv
+        for (h, w, c) in sizes[1:]:
+            hh, hw = h // 2, w // 2
+            for (qh, qw) in ((hh, hw), (h - hh, hw), (hh, w - hw), (h - hh, w - hw)):
+                ci = c // 2
+                for _ in range(3):
+                    conv(qh, qw, c, ci, 1)          # theta, phi, g
+                conv(qh, qw, ci, c, 1)              # conv_out
+                mm[0] += 2.0 * (qh * qw) * ci * (qh * qw)
+            conv(h, w, c, c, 1)                     # channel_conv ('linear')
     lv = []
     for (h, w, c) in sizes[1:]:
         conv(h, w, c, 256, 1)
@@ -87,7 +115,6 @@ def resdet_algorithmic(kind, H, W, nc=10, proxies=42):
         lv.append((h, w))
     for _ in range(2):
         lv.append(conv(lv[-1][0], lv[-1][1], 256, 256, 3, 2))
-    mm = 0.0
     for (h, w) in lv:
         for _ in range(8):
             conv(h, w, 256, 256, 3)
@@ -96,8 +123,8 @@ def resdet_algorithmic(kind, H, W, nc=10, proxies=42):
             conv(h, w, 256, nc, 3)
         else:
             conv(h, w, 256, 256, 3)
-            mm += h * w * 256 * proxies
-    return mac[0] / 1e9, mm / 1e9, byt[0]
+            mm[0] += h * w * 256 * proxies
+    return mac[0] / 1e9, mm[0] / 1e9, byt[0]
 
 
 def synthetic_state_dict(tag):
@@ -117,14 +144,18 @@ def synthetic_state_dict(tag):
     return sd
 
 
-def cpu_baseline(sd, kind, n, H, W, conf, nms_thr, budget_s=25.0):
-    """The oracle (a port: kind='port') timed on the host cores: forward + decode + NMS."""
-    from oracle import glsdet_oracle as O
+def _host_threads():
     try:
         ncpu = len(os.sched_getaffinity(0))
     except AttributeError:
         ncpu = os.cpu_count() or 1
-    torch.set_num_threads(max(1, min(ncpu, 64)))
+    return max(1, min(ncpu, 64))
+
+
+def cpu_baseline(sd, kind, n, H, W, conf, nms_thr, budget_s=25.0):
+    """The oracle (a port: kind='port') timed on the host cores: forward + decode + NMS."""
+    from oracle import glsdet_oracle as O
+    torch.set_num_threads(_host_threads())
     x = O.synth_input((n, 3, H, W), 100)
 
     def step():
@@ -145,23 +176,22 @@ def cpu_baseline(sd, kind, n, H, W, conf, nms_thr, budget_s=25.0):
                       % (iters, n, H, W)}
 
 
-def resdet_cpu_baseline(sd, kind, H, W, thr, budget_s=25.0):
+def resdet_cpu_baseline(sd, kind, H, W, thr, max_per_img, budget_s=25.0):
     """oracle/mpdet_oracle.py timed on the host cores on ONE image of the benchmark shape
     (a bs-8 batch of ResNet-50 at 800x1344 does not fit the time budget)."""
     from oracle import glsdet_oracle as O
     from oracle import mpdet_oracle as M
     from glsdet_amd.resdet import HipGflDetector
-    try:
-        ncpu = len(os.sched_getaffinity(0))
-    except AttributeError:
-        ncpu = os.cpu_count() or 1
-    torch.set_num_threads(max(1, min(ncpu, 64)))
+    torch.set_num_threads(_host_threads())
     x = O.synth_input((1, 3, H, W), 100)
+    fwd = {"gfl": lambda: M.gfl_forward(sd, x),
+           "mpdet": lambda: M.mpdet_forward(sd, x, HipGflDetector.DEFAULTS["proxies_list"]),
+           "mpdet_gl": lambda: M.mpdet_forward(sd, x, HipGflDetector.DEFAULTS["proxies_list"], gl_fusion=True)}[kind]
 
     def step():
         with torch.no_grad():
-            c, r = M.gfl_forward(sd, x) if kind == "gfl" else M.mpdet_forward(sd, x, HipGflDetector.DEFAULTS["proxies_list"])
-            M.gfl_get_bboxes(c, r, [8, 16, 32, 64, 128], [(H, W, 3)], thr, 1000, 0.6, 100)
+            c, r = fwd()
+            M.gfl_get_bboxes(c, r, [8, 16, 32, 64, 128], [(H, W, 3)], thr, 1000, 0.6, max_per_img)
     t0 = time.perf_counter()
     step()
     first = time.perf_counter() - t0
@@ -202,14 +232,36 @@ def calibrate_resdet(sd, kind, img, args, dev):
     return sd, round(0.5 * (lo + hi), 4)
 
 
-def calibrate_objectness(sd, kind, img, args, dev):
-    """Random-init weights evaluated far from the resolution their BN statistics were
-    calibrated at give saturated logits (almost every anchor a detection).  To load the
-    post-processing like a real image does (about 2000 candidates per image
-    after thresholding), shift the three objectness biases by one common offset found by
-    bisection on the raw logits of one untimed forward.  Weights only; the timed path is
-    untouched."""
+def _torch_decode(outs, H, W):
+    """decode_outputs (drone/models/core/utils_bbox.py:254-306) in torch on the device, for the
+    calibration below only (data preparation; the measured path uses glsdet_yolox_decode)."""
+    flat = torch.cat([o.flatten(2) for o in outs], 2).permute(0, 2, 1).clone()
+    flat[..., 4:] = torch.sigmoid(flat[..., 4:])
+    grids, strides = [], []
+    for o in outs:
+        h, w = o.shape[-2:]
+        gy, gx = torch.meshgrid(torch.arange(h, device=o.device), torch.arange(w, device=o.device), indexing="ij")
+        grids.append(torch.stack((gx, gy), 2).reshape(1, -1, 2).float())
+        strides.append(torch.full((1, h * w, 1), H / h, device=o.device))
+    grids, strides = torch.cat(grids, 1), torch.cat(strides, 1)
+    flat[..., :2] = (flat[..., :2] + grids) * strides
+    flat[..., 2:4] = torch.exp(flat[..., 2:4]) * strides
+    flat[..., [0, 2]] = flat[..., [0, 2]] / W
+    flat[..., [1, 3]] = flat[..., [1, 3]] / H
+    return flat.contiguous()
+
+
+def calibrate_yolox_head(sd, kind, img, args, dev):
+    """Make the random-init head behave like a trained one for the post-processing load (weights only; the
+    timed path is untouched; SURVEY 8d "dense mode"):
+      * objectness: one common bias shift so that about --candidates anchors per image pass --conf;
+      * box branch: random reg_preds saturate exp(w), exp(h) (infinite boxes, nothing overlaps, the NMS fixed
+        point converges in one sweep).  The reg_preds weights are rescaled per level so that the xy offsets have
+        std 0.5 cell and log(w/stride), log(h/stride) ~ N(mu, 0.35^2); mu is bisected until the class-wise NMS
+        at --nms suppresses about --suppress of the candidates (a trained detector's clustered duplicates).
+    The suppression is evaluated with the product's own NMS kernel on torch-decoded boxes."""
     from glsdet_amd.detector import HipDetector
+    from glsdet_amd.engine import Engine
     outs = HipDetector(kind, sd, dtype=args.dtype, device=dev).forward_raw(img)
     obj = torch.cat([o[:, 4].flatten(1) for o in outs], 1)
     cls = torch.cat([torch.sigmoid(o[:, 5:]).max(1)[0].flatten(1) for o in outs], 1)
@@ -218,107 +270,124 @@ def calibrate_objectness(sd, kind, img, args, dev):
         mid = 0.5 * (lo + hi)
         n = float((torch.sigmoid(obj + mid) * cls >= args.conf).sum(1).float().mean())
         lo, hi = (mid, hi) if n < args.candidates else (lo, mid)
+    shift = 0.5 * (lo + hi)
     sd = dict(sd)
-    for k in list(sd):
-        if k.startswith("head.obj_preds.") and k.endswith(".bias"):
-            sd[k] = sd[k] + 0.5 * (lo + hi)
-    return sd
+    scales = []
+    for k, o in enumerate(outs):
+        b = sd["head.reg_preds.%d.bias" % k].to(o.device).view(1, 4, 1, 1)
+        r = o[:, :4] - b
+        scales.append((0.5 / float(r[:, :2].std().clamp(min=1e-6)), 0.35 / float(r[:, 2:].std().clamp(min=1e-6))))
+        sd["head.obj_preds.%d.bias" % k] = sd["head.obj_preds.%d.bias" % k] + shift
+    eng = Engine("f32", dev)
+    n, A = outs[0].shape[0], sum(o.shape[2] * o.shape[3] for o in outs)
+    nb = eng.nms_buffers(n, A, A, args.max_det)
+
+    def suppressed(mu):
+        mod = []
+        for k, o in enumerate(outs):
+            b = sd["head.reg_preds.%d.bias" % k].to(o.device).view(1, 4, 1, 1)
+            t = o.clone()
+            t[:, :2] = (o[:, :2] - b[:, :2]) * scales[k][0]
+            t[:, 2:4] = (o[:, 2:4] - b[:, 2:]) * scales[k][1] + mu
+            t[:, 4] = o[:, 4] + shift
+            mod.append(t)
+        dets, count, status = eng.nms(_torch_decode(mod, img.shape[2], img.shape[3]), 10, 0, args.conf, args.nms, nb)
+        torch.cuda.synchronize()
+        cand = nb["ws"][: 4 * n].view(torch.int32).float().sum()
+        return 1.0 - float(count[n:2 * n].float().sum() / cand.clamp(min=1))
+    lo, hi = -1.0, 4.5
+    for _ in range(14):
+        mid = 0.5 * (lo + hi)
+        lo, hi = (mid, hi) if suppressed(mid) < args.suppress else (lo, mid)
+    mu = 0.5 * (lo + hi)
+    for k in range(len(outs)):
+        w = sd["head.reg_preds.%d.weight" % k].clone()
+        w[:2] *= scales[k][0]
+        w[2:] *= scales[k][1]
+        sd["head.reg_preds.%d.weight" % k] = w
+        sd["head.reg_preds.%d.bias" % k] = torch.tensor([0.0, 0.0, mu, mu])
+    return sd, {"objectness_bias_shift": round(shift, 3), "log_box_over_stride_mean": round(mu, 3)}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="yolox_s_glfusion_1344x800_bs8", choices=sorted(WORKLOADS))
-    ap.add_argument("--dtype", default="f16", choices=["f16", "f32"])
-    ap.add_argument("--conf", type=float, default=0.25)
-    ap.add_argument("--candidates", type=int, default=2000,
-                    help="calibrate the objectness bias so that about this many anchors per image pass --conf")
-    ap.add_argument("--max-det", type=int, default=3000)
-    ap.add_argument("--nms", type=float, default=0.65)
-    ap.add_argument("--no-graph", action="store_true")
-    ap.add_argument("--from-host", action="store_true",
-                    help="diagnostic: every step first copies its fp32 batch from pinned host memory (the "
-                         "PCIe-inclusive rate quoted in DESIGN.md; never the headline value)")
-    ap.add_argument("--streams", type=int, default=3,
-                    help="plan instances replayed round-robin on their own HIP streams (batches in flight)")
-    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
-                    help="torch.distributed backend; gloo is for rehearsing the N>1 control flow on a box with fewer "
-                         "GPUs than ranks (ranks then share devices round-robin) -- never for a reported number")
-    ap.add_argument("--no-autotune", action="store_true")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--op-table", default="", help="write the per-op timing table (tsv) here")
-    args = ap.parse_args()
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("--gpus %d needs a torch.distributed.run launch (WORLD_SIZE=%d)" % (args.gpus, world))
-    if args.backend == "gloo":
-        local_rank %= max(1, torch.cuda.device_count())
-    torch.cuda.set_device(local_rank)
-    dev = "cuda:%d" % local_rank
+# --------------------------------------------------------------------------------------------- one workload
+def run_workload(args, workload, rank, world, dev, with_cpu_baseline):
+    """Build, calibrate, time (warmup + exactly --steps steps between barriers) and profile per op ONE workload.
+    -> (result dict, elapsed seconds) on every rank."""
     import torch.distributed as dist
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.backend == "gloo":
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=torch.device(dev))
+    from glsdet_amd.dist import DetectionExchange
 
-    from glsdet_amd.detector import HipDetector
-    from glsdet_amd.dist import gather_detections
-
-    kind, tag, H, W, bs = WORKLOADS[args.workload]
+    kind, tag, H, W, bs = WORKLOADS[workload]
     gen = torch.Generator(device=dev).manual_seed(rank)
     img = torch.randn(bs, 3, H, W, generator=gen, device=dev)
     nstreams = 1 if args.no_graph else max(1, args.streams)
+    calib = {}
     if kind in RESDET:
         from glsdet_amd.resdet import HipGflDetector
         from glsdet_amd.synth import synth_input, synth_resdet_state_dict
-        sd = synth_resdet_state_dict(kind, 0, synth_input((1, 3, 128, 160), 100))
-        sd, score_thr = calibrate_resdet(sd, kind, img, args, dev)
-        det = HipGflDetector(kind, sd, dtype=args.dtype, device=dev, autotune=not args.no_autotune)
+        extra = dict(gl_fusion=True) if kind == "mpdet_gl" else {}
+        sd = synth_resdet_state_dict("mpdet" if kind == "mpdet_gl" else kind, 0, synth_input((1, 3, 128, 160), 100), **extra)
+        hip_kind = "mpdet" if kind == "mpdet_gl" else kind
+        sd, score_thr = calibrate_resdet(sd, hip_kind, img, args, dev)
+        det = HipGflDetector(hip_kind, sd, dtype=args.dtype, device=dev, autotune=not args.no_autotune)
         post = dict(score_thr=score_thr, iou_thr=0.6, nms_pre=1000, max_per_img=100 if kind == "gfl" else 500,
                     max_cand=16384)
         buf = lambda ci: ci.nb
     else:
+        from glsdet_amd.detector import HipDetector
         sd = synthetic_state_dict(tag)
-        sd = calibrate_objectness(sd, kind, img, args, dev)          # setup only, not timed
+        sd, calib = calibrate_yolox_head(sd, kind, img, args, dev)          # setup only, not timed
         det = HipDetector(kind, sd, dtype=args.dtype, device=dev, autotune=not args.no_autotune)
         post = dict(conf_thres=args.conf, nms_thres=args.nms, max_det=args.max_det)
         buf = lambda ci: ci.nmsb
+    if world > 1:
+        post["exchange_cap"] = min(args.exchange_cap, post.get("max_det", post.get("max_per_img", 1000)))
     cs = [det.compile(bs, H, W, post, use_graph=not args.no_graph, instance=i) for i in range(nstreams)]
     for ci in cs:
         ci.img.copy_(img)                                        # resident in HBM before timing
     c = cs[0]
+    exch = [DetectionExchange(buf(ci)["packed"]) for ci in cs] if world > 1 else None
+    # results leave the device every step: the per-image counts of a batch are copied to pinned host memory on the
+    # batch's own stream and consumed (summed) when that plan instance comes round again
+    h_count = [torch.zeros(2 * bs, dtype=torch.int32).pin_memory() for _ in cs]
+    ev = [torch.cuda.Event() for _ in cs]
+    pending = [False] * len(cs)
     host_img = img.cpu().pin_memory() if args.from_host else None
     torch.cuda.synchronize()
     turn = [0]
+    read_back = [0, 0]                     # detections, batches whose counts reached the host
+
+    def consume(i):
+        if pending[i]:
+            ev[i].synchronize()
+            read_back[0] += int(h_count[i][:bs].sum())
+            read_back[1] += 1
+            pending[i] = False
 
     def step():
-        ci = cs[turn[0] % nstreams]
+        i = turn[0] % nstreams
+        ci = cs[i]
         turn[0] += 1
+        consume(i)
+        st = ci.graph_stream if not args.no_graph else torch.cuda.current_stream()
         if args.no_graph:
             det.run(ci)
+        else:
+            # one batch = one graph replay on the instance's own stream (+ its gather when N>1);
+            # consecutive batches rotate over the instances, so `--streams` batches are in flight
+            if host_img is not None:
+                with torch.cuda.stream(st):
+                    ci.img.copy_(host_img, non_blocking=True)
+            det.run_async(ci)
+        with torch.cuda.stream(st):
             if world > 1:
-                gather_detections(buf(ci)["dets"], buf(ci)["count"])
-            return
-        # one batch = one graph replay on the instance's own stream (+ its gather when N>1);
-        # consecutive batches rotate over the instances, so `--streams` batches are in flight (3: +6 % over 2
-        # on the default workload, measured twice on one box; 4 is slower again)
-        if host_img is not None:
-            with torch.cuda.stream(ci.graph_stream):
-                ci.img.copy_(host_img, non_blocking=True)
-        det.run_async(ci)
-        if world > 1:
-            with torch.cuda.stream(ci.graph_stream):
-                gather_detections(buf(ci)["dets"], buf(ci)["count"])
+                exch[i].gather()
+            h_count[i].copy_(buf(ci)["count"], non_blocking=True)
+            ev[i].record(st)
+        pending[i] = True
 
     def fence():
+        for i in range(len(cs)):
+            consume(i)
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -326,6 +395,7 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
+    read_back[0] = read_back[1] = 0
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -335,6 +405,7 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    assert read_back[1] == args.steps, "every timed batch must have delivered its counts to the host"
     dets = det.collect(c)                    # also checks the NMS capacity/overflow flags
     if kind in RESDET:
         dets = [d[0] for d in dets]
@@ -351,26 +422,31 @@ def main():
     if kind in RESDET:
         alg_conv_gmac, alg_mm_gmac, alg_bytes = resdet_algorithmic(kind, H, W)
     else:
-        alg_conv_gmac, alg_mm_gmac = ALGORITHMIC_GMAC[args.workload]
+        alg_conv_gmac, alg_mm_gmac = ALGORITHMIC_GMAC[workload]
         alg_bytes = 431.8e6 if (H, W) == (800, 1344) else 164.5e6
     conv_flops = 2.0 * alg_conv_gmac * 1e9 * bs
     conv_ms = sum(t for _, t in conv)
     all_ms = float(ms.sum())
+    peak = PEAK_F16_TFLOPS if args.dtype == "f16" else PEAK_F32_TFLOPS
     achieved = conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+    wall_ms = elapsed / args.steps * 1e3
+    e2e = 2.0 * (alg_conv_gmac + alg_mm_gmac) * 1e9 * bs / (wall_ms * 1e-3) / 1e12
     # HBM traffic per conv launch: PMC counters cannot be read from inside the benchmark; the
     # latest committed rocprofv3 --pmc summary of this same command (tools/profile_round.sh ->
     # profiles/*/traffic.json, FETCH_SIZE doubled per the gfx950 correction) is reported.
     traffic = None
-    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "traffic.json")))      # round tags sort by name: r01_b < ... < r01_h
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "traffic.json")))      # round tags sort by name
     for cand in reversed(cands):
         with open(cand) as f:
             tj = json.load(f)
-        if tj.get("workload", "yolox_s_glfusion_1344x800_bs8") == args.workload and args.dtype == "f16":
+        if tj.get("workload", "yolox_s_glfusion_1344x800_bs8") == workload and args.dtype == "f16":
             traffic = round(tj["hbm_bytes_per_launch"])
             break
-    roofline = {"bound": "mfma", "kernel": "conv family: conv_igemm + conv_halo + conv1x1_ws (all instantiations)",
-                "achieved": round(achieved, 2), "peak": PEAK_F16_TFLOPS if args.dtype == "f16" else 157.3,
-                "unit": "TFLOP/s", "frac": round(achieved / (PEAK_F16_TFLOPS if args.dtype == "f16" else 157.3), 4),
+    roofline = {"bound": "mfma", "kernel": "conv family: conv_igemm + conv_halo + conv1x1_ws + fused bottleneck (all instantiations)",
+                "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
+                "achieved_end_to_end": round(e2e, 2), "frac_end_to_end": round(e2e / peak, 4),
+                "frac_note": "frac: algorithmic conv FLOPs / sum of conv launch durations, ONE stream (HIP events); "
+                             "frac_end_to_end: all algorithmic FLOPs / wall clock per step, %d batches in flight" % nstreams,
                 "traffic": traffic, "traffic_unit": "HBM bytes per conv launch (rocprofv3 PMC, profiles/)",
                 "algorithmic_bytes_per_launch": round(bs * alg_bytes / max(1, len(conv))),
                 "launches_per_step": len(conv),
@@ -380,40 +456,146 @@ def main():
                 "algorithmic_gflop_per_image": round(2.0 * (alg_conv_gmac + alg_mm_gmac), 2),
                 "executed_conv_gflop_per_image": round(executed_conv_flops / bs / 1e9, 2)}
     if args.op_table and rank == 0:
-        with open(args.op_table, "w") as f:
+        path = args.op_table if workload == args.workload else args.op_table + "." + workload
+        with open(path, "w") as f:
             f.write("idx\tkind\tms\tgflop\ttflops\tMB\tGBps\tname\n")
             for i, (o, t) in enumerate(zip(ops, ms)):
                 f.write("%d\t%d\t%.4f\t%.3f\t%.1f\t%.2f\t%.0f\t%s\n" % (
                     i, o["kind"], t, o["flops"] / 1e9, o["flops"] / max(t, 1e-6) / 1e9, o["bytes"] / 1e6,
                     o["bytes"] / max(t, 1e-6) / 1e6, o["name"]))
 
-    if kind in RESDET:      # stage-1 counters: [image][level] pairs above the threshold
+    if kind in RESDET:      # stage-1 counters: [image][level] pairs above the threshold; NMS input = per-level top-k merged
         nl = len(c.cls)
         cand_counts = c.nb["ws"][: 4 * bs * nl].view(torch.int32).view(bs, nl).sum(1).cpu().tolist()
+        nms_in = [int(min(v, post["nms_pre"] * nl)) for v in cand_counts]
+        unclamped = c.nb["count"][bs:2 * bs].cpu().tolist()
     else:
         cand_counts = [int(v) for v in c.nmsb["ws"][: 4 * bs].view(torch.int32).cpu().tolist()]
+        nms_in = cand_counts
+        unclamped = c.nmsb["count"][bs:2 * bs].cpu().tolist()
+    suppressed = 1.0 - float(sum(unclamped)) / max(1, sum(nms_in))
+    n_img = bs * world * args.steps
+    res = {"workload": workload, "value": round(n_img / elapsed, 2), "unit": "img/s",
+           "ms_per_step": round(wall_ms, 4),
+           "config": {"workload": workload, "detector": DETECTOR_NAME[kind],
+                      "input": [bs, 3, H, W], "images_per_gpu": bs, "global_batch": bs * world, "num_classes": 10,
+                      "post": post, "head_calibration": calib, "hip_graph": not args.no_graph,
+                      "batches_in_flight": nstreams, "input_from_host_each_step": bool(args.from_host),
+                      "detections_per_image_rank0": [int(len(d)) for d in dets],
+                      "candidates_per_image_rank0": cand_counts,
+                      "suppressed_frac": round(suppressed, 4),
+                      "detections_read_back_in_timed_loop_rank0": read_back[0],
+                      "parallelism": "image-sharded dp%d, one all_gather of detections per step" % world},
+           "roofline": roofline}
+    if with_cpu_baseline:
+        res["cpu_baseline"] = resdet_cpu_baseline(sd, kind, H, W, post["score_thr"], post["max_per_img"]) \
+            if kind in RESDET else cpu_baseline(sd, kind, bs, H, W, args.conf, args.nms)
+    del cs, c, det, exch
+    torch.cuda.empty_cache()
+    return res
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start N fresh processes (this one has not touched the GPU),
+    rank r on GPU r, rendezvous on 127.0.0.1.  Rank 0 inherits stdout and prints the line."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    try:
+        while any(p.poll() is None for p in procs):
+            for p in procs:
+                if p.poll() not in (None, 0):            # one rank failed: stop the others (exact PIDs)
+                    rc = p.returncode
+                    for q in procs:
+                        if q.poll() is None:
+                            q.terminate()
+            time.sleep(0.2)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return rc or max(abs(p.returncode or 0) for p in procs)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="yolox_s_glfusion_1344x800_bs8", choices=sorted(WORKLOADS))
+    ap.add_argument("--dtype", default="f16", choices=["f16", "f32"])
+    ap.add_argument("--conf", type=float, default=0.25)
+    ap.add_argument("--candidates", type=int, default=2000,
+                    help="calibrate the objectness bias so that about this many anchors per image pass --conf")
+    ap.add_argument("--suppress", type=float, default=0.5,
+                    help="calibrate the box branch so that NMS suppresses about this fraction of the candidates")
+    ap.add_argument("--max-det", type=int, default=3000)
+    ap.add_argument("--exchange-cap", type=int, default=1000,
+                    help="rows per image of the all_gather record (N>1); the reference's evaluation keeps maxDets<=500")
+    ap.add_argument("--nms", type=float, default=0.65)
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--from-host", action="store_true",
+                    help="diagnostic: every step first copies its fp32 batch from pinned host memory (the "
+                         "PCIe-inclusive rate quoted in DESIGN.md; never the headline value)")
+    ap.add_argument("--streams", type=int, default=3,
+                    help="plan instances replayed round-robin on their own HIP streams (batches in flight)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend; gloo is for rehearsing the N>1 control flow on a box with fewer "
+                         "GPUs than ranks (ranks then share devices round-robin) -- never for a reported number")
+    ap.add_argument("--no-autotune", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the BASELINE config-3 leg (`secondary`)")
+    ap.add_argument("--op-table", default="", help="write the per-op timing table (tsv) here")
+    args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args.gpus))                 # before any GPU call of this process
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d (launch one rank per GPU, or drop the launcher and let "
+                 "bench.py start the ranks itself)" % (args.gpus, world))
+    if args.backend == "gloo":
+        local_rank %= max(1, torch.cuda.device_count())
+    torch.cuda.set_device(local_rank)
+    dev = "cuda:%d" % local_rank
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if args.backend == "gloo":
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device(dev))
+
+    base = world == 1 and not args.no_cpu_baseline
+    main_res = run_workload(args, args.workload, rank, world, dev, base)
+    second = None
+    if not args.no_secondary and args.workload != SECONDARY:
+        second = run_workload(args, SECONDARY, rank, world, dev, base)
     if rank == 0:
-        n_img = bs * world * args.steps
         line = {
             "metric": "images/sec fwd @1333x800 bs=8 (detection forward incl. decode+NMS)",
-            "value": round(n_img / elapsed, 2), "unit": "img/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "value": main_res["value"], "unit": "img/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": main_res["ms_per_step"],
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": args.workload,
-                       "detector": {"gl": "YOLOX-s + GL-fusion neck", "base": "YOLOX-s", "gfl": "GFL ResNet-50 + FPN",
-                                    "mpdet": "MPDet ResNet-50 + FPN + MPHead"}[kind],
-                       "input": [bs, 3, H, W], "images_per_gpu": bs, "global_batch": bs * world, "num_classes": 10,
-                       "post": post, "hip_graph": not args.no_graph,
-                       "batches_in_flight": nstreams, "input_from_host_each_step": bool(args.from_host),
-                       "detections_per_image_rank0": [int(len(d)) for d in dets],
-                       "candidates_per_image_rank0": cand_counts,
-                       "parallelism": "image-sharded dp%d, one all_gather of detections per step" % world},
-            "roofline": roofline,
+            "config": main_res["config"], "roofline": main_res["roofline"],
         }
-        if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = resdet_cpu_baseline(sd, kind, H, W, post["score_thr"]) if kind in RESDET else \
-                cpu_baseline(sd, kind, bs, H, W, args.conf, args.nms)
+        if "cpu_baseline" in main_res:
+            line["cpu_baseline"] = main_res["cpu_baseline"]
+        if second is not None:
+            line["secondary"] = dict(second, metric=line["metric"], n_gpus=world, steps=args.steps, warmup=args.warmup,
+                                     dtype=args.dtype, note="BASELINE.json configs[2] (mp_det_res50: ResNet-50 + GL-fusion + "
+                                     "decoupled MPHead, 1333x800 bs=8), same protocol as the primary line")
         print(json.dumps(line))
     if world > 1:
         dist.barrier()

@@ -10,7 +10,7 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "lib", "libglsdet_hip.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 CAPTURE_LOCK = threading.RLock()        # hipGraph captures are serialised across host threads
 
 F16, F32 = 0, 1
@@ -64,6 +64,7 @@ _SIGS = {
     "glsdet_nms": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_float,
                              C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                              C.c_int64, C.c_void_p]),
+    "glsdet_pack_detections": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "glsdet_nchw_pack": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(View), C.c_void_p]),
     "glsdet_pool2d": (C.c_int, [C.POINTER(View), C.POINTER(View), C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "glsdet_upsample_add": (C.c_int, [C.POINTER(View), C.POINTER(View), C.c_void_p]),

@@ -561,17 +561,14 @@ static int build_conv_op(const glsdet_conv_desc* d, int hint, OpRecord& op) {
   const int xdt = x.dtype, ydt = y.dtype;
   // tile_hint: 0 auto, 1 generic kernel, 2 halo kernel, 4 halo kernel with wave-private weight staging,
   // 5 halo kernel with 64-row cout tiles also for wide layers,
-  // 8 / 9 halo kernel with the weight tiles in an LDS-DMA ring, 6 / 7 persistent LDS-DMA halo kernel (64- / 128-row
-  // cout tiles), 3 weight-stationary 1x1 kernel,
+  // 8 / 9 halo kernel with the weight tiles in an LDS-DMA ring (10 / 11: 64-byte channel chunks), 3 weight-stationary
+  // 1x1 kernel (6 / 7 were the persistent LDS-DMA halo kernel, removed in round 2: 1.3-1.9x slower),
   // else co<<16|px (generic)
   if (hint == 3) {
     if (conv1x1_ws_try(a, xdt, ydt, &op) == 0) return 0;
     GLS_FAIL(GLSDET_E_ARG, "conv2d: the weight-stationary 1x1 kernel does not apply to this problem");
   }
-  if (hint == 6 || hint == 7) {
-    if (conv_halo_dma_try(a, xdt, ydt, hint, &op) == 0) return 0;
-    GLS_FAIL(GLSDET_E_ARG, "conv2d: the LDS-DMA halo kernel does not apply to this problem");
-  }
+  if (hint == 6 || hint == 7) GLS_FAIL(GLSDET_E_ARG, "conv2d: tile_hint 6 / 7 (persistent LDS-DMA halo kernel) no longer exist");
   if (conv_halo_try(a, xdt, ydt, hint, &op) == 0) return 0;
   if (hint == 2 || hint == 4 || hint == 5 || (hint >= 8 && hint <= 11)) GLS_FAIL(GLSDET_E_ARG, "conv2d: the halo kernel does not apply to this problem");
 

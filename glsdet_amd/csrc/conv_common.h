@@ -236,8 +236,6 @@ __device__ __forceinline__ void halo_store_tile(const unsigned char* stile, cons
 
 // host-side dispatch of the halo kernel (conv_halo.hip); returns 1 if it does not apply
 int conv_halo_try(const ConvArgs& a, int xdt, int ydt, int hint, OpRecord* op);
-// the same problem class with LDS-DMA staging (conv_halo_dma.hip), tile_hint 6 / 7; returns 1 if it does not apply
-int conv_halo_dma_try(const ConvArgs& a, int xdt, int ydt, int hint, OpRecord* op);
 // weight-stationary persistent 1x1 kernel (conv1x1.hip), tile_hint 3; returns 1 if it does not apply
 int conv1x1_ws_try(const ConvArgs& a, int xdt, int ydt, OpRecord* op);
 

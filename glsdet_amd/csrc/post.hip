@@ -620,6 +620,49 @@ extern "C" int glsdet_gfl_detect(const glsdet_view* cls, const glsdet_view* reg,
   return submit(std::move(op), stream);
 }
 
+// ---- detections -> fixed-capacity exchange record (the payload of the one all_gather) -------------
+// out[img][0..cap) = the first min(count, cap) rows (score order), zero rows behind them; out[img][cap] = (count kept
+// here, count before the cap, 0...).  One thread per float of the record.
+__global__ __launch_bounds__(256) void pack_dets_kernel(const float* __restrict__ dets, const int* __restrict__ count,
+                                                        int n, int max_det, int cap, float* __restrict__ out) {
+  const long per = (long)(cap + 1) * 7;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n * per; i += (long)gridDim.x * 256) {
+    const int img = (int)(i / per);
+    const int r = (int)((i - img * per) / 7), f = (int)(i - img * per - r * 7);
+    int c = count[img];
+    c = c < max_det ? c : max_det;
+    const int kept = c < cap ? c : cap;
+    float v = 0.f;
+    if (r < cap) {
+      if (r < kept) v = dets[((long)img * max_det + r) * 7 + f];
+    } else if (f == 0) {
+      v = (float)kept;
+    } else if (f == 1) {
+      v = (float)count[n + img];
+    }
+    out[i] = v;
+  }
+}
+
+extern "C" int glsdet_pack_detections(const float* dets, const int32_t* count, int32_t n, int32_t max_det, int32_t cap,
+                                      float* out, void* stream) {
+  if (!dets || !count || !out) GLS_FAIL(GLSDET_E_ARG, "pack_detections: null argument");
+  if (n < 1 || max_det < 1 || cap < 1) GLS_FAIL(GLSDET_E_ARG, "pack_detections: bad sizes");
+  OpRecord op;
+  op.kind = 6;
+  op.flops = 0;
+  op.bytes = 2.0 * n * (cap + 1) * 28.0;
+  op.name = "pack_detections";
+  op.launch = [=](hipStream_t st) -> int {
+    long g = ((long)n * (cap + 1) * 7 + 255) / 256;
+    if (g > 2048) g = 2048;
+    hipLaunchKernelGGL(pack_dets_kernel, dim3((unsigned)g), dim3(256), 0, st, dets, count, n, max_det, cap, out);
+    GLS_HIP(hipGetLastError());
+    return 0;
+  };
+  return submit(std::move(op), stream);
+}
+
 extern "C" int64_t glsdet_ufp_merge_workspace_bytes(int32_t max_cand) {
   if (max_cand < 1) return 0;
   return nms_layout(1, max_cand, nullptr, nullptr, true);

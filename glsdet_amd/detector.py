@@ -30,7 +30,8 @@ class HipDetector:
     # ------------------------------------------------------------------ compile
     def compile(self, n: int, H: int, W: int, post: Optional[dict] = None, use_graph: bool = False,
                 instance: int = 0) -> _Compiled:
-        """post: None (raw logits only) or dict(conf_thres, nms_thres, max_cand, max_det, mode).
+        """post: None (raw logits only) or dict(conf_thres, nms_thres, max_cand, max_det, mode, exchange_cap);
+        exchange_cap = K appends the multi-GPU exchange record ([n, K+1, 7], Engine.pack_detections) to the plan.
         `instance` > 0 builds an independent copy (own buffers, own stream) of the same plan, so
         consecutive batches can be in flight concurrently (see run_async)."""
         key = (n, H, W, tuple(sorted(post.items())) if post else None, use_graph, instance)
@@ -56,6 +57,8 @@ class HipDetector:
                                        scale_factors=c.scale)
                 c.nmsb = eng.nms_buffers(n, A, min(post.get("max_cand", A), A), post.get("max_det", 1000))
                 eng.nms(c.decoded, self.num_classes, post.get("mode", 0), post["conf_thres"], post["nms_thres"], c.nmsb)
+                if post.get("exchange_cap"):
+                    eng.pack_detections(c.nmsb, int(post["exchange_cap"]))
         eng.save_tune_cache()
         c.graph_stream = None
         if use_graph:

@@ -4,8 +4,11 @@ The forward pass shards by image (no cross-image op at inference), one process p
 The only exchange is the gather of per-rank detections before evaluation.  The reference
 does it with two all_gathers of pickled uint8 payloads (size exchange, then zero-padded
 bytes: ufp/mmdet/apis/test.py:161-191); here it is ONE fixed-capacity all_gather of an
-fp32 tensor [imgs_per_rank, max_det + 1, 7] whose last row carries the count -- no pickle,
-no size round trip, latency-bound on xGMI (a few hundred KB per rank).
+fp32 record [imgs_per_rank, cap + 1, 7] whose last row carries the counts -- no pickle,
+no size round trip, latency-bound on xGMI (cap = 1000 rows: 224 KB per rank and step).
+The record is written by a kernel of the plan (glsdet_pack_detections, captured into the
+hipGraph with the forward pass); `DetectionExchange` owns the preallocated receive buffer,
+so a step allocates nothing and copies nothing on the host side.
 
 Image -> rank mapping follows the reference's DistributedSampler order that
 collect_results_* un-interleaves (test.py:150-155,186-190): image i lives on rank
@@ -44,6 +47,25 @@ def gather_detections(dets: torch.Tensor, count: torch.Tensor, group=None) -> to
     out = torch.empty((world * n,) + tuple(packed.shape[1:]), dtype=packed.dtype, device=packed.device)
     dist.all_gather_into_tensor(out, packed, group=group)       # rank-major concatenation
     return out.view((world, n) + tuple(packed.shape[1:]))
+
+
+class DetectionExchange:
+    """Per plan instance: the preallocated receive buffer of the one all_gather.  `packed` is the
+    [n, cap+1, 7] record the plan's glsdet_pack_detections op writes (Engine.pack_detections)."""
+
+    def __init__(self, packed: torch.Tensor, group=None):
+        self.packed, self.group = packed, group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        n = packed.shape[0]
+        self.out = packed.new_empty((self.world * n,) + tuple(packed.shape[1:])) if self.world > 1 else None
+
+    def gather(self) -> torch.Tensor:
+        """-> [world, n, cap+1, 7] on every rank; enqueued on the current stream (call it under the
+        stream the plan was launched on, after the launch)."""
+        if self.world == 1:
+            return self.packed[None]
+        dist.all_gather_into_tensor(self.out, self.packed, group=self.group)      # rank-major concatenation
+        return self.out.view((self.world,) + tuple(self.packed.shape))
 
 
 def unpack_in_dataset_order(gathered: torch.Tensor, num_images: Optional[int] = None) -> List[np.ndarray]:

@@ -147,6 +147,10 @@ class Engine:
             with open(self._tune_cache_path) as f:
                 self._tuned.update({tuple(json.loads(k)): v for k, v in json.load(f).get(dtype, {}).items()})
         self._dtype_name = dtype
+        # verification (tools/variant_check.py): {"hint": h, "multi": h or None, "log": []} -- every conv also runs
+        # on kernel variant h into a scratch tensor (same operands, before the real launch) and the two results are
+        # compared element by element; eager emission only
+        self.shadow = None
 
     # ---- memory
     def raw(self, nbytes: int) -> torch.Tensor:
@@ -215,13 +219,17 @@ class Engine:
                 self._tuned[key] = best.value
                 self._tune_dirty = True
             d.tile_hint = self._tuned[key]
-        forced = os.environ.get("GLSDET_FORCE_HINT")          # verification runs (tools/variant_check.py): every conv
-        if forced and tile_hint == 0:                          # uses this variant wherever it accepts the problem
+        sh = None
+        if self.shadow is not None and tile_hint == 0 and self.shadow.get("hint"):
+            sh = self._shadow_begin([d], [out], self.shadow["hint"], multi=False)
+        forced = os.environ.get("GLSDET_FORCE_HINT")          # verification runs: every conv uses this variant
+        if forced and tile_hint == 0:                          # wherever it accepts the problem
             d.tile_hint = int(forced, 0)
             if self.lib.glsdet_conv2d(C.byref(d), _stream_ptr(self.stream)) == 0:
                 return out
             d.tile_hint = 0
         check(self.lib.glsdet_conv2d(C.byref(d), _stream_ptr(self.stream)), "conv2d")
+        self._shadow_end(sh)
         return out
 
     def conv_multi(self, xs: Sequence[TView], packs, stride: int, pad: int, act: str,
@@ -243,6 +251,9 @@ class Engine:
             d.res = ress[i].as_c() if ress[i] is not None else View()
             d.w, d.scale, d.bias = wdev.data_ptr(), sdev.data_ptr(), bdev.data_ptr()
             d.R, d.S, d.stride, d.pad, d.act, d.tile_hint = R, S, stride, pad, ACT[act], tile_hint
+        sh = None
+        if self.shadow is not None and self.shadow.get("multi"):
+            sh = self._shadow_begin([arr[i] for i in range(n)], outs, self.shadow["multi"], multi=True)
         forced = os.environ.get("GLSDET_FORCE_MULTI_HINT")
         if forced and tile_hint == 0:
             arr[0].tile_hint = int(forced, 0)
@@ -250,6 +261,7 @@ class Engine:
                 return outs
             arr[0].tile_hint = 0
         check(self.lib.glsdet_conv2d_multi(arr, n, _stream_ptr(self.stream)), "conv2d_multi")
+        self._shadow_end(sh)
         return outs
 
     def conv_group(self, xs: Sequence[TView], packs, stride: int, pad: int, act: str,
@@ -295,6 +307,33 @@ class Engine:
         if hint < 0:
             return separate()
         return self.conv_multi(xs, packs, stride, pad, act, outs=outs, ress=ress, tile_hint=hint)
+
+    def _shadow_begin(self, descs, outs, hint: int, multi: bool):
+        """Run the conv(s) on kernel variant `hint` into dense scratch tensors BEFORE the real launch (an in-place
+        conv still sees its original residual).  -> state for _shadow_end, or None if the variant declines."""
+        n = len(descs)
+        arr = (ConvDesc * n)()
+        tmps = []
+        for i, (d, o) in enumerate(zip(descs, outs)):
+            C.memmove(C.addressof(arr[i]), C.addressof(d), C.sizeof(ConvDesc))
+            t = self.tensor(o.n, o.h, o.w, o.c, o.dtype)
+            tmps.append(t)
+            arr[i].y = t.as_c()
+            arr[i].tile_hint = hint
+        st = _stream_ptr(self.stream)
+        rc = self.lib.glsdet_conv2d_multi(arr, n, st) if multi else self.lib.glsdet_conv2d(C.byref(arr[0]), st)
+        if rc != 0:                       # the variant does not take this problem
+            return None
+        return [(d.x.n, d.x.h, d.x.w, d.x.c, o.c, d.R, d.stride) for d, o in zip(descs, outs)], list(outs), tmps
+
+    def _shadow_end(self, state):
+        """After the real launch: element-wise distance of the variant's result from it."""
+        if state is None:
+            return
+        for shape, o, t in zip(*state):
+            a, b = o.to_nchw(), t.to_nchw()
+            self.shadow["log"].append({"shape": shape, "scale": float(a.abs().max()), "err": float((a - b).abs().max()),
+                                       "nan": bool(torch.isnan(b).any()), "differ": float((a != b).float().mean())})
 
     def pack_dw(self, w: torch.Tensor, scale: torch.Tensor, bias: torch.Tensor, c_pad: int):
         """depthwise weights [C,1,R,S] -> ([R*S][c_pad] in engine dtype, scale, bias, C, R, S)"""
@@ -402,6 +441,16 @@ class Engine:
                                   nb["status"].data_ptr(), nb["ws"].data_ptr(), nb["ws"].numel(),
                                   _stream_ptr(self.stream)), "nms")
         return nb["dets"], nb["count"], nb["status"]
+
+    def pack_detections(self, nb, cap: int) -> torch.Tensor:
+        """Append the fixed-capacity exchange record of the multi-GPU path to the op sequence:
+        nb["packed"] = fp32 [n, cap+1, 7] (glsdet_pack_detections), allocated once here."""
+        n = nb["dets"].shape[0]
+        if "packed" not in nb or nb["packed"].shape[1] != cap + 1:
+            nb["packed"] = torch.zeros(n, cap + 1, 7, dtype=torch.float32, device=self.device)
+        check(self.lib.glsdet_pack_detections(nb["dets"].data_ptr(), nb["count"].data_ptr(), n, nb["max_det"], cap,
+                                              nb["packed"].data_ptr(), _stream_ptr(self.stream)), "pack_detections")
+        return nb["packed"]
 
     # ------------------------------------------------------------------ ResNet / FPN / GFL / MPHead ops
     def nchw_pack(self, img: torch.Tensor, out: Optional[TView] = None) -> TView:

@@ -36,6 +36,14 @@ class NetBuilder:
         self.e = eng
         self.sd = {k: v.detach().cpu() for k, v in sd.items()}
         self._packed = {}
+        self.trace = None       # tests: dict name -> NCHW fp32 snapshot of every stored tensor (eager emission only)
+
+    def _rec(self, name: str, v: TView, c0: int = 0, c1: Optional[int] = None):
+        """Per-layer trace for the parity tests (tests/test_f16_emulation.py): a snapshot of the tensor the
+        op at `name` just stored.  Only meaningful when ops are emitted eagerly (outside a plan)."""
+        if self.trace is not None:
+            t = v.to_nchw()
+            self.trace[name] = t[:, c0:(c1 if c1 is not None else t.shape[1])].cpu()
 
     # ------------------------------------------------------------------ weights
     def _bn_part(self, p: str):
@@ -73,7 +81,12 @@ class NetBuilder:
         parts = [self._bn_part(p) for p in prefixes]
         k = parts[0][0].shape[-1]
         pk = self._pack("+".join(prefixes), parts, x.c)
-        return self.e.conv(x, pk, stride, (k - 1) // 2, act, out=out, res=res)
+        y = self.e.conv(x, pk, stride, (k - 1) // 2, act, out=out, res=res)
+        c0 = 0
+        for p, pt in zip(prefixes, parts):
+            self._rec(p, y, c0, c0 + pt[0].shape[0])
+            c0 += pt[0].shape[0]
+        return y
 
     def cba_group(self, prefixes: Sequence[str], xs: Sequence[TView], stride: int = 1, act: str = "silu",
                   outs: Optional[Sequence[Optional[TView]]] = None) -> List[TView]:
@@ -85,7 +98,10 @@ class NetBuilder:
         parts = [self._bn_part(p) for p in prefixes]
         k = parts[0][0].shape[-1]
         packs = [self._pack(p, [pt], x.c) for p, pt, x in zip(prefixes, parts, xs)]
-        return self.e.conv_group(xs, packs, stride, (k - 1) // 2, act, outs=outs)
+        ys = self.e.conv_group(xs, packs, stride, (k - 1) // 2, act, outs=outs)
+        for p, pt, y in zip(prefixes, parts, ys):
+            self._rec(p, y, 0, pt[0].shape[0])
+        return ys
 
     def _dw_separable(self, prefixes, x: TView, stride, act, out, res) -> TView:
         """DWConv (baseConv.py:22-30): depthwise kxk (+BN+act) then pointwise 1x1 (+BN+act).
@@ -104,9 +120,11 @@ class NetBuilder:
             if key not in self._packed:
                 self._packed[key] = self.e.pack_dw(w, s, b, x.c)
             t = self.e.dwconv(x, self._packed[key], stride, (k - 1) // 2, act)
+            self._rec(p + ".dconv", t, 0, w.shape[0])
             dst = out if len(prefixes) == 1 else out.channels(c0, c0 + co)
             pk = self._pack(p + ".pconv", [self._bn_part(p + ".pconv")], t.c)
             self.e.conv(t, pk, 1, 0, act, out=dst, res=res)
+            self._rec(p + ".pconv", dst, 0, co)
             c0 += co
         return out
 
@@ -114,7 +132,9 @@ class NetBuilder:
               res: Optional[TView] = None) -> TView:
         """nn.Conv2d with bias, no norm; activation / residual add only where the caller fuses one."""
         pk = self._pack(p, [self._plain_part(p)], x.c)
-        return self.e.conv(x, pk, 1, pad, act, out=out, res=res)
+        y = self.e.conv(x, pk, 1, pad, act, out=out, res=res)
+        self._rec(p, y, 0, pk[3])
+        return y
 
     def conv_out_channels(self, p: str) -> int:
         if self.is_depthwise(p):
@@ -172,12 +192,16 @@ class NetBuilder:
         key = p + ".tpg"
         parts = [self._plain_part(p + ".theta"), self._plain_part(p + ".phi"), self._plain_part(p + ".g")]
         tpg = self.e.conv(x, self._pack(key, parts, x.c), 1, 0, "none")
+        for j, nm in enumerate(("theta", "phi", "g")):
+            self._rec("%s.%s" % (p, nm), tpg, j * ci, (j + 1) * ci)
         if key + ".out" not in self._packed:
             w = self.sd[p + ".conv_out.weight"].float().reshape(-1, ci)
             self._packed[key + ".out"] = (self.e.upload(w), self.e.upload(self.sd[p + ".conv_out.bias"].float()))
         wout, bout = self._packed[key + ".out"]
         assert wout.shape[0] == x.c, "Non_local_Block conv_out must map back to the input channels"
-        return self.e.nonlocal_(x, tpg, ci, wout, bout, out=x)
+        y = self.e.nonlocal_(x, tpg, ci, wout, bout, out=x)
+        self._rec(p + ".conv_out", y)
+        return y
 
     def nonlocal_blocks(self, ps: Sequence[str], xs: Sequence[TView]) -> List[TView]:
         """Several independent non-local blocks (the four quadrants), each in place on its x: the
@@ -188,6 +212,9 @@ class NetBuilder:
             parts = [self._plain_part(p + ".theta"), self._plain_part(p + ".phi"), self._plain_part(p + ".g")]
             packs.append(self._pack(p + ".tpg", parts, x.c))
         tpgs = self.e.conv_group(xs, packs, 1, 0, "none")
+        for p, tpg in zip(ps, tpgs):
+            for j, nm in enumerate(("theta", "phi", "g")):
+                self._rec("%s.%s" % (p, nm), tpg, j * ci, (j + 1) * ci)
         wouts, bouts = [], []
         for p, x in zip(ps, xs):
             key = p + ".tpg"
@@ -199,8 +226,12 @@ class NetBuilder:
             wouts.append(wout)
             bouts.append(bout)
         if len({(x.n, x.c) for x in xs}) == 1 and len(xs) <= 4 and not os.environ.get("GLSDET_NO_GROUP"):
-            return self.e.nonlocal_multi(xs, tpgs, ci, wouts, bouts)
-        return [self.e.nonlocal_(x, tpg, ci, w, b, out=x) for x, tpg, w, b in zip(xs, tpgs, wouts, bouts)]
+            ys = self.e.nonlocal_multi(xs, tpgs, ci, wouts, bouts)
+        else:
+            ys = [self.e.nonlocal_(x, tpg, ci, w, b, out=x) for x, tpg, w, b in zip(xs, tpgs, wouts, bouts)]
+        for p, y in zip(ps, ys):
+            self._rec(p + ".conv_out", y)
+        return ys
 
     def patch_conv(self, p: str, x: TView, stride: int, with_nonlocal: bool, out: Optional[TView] = None) -> TView:
         """Patch_Conv / Patch_Conv_NonLocal (Identity_Conv.py:267-387)."""
@@ -255,6 +286,7 @@ class NetBuilder:
         """SpatialAttention (new/Non_local_family.py:423-436) -> [n,h,w,8] view, channel 0 valid."""
         k = self.sd[p + ".conv.weight"].shape[-1]
         mm = self.e.channel_maxmean(x)
+        self._rec(p + ".maxmean", mm, 0, 2)
         return self.plain(p + ".conv", mm, pad=k // 2, act="sigmoid")
 
     def identity_conv(self, p: str, x: TView, out: Optional[TView] = None) -> TView:
@@ -374,10 +406,12 @@ class NetBuilder:
         return outs
 
 
-def build_forward(kind: str, eng: Engine, sd, img: torch.Tensor):
+def build_forward(kind: str, eng: Engine, sd, img: torch.Tensor, trace: Optional[dict] = None):
     """Emit the whole raw forward of a `kind` in {'base','gl','cross'} detector for the static input
-    tensor `img` (NCHW fp32 on the device).  Returns (list of fp32 level views, num_classes)."""
+    tensor `img` (NCHW fp32 on the device).  Returns (list of fp32 level views, num_classes).
+    trace: dict filled with a snapshot of every stored tensor (eager emission only; parity tests)."""
     b = NetBuilder(eng, sd)
+    b.trace = trace
     if kind not in ("base", "gl", "cross"):
         raise ValueError("unknown detector kind %r" % kind)
     feats = b.pafpn("backbone", img, gl=(kind == "gl"))

@@ -254,6 +254,8 @@ class HipGflDetector:
                                        post.get("max_per_img", 100))
                 eng.gfl_detect(c.cls, c.reg, self.cfg["strides"][:L], self.num_classes, self.cfg["reg_max"], H, W,
                                post["score_thr"], post["iou_thr"], c.nb, img_hw=c.img_hw, scale_factors=c.scale)
+                if post.get("exchange_cap"):
+                    eng.pack_detections(c.nb, int(post["exchange_cap"]))
         eng.save_tune_cache()
         c.graph_stream = None
         if use_graph:

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GLSDET_ABI_VERSION 4
+#define GLSDET_ABI_VERSION 5
 
 enum { GLSDET_F16 = 0, GLSDET_F32 = 1 };
 enum { GLSDET_ACT_NONE = 0, GLSDET_ACT_SILU = 1, GLSDET_ACT_RELU = 2, GLSDET_ACT_LRELU = 3,
@@ -85,8 +85,7 @@ typedef struct glsdet_conv_desc {
   int32_t R, S, stride, pad, act;
   int32_t tile_hint;       /* 0 auto | 1 generic | 2 halo (s1 kxk) | 4 halo, wave-private weights | 5 halo, 64-row cout tiles |
                             * 8 / 9 halo with the weight tiles in an LDS-DMA ring (64- / 128-row cout tiles) | 10 / 11 the same with
-                            *   64-byte channel chunks (64 / 128 rows) |
-                            * 6 / 7 persistent LDS-DMA halo (64- / 128-row cout tiles, fp16) | 3 weight-stationary 1x1 |
+                            *   64-byte channel chunks (64 / 128 rows) | 3 weight-stationary 1x1 |
                             * co_tile<<16|px_tile (|0x8000: 64-byte K steps) */
 } glsdet_conv_desc;
 
@@ -189,6 +188,15 @@ int glsdet_nms(const float* pred, int32_t n, int32_t A, int32_t num_classes, int
                float conf_thres, float nms_thres, int32_t max_cand, int32_t max_det,
                float* dets, int32_t* count, int32_t* status,
                void* ws, int64_t ws_bytes, void* stream);
+
+/* The exchange record of the multi-GPU path: replaces the pickled result list that
+ * collect_results_gpu pads and all_gathers (ufp/mmdet/apis/test.py:161-191).
+ *   dets [n][max_det][7], count int32 [2n] as glsdet_nms / glsdet_gfl_detect leave them
+ *   out  fp32 [n][cap+1][7]: rows 0..cap-1 = the first min(count, cap) detections in score order (zero rows
+ *        behind them), row cap = (rows kept here, detections before any cap, 0, 0, 0, 0, 0).
+ * One launch, recordable / capturable like every other op: the record is complete when the plan is.  */
+int glsdet_pack_detections(const float* dets, const int32_t* count, int32_t n, int32_t max_det, int32_t cap,
+                           float* out, void* stream);
 
 /* ---------------------------------------------------------------------------------
  * ResNet-50 / FPN / GFL / MPHead helpers

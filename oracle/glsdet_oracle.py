@@ -16,6 +16,15 @@ Pinning: ``tests/test_oracle_golden.py`` checks this file against golden vectors
 reference calls ``torchvision.ops.boxes.batched_nms`` which is not importable here, so
 ``batched_nms`` below is restated from torchvision's documented semantics and is
 "parity unpinned" (see DESIGN.md).
+
+fp16-storage emulation (``with fp16_storage(): ...``): the same restatement with every
+tensor rounded to fp16 exactly where the HIP path's benchmarked mode stores fp16 -- the
+input image, every conv weight, every conv / non-local output AFTER its fused epilogue
+(BN scale+bias, activation, residual add) -- and fp32 everywhere the HIP path keeps fp32
+(accumulators, BN scale/bias, the non-local Gram / fold matrices and its conv_out weights,
+the head logits, decode, NMS).  It separates kernel error (HIP f16 vs this) from the
+conditioning of the net (this vs the fp32 reference); ``fp16_storage(select=...)`` rounds
+only the named tensors and gives the per-layer attribution table of DESIGN.md.
 """
 from __future__ import annotations
 
@@ -34,6 +43,52 @@ DEPTH = {"nano": 0.33, "tiny": 0.33, "s": 0.33, "m": 0.67, "l": 1.00, "x": 1.33}
 WIDTH = {"nano": 0.25, "tiny": 0.375, "s": 0.50, "m": 0.75, "l": 1.00, "x": 1.25}
 BN_EPS = 1e-3  # drone/models/base/baseConv.py:12
 
+# --------------------------------------------------------------------------- fp16-storage emulation
+_EMU = None          # None: plain fp32.  Else callable(name) -> bool: round the tensor called `name` to fp16
+TRACE = None         # optional dict: name -> the (possibly rounded) tensor every conv-like op produced
+FORCE = None         # optional dict: name -> tensor that REPLACES the op's output after it was traced
+#                      ("teacher forcing": with the HIP path's own stored tensors here, every op of the
+#                      oracle consumes exactly what the corresponding kernel consumed, so a difference at one
+#                      store point is that kernel's own error and nothing propagates to the next)
+
+
+class fp16_storage:
+    """Context manager: emulate the HIP path's fp16 storage (see the module docstring).
+    select: None (round everything the HIP path rounds) or callable(name) -> bool, where name is
+    'input', '<prefix>.weight' for a conv weight or '<prefix>' for the output of the op at <prefix>."""
+
+    def __init__(self, select=None):
+        self.select = select if select is not None else (lambda name: True)
+
+    def __enter__(self):
+        global _EMU
+        self._old, _EMU = _EMU, self.select
+        return self
+
+    def __exit__(self, *exc):
+        global _EMU
+        _EMU = self._old
+        return False
+
+
+def _q(x: Tensor, name: str) -> Tensor:
+    """Store point of the HIP path: round to fp16 (round-to-nearest-even, as v_cvt_f16_f32) when emulating."""
+    if _EMU is not None and x.dtype == torch.float32 and _EMU(name):
+        x = x.half().float()
+    if TRACE is not None:
+        TRACE[name] = x
+    if FORCE is not None and name in FORCE:
+        f = FORCE[name]
+        assert f.shape == x.shape, (name, tuple(f.shape), tuple(x.shape))
+        x = f.to(x.dtype)
+    return x
+
+
+def _qw(w: Tensor, name: str) -> Tensor:
+    if _EMU is not None and w.dtype == torch.float32 and _EMU(name + ".weight"):
+        return w.half().float()
+    return w
+
 
 # --------------------------------------------------------------------------- primitives
 def _act(x: Tensor, kind: str) -> Tensor:
@@ -49,38 +104,51 @@ def _act(x: Tensor, kind: str) -> Tensor:
     raise AttributeError("Unsupported act type: {}".format(kind))
 
 
-def base_conv(sd: SD, p: str, x: Tensor, stride: int = 1, act: str = "silu") -> Tensor:
-    """act(bn(conv(x))), conv without bias, pad=(k-1)//2, eval-mode BN.
-    drone/models/base/baseConv.py:6-16.  groups is inferred from the weight shape."""
-    w = sd[p + ".conv.weight"]
+def base_conv(sd: SD, p: str, x: Tensor, stride: int = 1, act: str = "silu", res: Optional[Tensor] = None) -> Tensor:
+    """act(bn(conv(x))) [+ res], conv without bias, pad=(k-1)//2, eval-mode BN.
+    drone/models/base/baseConv.py:6-16.  groups is inferred from the weight shape.
+    `res` is the Bottleneck shortcut (darknet.py:61-62): the HIP path adds it in the conv epilogue
+    before the one fp16 store, so the emulation rounds after the add."""
+    w = _qw(sd[p + ".conv.weight"], p + ".conv")
     k = w.shape[-1]
     groups = x.shape[1] // w.shape[1]
     y = F.conv2d(x, w, None, stride, (k - 1) // 2, 1, groups)
     y = F.batch_norm(y, sd[p + ".bn.running_mean"], sd[p + ".bn.running_var"],
                      sd[p + ".bn.weight"], sd[p + ".bn.bias"], False, 0.0, BN_EPS)
-    return _act(y, act)
+    y = _act(y, act)
+    if res is not None:
+        y = y + res
+    return _q(y, p)
 
 
-def dw_conv(sd: SD, p: str, x: Tensor, stride: int = 1, act: str = "silu") -> Tensor:
+def dw_conv(sd: SD, p: str, x: Tensor, stride: int = 1, act: str = "silu", res: Optional[Tensor] = None) -> Tensor:
     # drone/models/base/baseConv.py:22-30  depthwise kxk then pointwise 1x1
-    return base_conv(sd, p + ".pconv", base_conv(sd, p + ".dconv", x, stride, act), 1, act)
+    return base_conv(sd, p + ".pconv", base_conv(sd, p + ".dconv", x, stride, act), 1, act, res)
 
 
-def any_conv(sd: SD, p: str, x: Tensor, stride: int = 1, act: str = "silu") -> Tensor:
+def any_conv(sd: SD, p: str, x: Tensor, stride: int = 1, act: str = "silu", res: Optional[Tensor] = None) -> Tensor:
     """BaseConv or DWConv depending on what the checkpoint holds at prefix p."""
     if p + ".dconv.conv.weight" in sd:
-        return dw_conv(sd, p, x, stride, act)
-    return base_conv(sd, p, x, stride, act)
+        return dw_conv(sd, p, x, stride, act, res)
+    return base_conv(sd, p, x, stride, act, res)
 
 
-def plain_conv(sd: SD, p: str, x: Tensor, stride: int = 1, pad: int = 0) -> Tensor:
-    # nn.Conv2d with bias (predictors, non-local projections, Identity_Conv)
-    return F.conv2d(x, sd[p + ".weight"], sd.get(p + ".bias"), stride, pad)
+def plain_conv(sd: SD, p: str, x: Tensor, stride: int = 1, pad: int = 0, store: bool = True,
+               post=None, weights_fp32: bool = False) -> Tensor:
+    """nn.Conv2d with bias (predictors, non-local projections, Identity_Conv).  `post` = what the HIP
+    path fuses into this conv's epilogue before its store (GELU, sigmoid, a residual add);
+    store=False: the output stays fp32 in the HIP path (head logits); weights_fp32: so do the weights."""
+    w = sd[p + ".weight"] if weights_fp32 else _qw(sd[p + ".weight"], p)
+    y = F.conv2d(x, w, sd.get(p + ".bias"), stride, pad)
+    if post is not None:
+        y = post(y)
+    return _q(y, p) if store else y
 
 
 # --------------------------------------------------------------------------- backbone
 def focus(sd: SD, p: str, x: Tensor) -> Tensor:
     # drone/models/base/darknet.py:15-21  order: TL, BL, TR, BR
+    x = _q(x, "input")                                  # glsdet_focus_pack stores the packed image in fp16
     tl, bl = x[..., 0::2, 0::2], x[..., 1::2, 0::2]
     tr, br = x[..., 0::2, 1::2], x[..., 1::2, 1::2]
     return base_conv(sd, p + ".conv", torch.cat((tl, bl, tr, br), 1))
@@ -95,8 +163,9 @@ def spp_bottleneck(sd: SD, p: str, x: Tensor, ks: Sequence[int] = (5, 9, 13)) ->
 
 def bottleneck(sd: SD, p: str, x: Tensor, shortcut: bool) -> Tensor:
     # drone/models/base/darknet.py:43-63
-    y = any_conv(sd, p + ".conv2", base_conv(sd, p + ".conv1", x))
-    return y + x if (shortcut and y.shape[1] == x.shape[1]) else y
+    add = shortcut and sd[p + ".conv1.conv.weight"].shape[1] == \
+        (sd.get(p + ".conv2.conv.weight", sd.get(p + ".conv2.pconv.conv.weight"))).shape[0]
+    return any_conv(sd, p + ".conv2", base_conv(sd, p + ".conv1", x), res=x if add else None)
 
 
 def csp_layer(sd: SD, p: str, x: Tensor, shortcut: bool = True) -> Tensor:
@@ -162,7 +231,8 @@ def non_local_block(sd: SD, p: str, x: Tensor) -> Tensor:
     pw = torch.matmul(th, ph)
     pw = pw / pw.shape[-1]
     y = torch.matmul(pw, g).transpose(1, 2).reshape(n, -1, h, w)
-    return x + plain_conv(sd, p + ".conv_out", y)
+    # HIP path: theta|phi|g stored fp16; Gram, fold and conv_out (weights included) in fp32; one store of x + ...
+    return plain_conv(sd, p + ".conv_out", y, post=lambda t: x + t, weights_fp32=True)
 
 
 def _quadrants(x: Tensor):
@@ -210,16 +280,16 @@ def patch_conv_nonlocal_new(sd: SD, p: str, x: Tensor) -> Tensor:
 def attention(sd: SD, p: str, x: Tensor) -> Tensor:
     """Attention (Non_local_family.py:254-272): proj_1 1x1 -> exact GELU -> quadrant non-local
     gating unit -> proj_2 1x1 -> + shortcut."""
-    y = F.gelu(plain_conv(sd, p + ".proj_1", x))
+    y = plain_conv(sd, p + ".proj_1", x, post=F.gelu)
     y = patch_conv_nonlocal_new(sd, p + ".spatial_gating_unit", y)
-    return plain_conv(sd, p + ".proj_2", y) + x
+    return plain_conv(sd, p + ".proj_2", y, post=lambda t: t + x)
 
 
 def spatial_attention(sd: SD, p: str, x: Tensor) -> Tensor:
     """SpatialAttention (Non_local_family.py:423-436): sigmoid(conv7x7([max_c x, mean_c x]))."""
     k = sd[p + ".conv.weight"].shape[-1]
-    r = torch.cat((x.max(1, keepdim=True)[0], x.mean(1, keepdim=True)), 1)
-    return torch.sigmoid(plain_conv(sd, p + ".conv", r, 1, k // 2))
+    r = _q(torch.cat((x.max(1, keepdim=True)[0], x.mean(1, keepdim=True)), 1), p + ".maxmean")
+    return plain_conv(sd, p + ".conv", r, 1, k // 2, post=torch.sigmoid)
 
 
 def csp_darknet_att(sd: SD, p: str, x: Tensor) -> Dict[str, Tensor]:
@@ -271,9 +341,9 @@ def yolox_head(sd: SD, p: str, feats: Sequence[Tensor]) -> List[Tensor]:
         x = base_conv(sd, "{}.stems.{}".format(p, k), x)
         cls_feat = _tower(sd, "{}.cls_convs.{}".format(p, k), x)
         reg_feat = _tower(sd, "{}.reg_convs.{}".format(p, k), x)
-        outs.append(torch.cat((plain_conv(sd, "{}.reg_preds.{}".format(p, k), reg_feat),
-                               plain_conv(sd, "{}.obj_preds.{}".format(p, k), reg_feat),
-                               plain_conv(sd, "{}.cls_preds.{}".format(p, k), cls_feat)), 1))
+        outs.append(torch.cat((plain_conv(sd, "{}.reg_preds.{}".format(p, k), reg_feat, store=False),
+                               plain_conv(sd, "{}.obj_preds.{}".format(p, k), reg_feat, store=False),
+                               plain_conv(sd, "{}.cls_preds.{}".format(p, k), cls_feat, store=False)), 1))
     return outs
 
 
@@ -295,9 +365,9 @@ def cross_scale_head(sd: SD, p: str, feats: Sequence[Tensor]) -> List[Tensor]:
             parts.append(_up2(lv[k + 1]))
         cls_feat = _tower(sd, "{}.cls_convs.{}".format(p, k), torch.cat(parts, 1))
         reg_feat = _tower(sd, "{}.reg_convs.{}".format(p, k), x)
-        outs.append(torch.cat((plain_conv(sd, "{}.reg_preds.{}".format(p, k), reg_feat),
-                               plain_conv(sd, "{}.obj_preds.{}".format(p, k), reg_feat),
-                               plain_conv(sd, "{}.cls_preds.{}".format(p, k), cls_feat)), 1))
+        outs.append(torch.cat((plain_conv(sd, "{}.reg_preds.{}".format(p, k), reg_feat, store=False),
+                               plain_conv(sd, "{}.obj_preds.{}".format(p, k), reg_feat, store=False),
+                               plain_conv(sd, "{}.cls_preds.{}".format(p, k), cls_feat, store=False)), 1))
     return outs
 
 
