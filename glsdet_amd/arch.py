@@ -212,6 +212,21 @@ def fpn_table(t: "_Table", p: str, in_channels, out_channels: int, start_level: 
             t.plain("%s.fpn_convs.%d.conv" % (p, n_lat + i), cin, out_channels, 3)
 
 
+def gl_fusion_table(t: "_Table", p: str, channels: int, channel_cat: str = "linear"):
+    """Patch_Conv_NonLocal_new(in_channel=C, out_channel=C, channel_scale=1, patch_scale=2, channel_cat)
+    (drone/models/new/Non_local_family.py:208-228), registration order of its __init__: four Non_local_Blocks
+    (g, theta, phi, conv_out: :15-18) with inter_channels = int(channel_scale * C) = C, then channel_conv."""
+    for q in ("lt", "lb", "rt", "rb"):
+        for nm in ("g", "theta", "phi"):
+            t.plain("%s.feat_patchconv_%s_nonlocal.%s" % (p, q, nm), channels, channels, 1)
+        t.plain("%s.feat_patchconv_%s_nonlocal.conv_out" % (p, q), channels, channels, 1)
+    if channel_cat == "linear":
+        t.plain(p + ".channel_conv", channels, channels, 1)
+    else:                                   # BaseConv(C, C, 3, 1, act='silu')
+        t[p + ".channel_conv.conv.weight"] = (channels, channels, 3, 3)
+        _bn(t, p + ".channel_conv.bn", channels)
+
+
 def _gn_tower(t: "_Table", p: str, cin: int, feat: int, stacked: int):
     for name in ("cls_convs", "reg_convs"):
         for i in range(stacked):
@@ -250,13 +265,18 @@ def mp_head_table(t: "_Table", p: str, proxies_list, in_channels: int = 256, fea
 
 def resdet_state_dict_shapes(kind: str, num_classes: int = 10, depth: int = 50, start_level: int = 1,
                              num_outs: int = 5, add_extra_convs="on_output", stacked: int = 4, reg_max: int = 16,
-                             proxies_list=(2, 3, 2, 5, 4, 8, 8, 4, 3, 3)) -> "OrderedDict[str, Tuple[int, ...]]":
-    """kind 'gfl': GFL r50-FPN (SingleStageDetector: backbone / neck / bbox_head); 'mpdet': MPDet."""
+                             proxies_list=(2, 3, 2, 5, 4, 8, 8, 4, 3, 3), gl_fusion: bool = False,
+                             gl_levels=(1, 2, 3), gl_channel_cat: str = "linear") -> "OrderedDict[str, Tuple[int, ...]]":
+    """kind 'gfl': GFL r50-FPN (SingleStageDetector: backbone / neck / bbox_head); 'mpdet': MPDet.
+    gl_fusion: the neck is a GLFusionFPN (plug-ins neck.gl_fusion.<i> on the backbone outputs gl_levels)."""
     if kind not in ("gfl", "mpdet"):
         raise ValueError("kind must be 'gfl' or 'mpdet'")
     t = _Table()
     resnet_table(t, "backbone", depth)
     fpn_table(t, "neck", [256, 512, 1024, 2048], 256, start_level, num_outs, add_extra_convs)
+    if gl_fusion:
+        for i in gl_levels:
+            gl_fusion_table(t, "neck.gl_fusion.%d" % i, [256, 512, 1024, 2048][i], gl_channel_cat)
     if kind == "gfl":
         gfl_head_table(t, "bbox_head", num_classes, 256, 256, stacked, reg_max, num_outs)
     else:

@@ -24,9 +24,9 @@
 namespace glsdet {
 
 template <int CO_T, int PX_T, int KB, typename TO>
-constexpr int conv_lds_bytes() {
+constexpr int conv_lds_bytes(bool wide) {        // wide: fp32 staging of an fp16 output tile (residual layers)
   constexpr int stage = 2 * (CO_T + PX_T) * (KB + 16);
-  constexpr int epi = PX_T * (CO_T * (int)sizeof(TO) + 16);
+  const int epi = epi_bytes<TO>(CO_T, PX_T, wide);
   return stage > epi ? stage : epi;
 }
 
@@ -253,6 +253,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
   if (a.dbg & 4) return;
   // ---- epilogue: fp32 scale/bias/act, transpose through LDS, 16-B channel chunks out
   constexpr int ORS = CO_T * (int)sizeof(TO) + 16;
+  const bool wide = sizeof(TO) == 2 && a.res != nullptr;      // fp32 staging: the residual is added before the one rounding
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -269,13 +270,45 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
         const f32x4 xv = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
         const f32x4 yv = scale_bias_act4<T>(xv, sc, bi, a.act);
         const float v[4] = {yv[0], yv[1], yv[2], yv[3]};
-        store4(smem + px_l * ORS + co_l * (int)sizeof(TO), v, (TO*)nullptr);
+        stage4<TO, CO_T>(smem, px_l, co_l, v, wide);
       }
     }
   }
   __syncthreads();
   constexpr int VO = 16 / (int)sizeof(TO);
   constexpr int OCPR = CO_T / VO;                // 16-B chunks per pixel row of the tile
+  if (wide) {                                    // residual loads batched four deep, fp32 add, one rounding
+    constexpr int ORSW = CO_T * 4 + 16, NITW = (PX_T * OCPR + 255) / 256, EBW = NITW < 4 ? NITW : 4;
+    for (int it0 = 0; it0 < NITW; it0 += EBW) {
+      u32x4 rv[EBW];
+      long yo[EBW];
+      bool ok[EBW];
+#pragma unroll
+      for (int b = 0; b < EBW; ++b) {
+        const int q = tid + (it0 + b) * 256;
+        const int px_l = q / OCPR, cc = q - px_l * OCPR;
+        const int p = px0 + px_l, co = co0 + cc * VO;
+        ok[b] = q < PX_T * OCPR && p < a.M && co < a.Cout;
+        yo[b] = 0;
+        if (ok[b]) {
+          yo[b] = gls_pix_off(p, HoWo, a.Wo, a.y_sn, a.y_sh, a.y_sw, a.y_lin, a) + co;
+          const long ro = gls_pix_off(p, HoWo, a.Wo, a.r_sn, a.r_sh, a.r_sw, a.r_lin, a) + co;
+          rv[b] = *reinterpret_cast<const u32x4*>(a.res + ro * 2);
+        }
+      }
+#pragma unroll
+      for (int b = 0; b < EBW; ++b) {
+        if (ok[b]) {
+          const int q = tid + (it0 + b) * 256;
+          const int px_l = q / OCPR, cc = q - px_l * OCPR;
+          const f32x4 lo = *reinterpret_cast<const f32x4*>(smem + px_l * ORSW + cc * 32);
+          const f32x4 hi = *reinterpret_cast<const f32x4*>(smem + px_l * ORSW + cc * 32 + 16);
+          *reinterpret_cast<u32x4*>(a.y + yo[b] * 2) = add_chunk_wide(lo, hi, rv[b], a.act_post);
+        }
+      }
+    }
+    return;
+  }
   // written in batches of EB chunks per thread: all residual loads of a batch are issued before the
   // first add / store, so a residual layer keeps EB x 16 B per thread in flight instead of one
   // (measured: +3...8 % on the residual 1x1 layers with 64-wide tiles; on the 128x128 tile, 8 chunks
@@ -336,10 +369,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
 }
 
 // Several independent convolutions of the SAME shape class (kernel size, stride, channels, dtypes:
-// the four quadrant convs of the GL-fusion block, the cls/reg tower convs of one level) as ONE
+// the four quadrant convs of the GL-fusion block, the cls/reg tower convs of one level, the per-image /
+// per-quadrant GEMMs of the large-channel non-local block) as ONE
 // launch: each is too small to fill 256 CUs on its own.  The argument blocks travel in the kernarg
 // segment; a workgroup finds its problem from the prefix of tile counts (wave-uniform).
-#define GLS_MULTI 4
+#define GLS_MULTI 8       // 8 x sizeof(ConvArgs) = 2.2 KB of the 4 KB kernarg segment
 struct ConvArgsN {
   ConvArgs p[GLS_MULTI];
   int start[GLS_MULTI + 1];
@@ -357,12 +391,12 @@ __global__ __launch_bounds__(256) void conv_igemm_multi_kernel(const ConvArgsN m
 // ---- host side --------------------------------------------------------------------------
 template <typename T, typename TO, int CO_T, int PX_T, int KB, int WCO, bool UT>
 static int launch_conv(const ConvArgs& a, hipStream_t st) {
-  constexpr int lds = conv_lds_bytes<CO_T, PX_T, KB, TO>();
+  const int lds = conv_lds_bytes<CO_T, PX_T, KB, TO>(a.res != nullptr);
   static bool attr_set = false;
   auto kern = conv_igemm_kernel<T, TO, CO_T, PX_T, KB, WCO, UT>;
-  if (!attr_set && lds > 64 * 1024) {
+  if (!attr_set && conv_lds_bytes<CO_T, PX_T, KB, TO>(true) > 64 * 1024) {
     GLS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+                                hipFuncAttributeMaxDynamicSharedMemorySize, conv_lds_bytes<CO_T, PX_T, KB, TO>(true)));
     attr_set = true;
   }
   ConvArgs b = a;
@@ -380,12 +414,14 @@ static int launch_conv(const ConvArgs& a, hipStream_t st) {
 
 template <typename T, typename TO, int CO_T, int PX_T, int KB, int WCO, bool UT>
 static int launch_conv_multi(const ConvArgsN& m0, hipStream_t st) {
-  constexpr int lds = conv_lds_bytes<CO_T, PX_T, KB, TO>();
+  bool any_res = false;
+  for (int i = 0; i < m0.n; ++i) any_res = any_res || m0.p[i].res != nullptr;
+  const int lds = conv_lds_bytes<CO_T, PX_T, KB, TO>(any_res);
   static bool attr_set = false;
   auto kern = conv_igemm_multi_kernel<T, TO, CO_T, PX_T, KB, WCO, UT>;
-  if (!attr_set && lds > 64 * 1024) {
+  if (!attr_set && conv_lds_bytes<CO_T, PX_T, KB, TO>(true) > 64 * 1024) {
     GLS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+                                hipFuncAttributeMaxDynamicSharedMemorySize, conv_lds_bytes<CO_T, PX_T, KB, TO>(true)));
     attr_set = true;
   }
   ConvArgsN m = m0;

@@ -28,6 +28,7 @@ __global__ __launch_bounds__(256) void conv1x1_ws_kernel(const ConvArgs a, const
   unsigned char* sE = sB + 2 * PX_T * RS;                            // [PX_T][ORS]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const bool wide = sizeof(T) == 2 && a.res != nullptr;              // fp32 staging of the output tile (conv_common.h)
   const auto xrs = gls_make_rsrc(a.x_lo, a.x_bytes);
   const auto wrs = gls_make_rsrc(a.w, a.w_bytes);
   const int n_co = a.n_co_tiles;
@@ -149,7 +150,7 @@ __global__ __launch_bounds__(256) void conv1x1_ws_kernel(const ConvArgs a, const
           const float v[4] = {yv[0], yv[1], yv[2], yv[3]};
 #pragma unroll
           for (int e = 0; e < 4; ++e) acc[i][4 * g + e] = 0.0f;
-          store4(sE + (wpx * 32 + l31) * ORS + co_l * (int)sizeof(T), v, (T*)nullptr);
+          stage4<T, CO_T>(sE, wpx * 32 + l31, co_l, v, wide);
         }
       }
       __syncthreads();
@@ -158,6 +159,15 @@ __global__ __launch_bounds__(256) void conv1x1_ws_kernel(const ConvArgs a, const
         const int px_l = q / OCPR, cq = q - px_l * OCPR;
         const int p = ctile * PX_T + px_l, co = co0 + cq * VEC;
         if (p < a.M && co < a.Cout) {
+          if (wide) {                      // fp32 staging: residual add in fp32, one rounding
+            constexpr int ORSW = CO_T * 4 + 16;
+            const f32x4 lo = *reinterpret_cast<const f32x4*>(sE + px_l * ORSW + cq * 32);
+            const f32x4 hi = *reinterpret_cast<const f32x4*>(sE + px_l * ORSW + cq * 32 + 16);
+            const long ro = gls_pix_off(p, HoWo, a.Wo, a.r_sn, a.r_sh, a.r_sw, a.r_lin, a) + co;
+            const long yo = gls_pix_off(p, HoWo, a.Wo, a.y_sn, a.y_sh, a.y_sw, a.y_lin, a) + co;
+            *reinterpret_cast<u32x4*>(a.y + yo * 2) = add_chunk_wide(lo, hi, *reinterpret_cast<const u32x4*>(a.res + ro * 2), a.act_post);
+            continue;
+          }
           u32x4 v = *reinterpret_cast<const u32x4*>(sE + px_l * ORS + cq * 16);
           if (a.res) {
             const long ro = gls_pix_off(p, HoWo, a.Wo, a.r_sn, a.r_sh, a.r_sw, a.r_lin, a) + co;
@@ -183,7 +193,7 @@ template <typename T, int CO_T>
 static int launch_ws(const ConvArgs& a, hipStream_t st) {
   const int kbytes = a.Cin * (int)sizeof(T);
   const int a_rs = kbytes + 16;
-  const int lds = CO_T * a_rs + 2 * 64 * 144 + 64 * (CO_T * (int)sizeof(T) + 16);
+  const int lds = CO_T * a_rs + 2 * 64 * 144 + epi_bytes<T>(CO_T, 64, a.res != nullptr);
   auto kern = conv1x1_ws_kernel<T, CO_T>;
   static int attr_lds = 0;
   if (lds > 64 * 1024 && lds > attr_lds) {

@@ -161,6 +161,32 @@ __device__ __forceinline__ u32x4 add_chunk(u32x4 a, u32x4 b, float*, int act_pos
 }
 
 
+// fp16 output with a residual: the epilogue stages the conv result in fp32 ("wide" tile rows of CO_T * 4 + 16 bytes)
+// so that residual add (and, for GLSDET_ACT_RES_FIRST, the activation) act on the UNROUNDED value and the sum is
+// rounded to fp16 ONCE -- act(conv*scale+bias) + res as one expression, which is what the fp16-storage emulation of
+// the oracle models (round 2: the per-layer trace showed 28 % of the Bottleneck outputs one ulp off when the conv
+// result was rounded before the add).  lo / hi: the 8 staged floats of a 16-byte output chunk.
+__device__ __forceinline__ u32x4 add_chunk_wide(f32x4 lo, f32x4 hi, u32x4 r, int act_post) {
+  const f16x8 y = __builtin_bit_cast(f16x8, r);
+  f16x8 o;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    float v = (i < 4 ? lo[i] : hi[i - 4]) + (float)y[i];
+    if (act_post) v = apply_act<f16>(v, act_post);
+    o[i] = (f16)v;
+  }
+  return __builtin_bit_cast(u32x4, o);
+}
+// one 4-value group of the accumulator -> the staged tile (wide: fp32 rows, see above)
+template <typename TO, int CO_T>
+__device__ __forceinline__ void stage4(unsigned char* tile, int px_l, int co_l, const float (&v)[4], bool wide) {
+  if (sizeof(TO) == 2 && wide) store4(tile + px_l * (CO_T * 4 + 16) + co_l * 4, v, (float*)nullptr);
+  else store4(tile + px_l * (CO_T * (int)sizeof(TO) + 16) + co_l * (int)sizeof(TO), v, (TO*)nullptr);
+}
+// bytes of the staged output tile of PX pixels
+template <typename TO>
+constexpr int epi_bytes(int co_t, int px, bool wide) { return px * (co_t * (wide ? 4 : (int)sizeof(TO)) + 16); }
+
 // Tile-local pixel index -> (oy, ox) for 16-pixel-wide tiles.  A 32-lane MFMA subtile covers
 // two pixel rows; the patch row pitch PW is not a multiple of 16 rows-of-144-bytes, so the
 // second row would land on the bank sets of the first (2-way conflicts on ds_read_b128).
@@ -186,6 +212,24 @@ __device__ __forceinline__ void halo_store_tile(const unsigned char* stile, cons
   constexpr int VO = 16 / (int)sizeof(TO);
   constexpr int OCPR = CO_T / VO;                 // chunks per pixel
   constexpr int PXS = 256 / OCPR;                 // pixels between two chunks of one thread (a multiple of 16)
+  if (sizeof(TO) == 2 && a.res) {                 // wide staging (fp32 rows): add in fp32, round once
+    constexpr int ORSW = CO_T * 4 + 16;
+    for (int q = tid; q < PX_T * OCPR; q += 256) {
+      const int px_l = q / OCPR, cq = q - px_l * OCPR;
+      int oy, ox;
+      pix_to_xy16<PW>(px_l, oy, ox);
+      const int ho = ty0 + oy, wo = tx0 + ox, co = co0 + cq * VO;
+      if (ho < a.Ho && wo < a.Wo && co < a.Cout) {
+        const f32x4 lo = *reinterpret_cast<const f32x4*>(stile + px_l * ORSW + cq * 32);
+        const f32x4 hi = *reinterpret_cast<const f32x4*>(stile + px_l * ORSW + cq * 32 + 16);
+        const long ro = (long)img * a.r_sn + (long)ho * a.r_sh + (long)wo * a.r_sw + co;
+        const u32x4 v = add_chunk_wide(lo, hi, *reinterpret_cast<const u32x4*>(a.res + ro * 2), a.act_post);
+        const long yo = (long)img * a.y_sn + (long)ho * a.y_sh + (long)wo * a.y_sw + co;
+        *reinterpret_cast<u32x4*>(a.y + yo * 2) = v;
+      }
+    }
+    return;
+  }
   if constexpr (PXS % 16 != 0) {                  // fp32 output with 128-row tiles: 8 pixels apart, plain form
     for (int q = tid; q < PX_T * OCPR; q += 256) {
       const int px_l = q / OCPR, cq = q - px_l * OCPR;

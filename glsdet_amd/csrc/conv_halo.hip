@@ -196,7 +196,7 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const ConvArgs a, const 
   // form nothing else orders them)
   __syncthreads();
   // ---- epilogue (as conv.hip; tile-local pixel -> (oy, ox))
-  constexpr int ORS = CO_T * (int)sizeof(TO) + 16;
+  const bool wide = sizeof(TO) == 2 && a.res != nullptr;      // fp32 staging: the residual is added before the one rounding
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -213,7 +213,7 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const ConvArgs a, const 
         const f32x4 xv = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
         const f32x4 yv = scale_bias_act4<T>(xv, sc, bi, a.act);
         const float v[4] = {yv[0], yv[1], yv[2], yv[3]};
-        store4(smem + px_l * ORS + co_l * (int)sizeof(TO), v, (TO*)nullptr);
+        stage4<TO, CO_T>(smem, px_l, co_l, v, wide);
       }
     }
   }
@@ -410,7 +410,7 @@ __global__ __launch_bounds__(256) void conv_halo_ring_kernel(const ConvArgs a, c
   }
   halo_wait_vm_barrier<0>();                        // the zero fills of the tail have landed; all waves done reading
 
-  constexpr int ORS = CO_T * (int)sizeof(TO) + 16;
+  const bool wide = sizeof(TO) == 2 && a.res != nullptr;
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -427,7 +427,7 @@ __global__ __launch_bounds__(256) void conv_halo_ring_kernel(const ConvArgs a, c
         const f32x4 xv = {acc[i][j][4 * gq], acc[i][j][4 * gq + 1], acc[i][j][4 * gq + 2], acc[i][j][4 * gq + 3]};
         const f32x4 yv = scale_bias_act4<T>(xv, sc, bi, a.act);
         const float v[4] = {yv[0], yv[1], yv[2], yv[3]};
-        store4(smem + px_l * ORS + co_l * (int)sizeof(TO), v, (TO*)nullptr);
+        stage4<TO, CO_T>(smem, px_l, co_l, v, wide);
       }
     }
   }
@@ -439,12 +439,13 @@ template <typename T, typename TO, int CO_T, int KS, int RING, int KB = 128>
 static int launch_halo_ring(const ConvArgs& a, hipStream_t st) {
   constexpr int PH = 8 + KS - 1, PW = 16 + KS - 1;
   constexpr int stage = RING * CO_T * KB + PH * PW * (KB + 16);
-  constexpr int epi = 128 * (CO_T * (int)sizeof(TO) + 16);
-  constexpr int lds = stage > epi ? stage : epi;
+  constexpr int epiw = epi_bytes<TO>(CO_T, 128, true), ldsw = stage > epiw ? stage : epiw;
+  const int epi = epi_bytes<TO>(CO_T, 128, a.res != nullptr);
+  const int lds = stage > epi ? stage : epi;
   auto kern = conv_halo_ring_kernel<T, TO, CO_T, KS, RING, KB>;
   static bool attr_set = false;
-  if (!attr_set && lds > 64 * 1024) {
-    GLS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  if (!attr_set && ldsw > 64 * 1024) {
+    GLS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, ldsw));
     attr_set = true;
   }
   ConvArgs b = a;
@@ -474,12 +475,13 @@ template <typename T, typename TO, int CO_T, int WCO, int KS, int TH, int TW>
 static int launch_halo(const ConvArgs& a, hipStream_t st) {
   constexpr int PH = TH + KS - 1, PW = TW + KS - 1;
   constexpr int stage = 2 * CO_T * 144 + PH * PW * 144;
-  constexpr int epi = TH * TW * (CO_T * (int)sizeof(TO) + 16);
-  constexpr int lds = stage > epi ? stage : epi;
+  constexpr int epiw = epi_bytes<TO>(CO_T, TH * TW, true), ldsw = stage > epiw ? stage : epiw;
+  const int epi = epi_bytes<TO>(CO_T, TH * TW, a.res != nullptr);
+  const int lds = stage > epi ? stage : epi;
   auto kern = conv_halo_kernel<T, TO, CO_T, WCO, KS, TH, TW>;
   static bool attr_set = false;
-  if (!attr_set && lds > 64 * 1024) {
-    GLS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  if (!attr_set && ldsw > 64 * 1024) {
+    GLS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, ldsw));
     attr_set = true;
   }
   ConvArgs b = a;

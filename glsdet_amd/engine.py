@@ -39,6 +39,11 @@ class TView:
         assert 0 <= c0 < c1 <= self.c and c0 % 8 == 0, (c0, c1, self.c)
         return TView(self.buf, self.off + c0, self.n, self.h, self.w, c1 - c0, self.sn, self.sh, self.sw, self.dtype)
 
+    def image(self, b: int) -> "TView":
+        """the n = 1 view of image b"""
+        assert 0 <= b < self.n
+        return TView(self.buf, self.off + b * self.sn, 1, self.h, self.w, self.c, self.sn, self.sh, self.sw, self.dtype)
+
     def window(self, h0: int, h1: int, w0: int, w1: int) -> "TView":
         assert 0 <= h0 < h1 <= self.h and 0 <= w0 < w1 <= self.w
         return TView(self.buf, self.off + h0 * self.sh + w0 * self.sw, self.n, h1 - h0, w1 - w0, self.c,
@@ -124,6 +129,16 @@ def _stream_ptr(stream) -> int:
 _SHARED_TUNED: dict = {}
 
 
+class _Ptr:
+    """device address with the .data_ptr() of a tensor (a weight operand that lives in an activation buffer)"""
+
+    def __init__(self, ptr: int):
+        self._p = ptr
+
+    def data_ptr(self) -> int:
+        return self._p
+
+
 class Engine:
     """Owns device buffers and packed weights; emits ops (eagerly or into a Plan)."""
 
@@ -147,6 +162,7 @@ class Engine:
             with open(self._tune_cache_path) as f:
                 self._tuned.update({tuple(json.loads(k)): v for k, v in json.load(f).get(dtype, {}).items()})
         self._dtype_name = dtype
+        self._vecs: dict = {}
         # verification (tools/variant_check.py): {"hint": h, "multi": h or None, "log": []} -- every conv also runs
         # on kernel variant h into a scratch tensor (same operands, before the real launch) and the two results are
         # compared element by element; eager emission only
@@ -235,10 +251,10 @@ class Engine:
     def conv_multi(self, xs: Sequence[TView], packs, stride: int, pad: int, act: str,
                    outs: Optional[Sequence[Optional[TView]]] = None, ress: Optional[Sequence[Optional[TView]]] = None,
                    out_dtype: Optional[int] = None, tile_hint: int = 0) -> List[TView]:
-        """Up to 4 independent convs of one shape class (same k, stride, Cin, Cout) as ONE launch
+        """Up to 8 independent convs of one shape class (same k, stride, Cin, Cout) as ONE launch
         (glsdet_conv2d_multi): each alone is too small to fill the chip."""
         n = len(xs)
-        assert 1 <= n <= 4 and len(packs) == n
+        assert 1 <= n <= 8 and len(packs) == n
         outs = list(outs) if outs is not None else [None] * n
         ress = list(ress) if ress is not None else [None] * n
         arr = (ConvDesc * n)()
@@ -263,6 +279,44 @@ class Engine:
         check(self.lib.glsdet_conv2d_multi(arr, n, _stream_ptr(self.stream)), "conv2d_multi")
         self._shadow_end(sh)
         return outs
+
+    def conv_many(self, xs: Sequence[TView], packs, stride: int, pad: int, act: str, outs: Sequence[TView],
+                  ress: Optional[Sequence[Optional[TView]]] = None) -> List[TView]:
+        """Any number of independent convs of one shape class, eight per launch."""
+        ress = list(ress) if ress is not None else [None] * len(xs)
+        for i in range(0, len(xs), 8):
+            self.conv_multi(xs[i:i + 8], packs[i:i + 8], stride, pad, act, outs=outs[i:i + 8], ress=ress[i:i + 8])
+        return list(outs)
+
+    def matrix(self, rows: int, cols: int, dtype: Optional[int] = None) -> TView:
+        """Dense rows x cols matrix that can serve BOTH as a 1x1-conv activation (rows = pixels, cols = channels)
+        and as a 1x1-conv weight operand (rows = output channels): row pitch = glsdet_conv_kpad(cols), rows padded
+        to the weight tile granule (32), zero filled.  -> view [1, 1, rows, ceil8(cols)]."""
+        dt = self.dt if dtype is None else dtype
+        c8 = ceil_to(cols, 8)
+        pitch = self.lib.glsdet_conv_kpad(1, 1, c8, dt)
+        rp = self.lib.glsdet_conv_cout_pad(ceil_to(rows, 8))
+        buf = self.raw(rp * pitch * _ESIZE[dt])
+        return TView(buf, 0, 1, 1, rows, c8, rows * pitch, rows * pitch, pitch, dt)
+
+    def as_weight(self, m: TView, alpha: float = 1.0, bias: Optional[torch.Tensor] = None):
+        """`packed` tuple for Engine.conv whose weight operand is the activation matrix m (Engine.matrix layout):
+        out[pixel][r] = alpha * sum_k x[pixel][k] * m[r][k] (+ bias[r])."""
+        rows = m.h * m.w
+        assert m.n == 1 and m.sw == self.lib.glsdet_conv_kpad(1, 1, m.c, m.dtype), "as_weight needs an Engine.matrix view"
+        cpad = self.lib.glsdet_conv_cout_pad(ceil_to(rows, 8))
+        key = ("vec", cpad, float(alpha))
+        if key not in self._vecs:
+            self._vecs[key] = (self.upload(torch.full((cpad,), float(alpha))), self.upload(torch.zeros(cpad)))
+        sc, zero = self._vecs[key]
+        if bias is not None:
+            bkey = ("bias", cpad, bias.data_ptr())
+            if bkey not in self._vecs:
+                b = torch.zeros(cpad)
+                b[: bias.numel()] = bias.float()
+                self._vecs[bkey] = (self.upload(b), bias)        # keeps `bias` alive: its address is the key
+            zero = self._vecs[bkey][0]
+        return (_Ptr(m.buf.data_ptr() + m.off * _ESIZE[m.dtype]), sc, zero, ceil_to(rows, 8), 1, 1)
 
     def conv_group(self, xs: Sequence[TView], packs, stride: int, pad: int, act: str,
                    outs: Optional[Sequence[Optional[TView]]] = None, ress: Optional[Sequence[Optional[TView]]] = None,

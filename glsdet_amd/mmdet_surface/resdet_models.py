@@ -16,7 +16,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from ..arch import _Table, fpn_table, gfl_head_table, mp_head_table, resnet_table, RESNET_STAGE_BLOCKS
+from ..arch import _Table, fpn_table, gfl_head_table, gl_fusion_table, mp_head_table, resnet_table, RESNET_STAGE_BLOCKS
 from ..drone.body import TableModule, _autotune
 from ..resdet import HipGflDetector
 from .registry import BACKBONES, DETECTORS, HEADS, NECKS, ConfigDict, build_backbone, build_head, build_neck
@@ -77,6 +77,29 @@ class FPN(TableModule):
         self.start_level, self.add_extra_convs = start_level, add_extra_convs
         t = _Table()
         fpn_table(t, "x", self.in_channels, out_channels, start_level, num_outs, add_extra_convs)
+        self._init_table(_Table((k[2:], v) for k, v in t.items()))
+
+
+@NECKS.register_module()
+class GLFusionFPN(FPN):
+    """FPN whose inputs first pass the GL-fusion plug-in: in_i <- in_i + Patch_Conv_NonLocal_new(in_i) on the backbone
+    outputs `gl_levels` (default C3, C4, C5), the residual of drone/models/new/yolox10.py:262-266 with the block of
+    drone/models/new/Non_local_family.py:208-252 (in = out = C_i, channel_scale = 1, patch_scale = 2).  Authored by this
+    build: BASELINE config 3 names "ResNet-50 + GL-fusion + decoupled head", a model the reference never wires up
+    (SURVEY F4, App. B).  gl_channel_cat: 'linear' (1x1 conv + bias) or 'non_linear' (BaseConv 3x3 + BN + SiLU), the two
+    options of the reference class.  State-dict names: gl_fusion.<i>.feat_patchconv_{lt,lb,rt,rb}_nonlocal.{g,theta,phi,
+    conv_out}.{weight,bias}, gl_fusion.<i>.channel_conv.*."""
+
+    def __init__(self, in_channels, out_channels, num_outs, gl_levels=(1, 2, 3), gl_channel_cat="linear", **kwargs):
+        super().__init__(in_channels, out_channels, num_outs, **kwargs)
+        if gl_channel_cat not in ("linear", "non_linear"):
+            raise ValueError("gl_channel_cat must be 'linear' or 'non_linear'")
+        self.gl_levels, self.gl_channel_cat = tuple(gl_levels), gl_channel_cat
+        assert all(0 <= i < len(self.in_channels) for i in self.gl_levels)
+        t = _Table()
+        fpn_table(t, "x", self.in_channels, out_channels, self.start_level, num_outs, self.add_extra_convs)
+        for i in self.gl_levels:
+            gl_fusion_table(t, "x.gl_fusion.%d" % i, self.in_channels[i], gl_channel_cat)
         self._init_table(_Table((k[2:], v) for k, v in t.items()))
 
 
@@ -198,6 +221,7 @@ class SingleStageDetector(nn.Module):
                        out_indices=self.backbone.out_indices)
             if kind == "mpdet":
                 cfg.update(proxies_list=tuple(h.proxies_list), gamma=float(h.gamma))
+            cfg.update(gl_levels=list(n.gl_levels) if isinstance(n, GLFusionFPN) else [])
             self._det = HipGflDetector(kind, self.state_dict(), dtype=self.hip_dtype, autotune=_autotune(), **cfg)
         return self._det
 

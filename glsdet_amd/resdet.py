@@ -86,6 +86,131 @@ class ResDetBuilder:
                 outs.append(x)
         return outs
 
+    # ------------------------------------------------------------------ GL-fusion plug-in (BASELINE config 3)
+    def _wmat(self, key: str, w: torch.Tensor) -> TView:
+        """A conv weight [rows, cols] as an Engine.matrix (so that it can be the ACTIVATION operand of a GEMM)."""
+        if key not in self._packed:
+            m = self.e.matrix(w.shape[0], w.shape[1])
+            pitch = m.sw
+            t = torch.zeros(w.shape[0], pitch, dtype=torch.float32)
+            t[:, : w.shape[1]] = w.float()
+            m.buf.view(torch.float16 if m.dtype == 0 else torch.float32)[: t.numel()].copy_(t.flatten())
+            self._packed[key] = m
+        return self._packed[key]
+
+    def nonlocal_gemm(self, ps: Sequence[str], xs: Sequence[TView], outs: Sequence[TView], assoc: str = "auto"):
+        """Non_local_Block (drone/models/new/Non_local_family.py:6-50) at ResNet widths (C = 512...2048), for the
+        quadrants `xs` (views with the batch in n) of ONE feature map, written to `outs`:
+            out = x + conv_out( (theta^T phi / N) g^T )            (dot product, divide by N, no softmax)
+        Every product is a 1x1 "conv" on the MFMA conv kernels whose weight operand is an activation matrix of the
+        same image (Engine.matrix / as_weight), one problem per (image, quadrant), eight problems per launch.
+        Two associations, chosen per map by their multiply count (N = pixels of a quadrant, C = channels):
+          're'  : Phi^T|G^T = [Wphi;Wg] Xq^T ; M = Phi^T G / N ; P = Wout M^T ; out = x + Theta P^T + b   (2NC^2 + C^3)
+          'dir' : S = Theta Phi^T / N ; G^T = Wg Xq^T ; Y = S G ; out = x + Y Wout^T + b                   (2N^2C + NC^2)
+        (the reference order is 'dir' with fp32 intermediates; here S / Y / M / P are stored in the engine dtype)."""
+        e = self.e
+        ci = self.sd[ps[0] + ".theta.weight"].shape[0]
+        C_ = xs[0].c
+        assert self.sd[ps[0] + ".conv_out.weight"].shape[0] == C_
+        nimg = xs[0].n
+        Ns = [x.h * x.w for x in xs]
+        Np = (max(Ns) + 7) // 8 * 8
+        if assoc == "auto":
+            n = max(Ns)
+            assoc = "re" if 2 * n * ci * ci + ci * ci * C_ <= 2 * n * n * ci + n * ci * C_ else "dir"
+        w2 = lambda p, nm: self.sd["%s.%s.weight" % (p, nm)].float().reshape(self.sd["%s.%s.weight" % (p, nm)].shape[0], -1)
+        bias = lambda p, nm: self.sd["%s.%s.bias" % (p, nm)]
+        pk = lambda p, nm: self._pack("%s.%s" % (p, nm), [self._plain_part("%s.%s" % (p, nm))], C_)
+
+        def bias_rows(key, b, cols, valid):       # [rows, cols] matrix holding b[r] in the first `valid` columns
+            k = ("biasrows", key, cols, valid)
+            if k not in self._packed:
+                m = e.matrix(b.numel(), cols)
+                t = torch.zeros(b.numel(), m.sw)
+                t[:, :valid] = b.float()[:, None]
+                m.buf.view(torch.float16 if m.dtype == 0 else torch.float32)[: t.numel()].copy_(t.flatten())
+                self._packed[k] = m
+            return self._packed[k]
+
+        jobs = [(b, q) for b in range(nimg) for q in range(len(xs))]
+        xq = {(b, q): xs[q].image(b) for b, q in jobs}
+        oq = {(b, q): outs[q].image(b) for b, q in jobs}
+        # theta for every (image, quadrant): a plain conv per quadrant over the whole batch
+        theta = [e.tensor(x.n, x.h, x.w, ci) for x in xs]
+        e.conv_many(list(xs), [pk(p, "theta") for p in ps], 1, 0, "none", theta)
+        th = {(b, q): theta[q].image(b) for b, q in jobs}
+        # dense copy of each quadrant: rows = pixels (the weight operand of the transposed projections)
+        Xq = {}
+        for (b, q) in jobs:
+            m = e.matrix(Np, C_)
+            Xq[b, q] = m
+            x = xs[q]
+            e.resample(xq[b, q], 1, out=TView(m.buf, 0, 1, x.h, x.w, C_, x.h * x.w * m.sw, x.w * m.sw, m.sw, m.dtype))
+        if assoc == "re":
+            # [Phi^T ; G^T] (2ci x Np) = [Wphi ; Wg] (as pixels) x Xq^T, bias per row through the residual operand
+            PG = {j: e.matrix(2 * ci, Np) for j in jobs}
+            srcs, packs, ress = [], [], []
+            for (b, q) in jobs:
+                p = ps[q]
+                srcs.append(self._wmat(p + ".phig", torch.cat([w2(p, "phi"), w2(p, "g")], 0)))
+                packs.append(e.as_weight(Xq[b, q]))
+                ress.append(bias_rows(p + ".phig", torch.cat([bias(p, "phi").float(), bias(p, "g").float()]), Np, Ns[q]))
+            e.conv_many(srcs, packs, 1, 0, "none", [PG[j] for j in jobs], ress)
+            rows = lambda m, r0, r1: TView(m.buf, m.off + r0 * m.sw, 1, 1, r1 - r0, m.c, (r1 - r0) * m.sw, (r1 - r0) * m.sw, m.sw, m.dtype)
+            # M/N (ci x ci): rows a = Phi^T[a][:], weight rows b = G^T[b][:]
+            M = {j: e.matrix(ci, ci) for j in jobs}
+            e.conv_many([rows(PG[j], 0, ci) for j in jobs],
+                        [e.as_weight(rows(PG[b, q], ci, 2 * ci), alpha=1.0 / Ns[q]) for (b, q) in jobs], 1, 0, "none",
+                        [M[j] for j in jobs])
+            # P (C x ci) = Wout (as pixels) x M^T
+            P = {j: e.matrix(C_, ci) for j in jobs}
+            e.conv_many([self._wmat(ps[q] + ".wout", w2(ps[q], "conv_out")) for (b, q) in jobs],
+                        [e.as_weight(M[j]) for j in jobs], 1, 0, "none", [P[j] for j in jobs])
+            # out = x + Theta P^T + bout
+            e.conv_many([th[j] for j in jobs], [e.as_weight(P[b, q], bias=bias(ps[q], "conv_out")) for (b, q) in jobs],
+                        1, 0, "none", [oq[j] for j in jobs], [xq[j] for j in jobs])
+            return list(outs)
+        # ---- direct association
+        phi = [e.matrix(Np, ci) for _ in jobs]
+        # Phi (Np x ci) per job as a weight matrix: conv of the dense quadrant copy (rows beyond N stay zero)
+        e.conv_many([TView(Xq[j].buf, 0, 1, 1, Ns[j[1]], C_, Ns[j[1]] * Xq[j].sw, Ns[j[1]] * Xq[j].sw, Xq[j].sw, Xq[j].dtype) for j in jobs],
+                    [pk(ps[q], "phi") for (b, q) in jobs], 1, 0, "none",
+                    [TView(m.buf, 0, 1, 1, Ns[j[1]], ci, Ns[j[1]] * m.sw, Ns[j[1]] * m.sw, m.sw, m.dtype) for m, j in zip(phi, jobs)])
+        # S (N x Np) = Theta Phi^T / N
+        S = [e.matrix(Ns[q], Np) for (b, q) in jobs]
+        e.conv_many([th[j] for j in jobs],
+                    [e.as_weight(m, alpha=1.0 / Ns[j[1]]) for m, j in zip(phi, jobs)], 1, 0, "none",
+                    [TView(m.buf, 0, 1, th[j].h, th[j].w, m.c, th[j].h * th[j].w * m.sw, th[j].w * m.sw, m.sw, m.dtype) for m, j in zip(S, jobs)])
+        # G^T (ci x Np) = Wg (as pixels) x Xq^T + bg per row
+        GT = [e.matrix(ci, Np) for _ in jobs]
+        e.conv_many([self._wmat(ps[q] + ".wg", w2(ps[q], "g")) for (b, q) in jobs], [e.as_weight(Xq[j]) for j in jobs], 1, 0, "none",
+                    GT, [bias_rows(ps[q] + ".g", bias(ps[q], "g"), Np, Ns[q]) for (b, q) in jobs])
+        # Y (N x ci) = S G
+        Y = [e.matrix(Ns[q], ci) for (b, q) in jobs]
+        e.conv_many(S, [e.as_weight(m) for m in GT], 1, 0, "none", Y)
+        # out = x + Y Wout^T + bout, written as an NHWC quadrant
+        yv = [TView(m.buf, 0, 1, th[j].h, th[j].w, m.c, th[j].h * th[j].w * m.sw, th[j].w * m.sw, m.sw, m.dtype) for m, j in zip(Y, jobs)]
+        e.conv_many(yv, [pk(ps[q], "conv_out") for (b, q) in jobs], 1, 0, "none", [oq[j] for j in jobs], [xq[j] for j in jobs])
+        return list(outs)
+
+    def gl_fusion(self, p: str, x: TView, assoc: str = "auto") -> TView:
+        """x + Patch_Conv_NonLocal_new(x)  (drone/models/new/yolox10.py:262-266 applied to a ResNet stage output;
+        Non_local_family.py:208-252): quadrant non-local blocks at the input resolution, re-stitch (free: the
+        blocks write their windows of one buffer), channel_conv, residual."""
+        e = self.e
+        hh, hw = x.h // 2, x.w // 2
+        st = e.tensor(x.n, x.h, x.w, x.c)
+        wins = lambda t: [t.window(0, hh, 0, hw), t.window(hh, t.h, 0, hw), t.window(0, hh, hw, t.w), t.window(hh, t.h, hw, t.w)]
+        names = ["%s.feat_patchconv_%s_nonlocal" % (p, q) for q in ("lt", "lb", "rt", "rb")]
+        self.nonlocal_gemm(names, wins(x), wins(st), assoc)
+        if p + ".channel_conv.weight" in self.sd:                       # channel_cat == 'linear': 1x1 conv + bias
+            pkc = self._pack(p + ".channel_conv", [self._plain_part(p + ".channel_conv")], st.c)
+            return e.conv(st, pkc, 1, 0, "none", res=x)
+        s, b = fold_bn(self.sd[p + ".channel_conv.bn.weight"], self.sd[p + ".channel_conv.bn.bias"],
+                       self.sd[p + ".channel_conv.bn.running_mean"], self.sd[p + ".channel_conv.bn.running_var"], 1e-3)
+        pkc = self._pack(p + ".channel_conv", [(self.sd[p + ".channel_conv.conv.weight"], s, b)], st.c)
+        return e.conv(st, pkc, 1, 1, "silu", res=x)                     # BaseConv 3x3 + BN(1e-3) + SiLU, then + x
+
     # ------------------------------------------------------------------ neck
     def fpn(self, p: str, inputs: Sequence[TView], start_level: int = 0, num_outs: int = 5,
             add_extra_convs="on_output", relu_before_extra_convs: bool = False) -> List[TView]:
@@ -205,7 +330,9 @@ class HipGflDetector:
 
     DEFAULTS = dict(start_level=1, num_outs=5, add_extra_convs="on_output", relu_before_extra_convs=False,
                     stacked_convs=4, strides=(8, 16, 32, 64, 128), reg_max=16, depth=50, out_indices=(0, 1, 2, 3),
-                    proxies_list=(2, 3, 2, 5, 4, 8, 8, 4, 3, 3), gamma=10.0)
+                    proxies_list=(2, 3, 2, 5, 4, 8, 8, 4, 3, 3), gamma=10.0,
+                    gl_levels=None,          # backbone outputs that get x + Patch_Conv_NonLocal_new(x) (None: those whose
+                    gl_assoc="auto")         # neck.gl_fusion.<i>.* keys exist in the state_dict); association of its products
 
     def __init__(self, kind: str, state_dict, dtype: str = "f16", device: str = "cuda:0", autotune: bool = False, **cfg):
         if kind not in ("gfl", "mpdet"):
@@ -224,7 +351,13 @@ class HipGflDetector:
 
     def _emit(self, eng: Engine, img: torch.Tensor):
         b, c = ResDetBuilder(eng, self.sd), self.cfg
-        feats = b.fpn("neck", b.resnet("backbone", img, c["depth"], c["out_indices"]), c["start_level"], c["num_outs"],
+        stages = b.resnet("backbone", img, c["depth"], c["out_indices"])
+        levels = c["gl_levels"]
+        if levels is None:
+            levels = [i for i in range(len(stages)) if "neck.gl_fusion.%d.feat_patchconv_lt_nonlocal.theta.weight" % i in self.sd]
+        for i in levels:                       # GLFusionFPN: the plug-in sits on the FPN inputs (C3..C5), before the laterals
+            stages[i] = b.gl_fusion("neck.gl_fusion.%d" % i, stages[i], c["gl_assoc"])
+        feats = b.fpn("neck", stages, c["start_level"], c["num_outs"],
                       c["add_extra_convs"], c["relu_before_extra_convs"])
         if self.kind == "gfl":
             return b.gfl_head("bbox_head", feats, c["stacked_convs"])

@@ -90,11 +90,13 @@ typedef struct glsdet_conv_desc {
 } glsdet_conv_desc;
 
 int     glsdet_conv2d(const glsdet_conv_desc* d, void* stream);
-/* Up to 4 independent convolutions of ONE shape class (same R, S, stride, pad, Cin, Cout and
+/* Up to 8 independent convolutions of ONE shape class (same R, S, stride, pad, Cin, Cout and
  * dtypes; extents, strides, weights, residuals may differ) as one launch of the generic kernel:
  * the four quadrant convs of Patch_Conv (drone/models/block/non_local/Identity_Conv.py:298-301),
  * the cls / reg tower convs of one head level (base/yolox.py:62-75).  Each alone is too small
- * to fill the chip.  tile_hint of d[0] applies (0 = auto).  Results are those of n glsdet_conv2d. */
+ * to fill the chip.  tile_hint of d[0] applies (0 = auto).  Results are those of n glsdet_conv2d.
+ * `w` may point at an ACTIVATION matrix (rows of x.c elements at a pitch of glsdet_conv_kpad elements, zero padded):
+ * the batched products of the non-local block at ResNet widths are such 1x1 "convs" with per-image weights. */
 int     glsdet_conv2d_multi(const glsdet_conv_desc* d, int32_t n, void* stream);
 /* as glsdet_conv2d_tune, for the group: fastest tile_hint of the one-launch form and its time */
 int     glsdet_conv2d_multi_tune(const glsdet_conv_desc* d, int32_t n, void* stream, int32_t* best_hint, float* best_us);

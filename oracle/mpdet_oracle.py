@@ -33,7 +33,7 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
-from .glsdet_oracle import batched_nms
+from .glsdet_oracle import batched_nms, patch_conv_nonlocal_new
 
 Tensor = torch.Tensor
 SD = Dict[str, Tensor]
@@ -202,15 +202,33 @@ def gfl_get_bboxes(cls_scores: Sequence[Tensor], bbox_preds: Sequence[Tensor], s
     return results
 
 
+# ------------------------------------------------------------------------------- GL-fusion plug-in (BASELINE config 3)
+def gl_fusion_inputs(sd: SD, p: str, stages: Sequence[Tensor]) -> List[Tensor]:
+    """`GLFusionFPN` (authored by this build; the reference never wires GL-fusion onto a ResNet):
+    every backbone output i that has a plug-in `<p>.gl_fusion.<i>` becomes  feat + Patch_Conv_NonLocal_new(feat)
+    -- the residual of drone/models/new/yolox10.py:262-266 -- before the FPN laterals.  The block itself is the
+    pinned restatement of the reference class (glsdet_oracle.patch_conv_nonlocal_new, golden attention_golden.npz)."""
+    out = list(stages)
+    for i, f in enumerate(stages):
+        q = "%s.gl_fusion.%d" % (p, i)
+        if q + ".feat_patchconv_lt_nonlocal.theta.weight" in sd:
+            out[i] = f + patch_conv_nonlocal_new(sd, q, f)
+    return out
+
+
 # ------------------------------------------------------------------------------- detectors
 def gfl_forward(sd: SD, x: Tensor, start_level: int = 1, num_outs: int = 5, add_extra_convs="on_output"):
     """SingleStageDetector.extract_feat + bbox_head (single_stage.py:41-60): GFL r50-FPN."""
-    feats = fpn(sd, "neck", resnet(sd, "backbone", x), start_level, num_outs, add_extra_convs)
+    feats = fpn(sd, "neck", gl_fusion_inputs(sd, "neck", resnet(sd, "backbone", x)), start_level, num_outs, add_extra_convs)
     return gfl_head(sd, "bbox_head", feats)
 
 
 def mpdet_forward(sd: SD, x: Tensor, proxies_list: Sequence[int], gamma: float = 10.0, start_level: int = 1,
-                  num_outs: int = 5, add_extra_convs="on_output"):
-    """MPDet (mpdet.py:9-18) = SingleStageDetector with MPHead."""
-    feats = fpn(sd, "neck", resnet(sd, "backbone", x), start_level, num_outs, add_extra_convs)
+                  num_outs: int = 5, add_extra_convs="on_output", gl_fusion: Optional[bool] = None):
+    """MPDet (mpdet.py:9-18) = SingleStageDetector with MPHead; with a GLFusionFPN neck when the state_dict holds
+    neck.gl_fusion.* (gl_fusion=True asserts that it does)."""
+    stages = gl_fusion_inputs(sd, "neck", resnet(sd, "backbone", x))
+    if gl_fusion:
+        assert any(k.startswith("neck.gl_fusion.") for k in sd), "state_dict has no GL-fusion plug-in"
+    feats = fpn(sd, "neck", stages, start_level, num_outs, add_extra_convs)
     return mp_head(sd, "bbox_head", feats, proxies_list, gamma)

@@ -521,3 +521,71 @@ def test_two_gfl_graph_instances_in_flight_replay_bit_identically():
             r = ref.setdefault(i, cur)
             assert torch.equal(cur[0], r[0]) and torch.equal(cur[1], r[1]), "step %d instance %d differs" % (step, i)
     assert int(ref[0][0][0]) > 0
+
+
+# ------------------------------------------------------------------------------- BASELINE config 3: ResNet-50 + GL-fusion
+def _gl_plugin_sd(p, c, seed, channel_cat="linear"):
+    from glsdet_amd.arch import _Table, gl_fusion_table
+    from glsdet_amd.synth import synth_state_dict
+    t = _Table()
+    gl_fusion_table(t, p, c, channel_cat)
+    return synth_state_dict(t, seed)
+
+
+def test_gl_fusion_config_builds_and_oracle_composes():
+    """configs/UFPMP-Det/mp_det_res50_gl.py: MPDet with a GLFusionFPN neck; the state-dict names are those of the
+    reference's Patch_Conv_NonLocal_new under neck.gl_fusion.<i>; the oracle composition is feat + block(feat)."""
+    from glsdet_amd.arch import resdet_state_dict_shapes
+    from glsdet_amd.mmdet_surface import init_detector
+    m = init_detector(os.path.join(ROOT, "configs/UFPMP-Det/mp_det_res50_gl.py"))
+    assert type(m).__name__ == "MPDet" and type(m.neck).__name__ == "GLFusionFPN" and m.neck.gl_levels == (1, 2, 3)
+    got = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    assert got == {k: tuple(v) for k, v in resdet_state_dict_shapes("mpdet", gl_fusion=True).items()}
+    assert got["neck.gl_fusion.3.feat_patchconv_rb_nonlocal.conv_out.weight"] == (2048, 2048, 1, 1)
+    assert got["neck.gl_fusion.1.channel_conv.weight"] == (512, 512, 1, 1) and "neck.gl_fusion.0.channel_conv.weight" not in got
+    sd = _gl_plugin_sd("neck.gl_fusion.1", 32, 0)
+    feats = [O.synth_input((1, 8, 6, 6), 0), O.synth_input((2, 32, 7, 10), 1)]
+    out = M.gl_fusion_inputs(sd, "neck", feats)
+    assert out[0] is feats[0]
+    assert torch.equal(out[1], feats[1] + O.patch_conv_nonlocal_new(sd, "neck.gl_fusion.1", feats[1]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["f32", "f16"])
+@pytest.mark.parametrize("assoc", ["re", "dir"])
+@pytest.mark.parametrize("c,hw,cat", [(64, (12, 16), "linear"), (128, (13, 21), "linear"), (512, (9, 10), "non_linear")])
+def test_gl_fusion_plugin_vs_oracle(engines, mode, assoc, c, hw, cat):
+    """x + Patch_Conv_NonLocal_new(x) at ResNet-like widths through the GEMM lowering of the non-local block, both
+    associations of its products, odd quadrant sizes, both channel_cat options."""
+    from glsdet_amd.resdet import ResDetBuilder
+    from tests.test_hip_ops import _to_view
+    eng = engines[mode]
+    sd = _gl_plugin_sd("g", c, 3, cat)
+    if cat == "non_linear":
+        sd["g.channel_conv.bn.running_var"] = sd["g.channel_conv.bn.running_var"] + 1.0
+    x = O.synth_input((2, c, hw[0], hw[1]), 11)
+    want = _r(x, mode) + O.patch_conv_nonlocal_new(sd, "g", _r(x, mode))
+    out = ResDetBuilder(eng, sd).gl_fusion("g", _to_view(eng, x), assoc)
+    torch.cuda.synchronize()
+    err = _err(out.to_nchw().cpu(), want)
+    print("gl_fusion c=%d %s %s %s: %.2e" % (c, hw, assoc, mode, err))
+    assert err <= (1e-4 if mode == "f32" else 3e-2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["f32", "f16"])
+def test_gl_fusion_detector_vs_oracle(mode):
+    """BASELINE config 3 as named: MPDet = ResNet-50 + GL-fusion plug-in on C3..C5 + FPN + MPHead, vs the restatement."""
+    from glsdet_amd.resdet import HipGflDetector
+    x = O.synth_input((1, 3, 128, 160), 7)
+    sd = calibrated_resdet_sd("mpdet", 1, x, gl_fusion=True)
+    assert "neck.gl_fusion.2.channel_conv.weight" in sd
+    pl = HipGflDetector.DEFAULTS["proxies_list"]
+    wc, wr = M.mpdet_forward(sd, x, pl, gl_fusion=True)
+    bc, br = M.mpdet_forward({k: v for k, v in sd.items() if "gl_fusion" not in k}, x, pl)
+    assert max(_err(a, b) for a, b in zip(wc, bc)) > 1e-2, "the plug-in must change the result"
+    det = HipGflDetector("mpdet", sd, dtype=mode)
+    gc, gr = det.forward_raw(x.cuda())
+    err = max(_err(g.cpu(), w) for g, w in zip(gc + gr, wc + wr))
+    print("mpdet + GL-fusion %s: hip-vs-oracle %.2e" % (mode, err))
+    assert err <= (2e-4 if mode == "f32" else 0.1)
