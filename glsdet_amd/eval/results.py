@@ -102,12 +102,16 @@ class ResultMerger:
             return rows
         if n > self.cap:
             raise RuntimeError("more rows (%d) than the merger's capacity %d" % (n, self.cap))
-        host = np.zeros((self.cap, 5 + nc), np.float32)
+        # obj = 1 and the class scores are -1 everywhere except the row's own class: the class max is then the row's
+        # score at the row's class also for a score of exactly 0 (a '0.0000' cut of the reference's 6-character score
+        # string, which merge_results.py keeps), and the all -1 padding rows fall under the threshold of -0.5
+        host = np.full((self.cap, 5 + nc), -1.0, np.float32)
+        host[:, :4] = 0.0
+        host[:, 4] = 1.0
         host[:n, :4] = rows[:, :4]
-        host[:n, 4] = 1.0
         host[np.arange(n), 5 + rows[:, 5].astype(np.int64)] = rows[:, 4]
         self._pred[0].copy_(torch.from_numpy(host))
-        dets, count, status = self.eng.nms(self._pred, nc, 1, 1e-30, self.thr, self._nb)
+        dets, count, status = self.eng.nms(self._pred, nc, 1, -0.5, self.thr, self._nb)
         torch.cuda.current_stream(self.eng.device).synchronize()
         if int(status.item()) & 1:
             raise RuntimeError("NMS candidate capacity exceeded")

@@ -50,7 +50,9 @@ class UfpSecondStage:
         ch, cw = max(1, math.ceil(height)), max(1, math.ceil(width))
         canvas = torch.empty(ch, cw, 3, dtype=torch.float32, device=self.device)
         n = len(chips)
-        cdev = torch.tensor(np.asarray(chips, np.float32).reshape(-1, 7), device=self.device) if n else None
+        # the reference floors every chip field with math.floor on Python floats (ufpmp_det_eval.py:283): floor in
+        # float64 on the host, so a value just below an integer cannot round up on its way to float32
+        cdev = torch.tensor(np.floor(np.asarray(chips, np.float64)).astype(np.float32).reshape(-1, 7), device=self.device) if n else None
         _lib.check(self.lib.glsdet_ufp_mosaic(img_bgr.data_ptr(), img_bgr.shape[0], img_bgr.shape[1],
                                               cdev.data_ptr() if n else None, n, canvas.data_ptr(), ch, cw, self._stream()),
                    "ufp_mosaic")
@@ -81,7 +83,9 @@ class UfpSecondStage:
         -> per class ndarray (k,5) x1,y1,x2,y2,score in source-image coordinates, NMS order."""
         max_det = int(dets.shape[0])
         n = len(chips)
-        cdev = torch.tensor(np.asarray(chips, np.float32).reshape(-1, 7), device=self.device) if n else None
+        # the reference floors every chip field with math.floor on Python floats (ufpmp_det_eval.py:283): floor in
+        # float64 on the host, so a value just below an integer cannot round up on its way to float32
+        cdev = torch.tensor(np.floor(np.asarray(chips, np.float64)).astype(np.float32).reshape(-1, 7), device=self.device) if n else None
         ws = torch.zeros(int(self.lib.glsdet_ufp_merge_workspace_bytes(max_cand)) + 256, dtype=torch.uint8, device=self.device)
         off = (-ws.data_ptr()) % 256
         out = torch.zeros(max_cand, 7, dtype=torch.float32, device=self.device)

@@ -14,9 +14,13 @@ below follow it:
     accumulate     :315-420   precision at 101 recall thresholds per (T, K, A, M), recall, scores
     summarize      :422-470   the 12 numbers
 
-PARITY UNPINNED: pycocotools is not installed and the vendored module imports `pycocotools._mask`, so neither
-can run here, and the reference holds no evaluation fixture.  The oracle is pinned only by hand-derived
-known answers (tests/test_cocoeval.py).  `COCO_AREA` are pycocotools' own ranges (what the two-stage eval
+PINNED (round 2) for everything but the IoU arithmetic: tests/golden/eval_golden.npz holds evalImgs, precision /
+recall / scores and the 12 stats produced by the reference's OWN vendored COCOeval (`_prepare`, `computeIoU`'s
+score ordering and maxDets cut, `evaluateImg`, `accumulate`, `summarize`) on seeded data sets
+(tests/golden/make_golden.py::eval_cases; tests/test_pinned_goldens.py holds this file to them exactly).
+STILL UNPINNED: `bb_iou`.  The reference reaches it through pycocotools' compiled `_mask.iou`, which is not
+installed; the fixture generator routes the vendored module's `maskUtils.iou` to this restatement of
+maskApi.c's bbIou, so the fixtures say nothing about it (hand-derived values: tests/test_cocoeval.py).  `COCO_AREA` are pycocotools' own ranges (what the two-stage eval
 runs with); `DRONE_AREA` are the edited ones of the vendored copy (:507-508)."""
 from __future__ import annotations
 

@@ -150,7 +150,169 @@ def ufp_cases():
     print("ufp:", len(out) // 2, "cases,", os.path.getsize(os.path.join(HERE, "ufp_golden.npz")), "bytes")
 
 
+def _stub(name, **attrs):
+    m = types.ModuleType(name)
+    for k, v in attrs.items():
+        setattr(m, k, v)
+    sys.modules[name] = m
+    return m
+
+
+def merge_cases():
+    """Row f.2: the reference's own pure-numpy `compute_iof` and `py_cpu_nms` (ufp/ufpmp_det_eval.py:36-50, 149-178).
+    The script imports mmdet / mmcv / cv2 / pycocotools at its top; none of them is installed and none is touched by
+    the two functions, so empty stand-in modules satisfy the imports (as for torchvision above) and the functions
+    themselves run as shipped.  Inputs: seeded boxes; outputs: IoF values and keep lists."""
+    none = lambda *a, **k: None
+    _stub("mmdet")
+    _stub("mmdet.apis", init_detector=none, show_result_pyplot=none, inference_detector=none)
+    _stub("cv2")
+    _stub("mmcv")
+    _stub("mmcv.parallel", collate=none, scatter=none)
+    _stub("mmdet.datasets")
+    _stub("mmdet.datasets.pipelines", Compose=none)
+    _stub("mmdet.core", UnifiedForegroundPacking=none)
+    _stub("pycocotools")
+    _stub("pycocotools.coco", COCO=none)
+    _stub("pycocotools.cocoeval", COCOeval=none)
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ref_ufpmp_det_eval", "/root/reference/yolox-ufp/ufpmp_det_eval.py")
+    ref = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ref)
+    for k in ("mmdet", "mmdet.apis", "cv2", "mmcv", "mmcv.parallel", "mmdet.datasets", "mmdet.datasets.pipelines", "mmdet.core",
+              "pycocotools", "pycocotools.coco", "pycocotools.cocoeval"):
+        sys.modules.pop(k, None)
+    out = {}
+    rng = np.random.default_rng(0x10F)
+    # compute_iof: box pairs incl. disjoint, touching, contained, degenerate-but-positive
+    a = rng.uniform(0, 200, (400, 2))
+    b = rng.uniform(0, 200, (400, 2))
+    A = np.concatenate([a, a + rng.uniform(1, 120, (400, 2))], 1)
+    B = np.concatenate([b, b + rng.uniform(1, 120, (400, 2))], 1)
+    B[:40] = A[:40]                                            # identical
+    B[40:80, :2] = A[40:80, 2:]                                # touching at a corner -> 0
+    B[80:120] = np.concatenate([A[80:120, :2] + 1, A[80:120, :2] + 2], 1)   # small box inside (or outside) the other
+    A32 = A.astype(np.float32)
+    out["iof/a"], out["iof/b"] = A, B
+    out["iof/value"] = np.array([ref.compute_iof(list(x), list(y)) for x, y in zip(A, B)], np.float64)
+    out["iof/value_f32_first"] = np.array([ref.compute_iof(list(x), list(y)) for x, y in zip(A32, B)], np.float64)
+    # py_cpu_nms: clustered boxes, several thresholds, with and without score ties
+    for case in range(12):
+        r = np.random.default_rng([case, 0x2C5])
+        n = int(r.integers(1, 90)) if case else 1
+        centres = r.uniform(20, 400, (max(1, n // 6), 2))
+        c = centres[r.integers(0, len(centres), n)] + r.normal(0, 6, (n, 2))
+        wh = r.uniform(8, 90, (n, 2))
+        sc = r.uniform(0.05, 1.0, n)
+        if case % 3 == 2:
+            sc = np.round(sc, 1)                               # ties: the reference order is numpy's argsort()[::-1]
+        dets = np.concatenate([c - wh / 2, c + wh / 2, sc[:, None]], 1)
+        if case % 4 == 1:
+            dets = dets.astype(np.float32)
+        thr = [0.6, 0.5, 0.3, 0.65][case % 4]
+        out["nms/%d/dets" % case] = dets
+        out["nms/%d/thr" % case] = np.float64(thr)
+        out["nms/%d/keep" % case] = np.asarray(ref.py_cpu_nms(dets, thr), np.int64)
+    np.savez_compressed(os.path.join(HERE, "merge_golden.npz"), **out)
+    print("merge:", len(out), "arrays,", os.path.getsize(os.path.join(HERE, "merge_golden.npz")), "bytes")
+
+
+class _CocoBox:
+    """Input container for the reference's COCOeval: the four accessors it calls, with pycocotools.COCO's
+    documented ordering (getAnnIds: by image in the order given, annotation order inside an image, then the
+    category filter).  Data plumbing only."""
+
+    def __init__(self, dataset):
+        self.dataset = dataset
+        self.anns = {a["id"]: a for a in dataset["annotations"]}
+        self.by_img = {}
+        for a in dataset["annotations"]:
+            self.by_img.setdefault(a["image_id"], []).append(a)
+
+    def getImgIds(self):
+        return [im["id"] for im in self.dataset["images"]]
+
+    def getCatIds(self):
+        return [c["id"] for c in self.dataset["categories"]]
+
+    def getAnnIds(self, imgIds=[], catIds=[]):
+        anns = [a for i in imgIds for a in self.by_img.get(i, [])] if len(imgIds) else list(self.dataset["annotations"])
+        if len(catIds):
+            anns = [a for a in anns if a["category_id"] in catIds]
+        return [a["id"] for a in anns]
+
+    def loadAnns(self, ids):
+        return [self.anns[i] for i in ids]
+
+
+def eval_cases():
+    """Row f.4: the reference's vendored COCOeval (drone/models/core/cocoeval.py) run on seeded data sets:
+    `_prepare`, `computeIoU` (sorting, maxDets cut), `evaluateImg`, `accumulate`, `summarize` are the reference's
+    own code.  The ONE piece that is not: `maskUtils.iou`, compiled code of pycocotools (`_mask`, absent) -- the
+    stand-in module routes it to the restatement `cocoeval_oracle.bb_iou` (maskApi.c bbIou), which therefore stays
+    unpinned.  `np.float` (removed from numpy 1.24; the file predates that) is restored as the alias of `float` it
+    always was."""
+    import copy
+    from oracle import cocoeval_oracle as CO
+    from tests.test_cocoeval import random_case
+
+    def iou(d, g, iscrowd):
+        if len(d) == 0 or len(g) == 0:
+            return []
+        return CO.bb_iou(d, g, iscrowd)
+    _stub("pycocotools")
+    _stub("pycocotools._mask", iou=iou, merge=None, frPyObjects=None)      # mask.py:76-78 binds the three names at import
+    if not hasattr(np, "float"):
+        np.float = float
+    from models.core.cocoeval import COCOeval
+    out = {}
+    cases = [(0, {}, (1, 10, 25), "coco", 1), (1, dict(zero_id=True), (1, 10, 25), "coco", 1), (2, dict(crowd=0.5), (1, 10, 25), "coco", 0),
+             (3, dict(n_img=1, n_cat=1, max_gt=70, max_dt=150), (10, 100, 120), "coco", 1),
+             (5, dict(big=True), (1, 10, 25), "drone", 1), (6, dict(n_img=12, n_cat=10), (10, 100, 500), "coco", 1),
+             (7, dict(crowd=0.0, ties=False), (1, 10, 25), "coco", 0)]
+    meta = []
+    for ci, (seed, kw, max_dets, area, use_cats) in enumerate(cases):
+        ds, res = random_case(100 + seed, **kw)
+        gt = _CocoBox(copy.deepcopy(ds))
+        dt = _CocoBox(CO.load_res(ds, res))
+        E = COCOeval(gt, dt, "bbox")
+        E.params.imgIds = sorted(gt.getImgIds())
+        E.params.catIds = sorted(gt.getCatIds())
+        E.params.maxDets = list(max_dets)
+        E.params.areaRng = [list(r) for r in (CO.DRONE_AREA if area == "drone" else CO.COCO_AREA)]
+        E.params.useCats = use_cats
+        E.evaluate()
+        E.accumulate()
+        E.summarize()
+        pre = "eval/%d/" % ci
+        out[pre + "stats"] = np.asarray(E.stats, np.float64)
+        for k in ("precision", "recall", "scores"):
+            out[pre + k] = np.asarray(E.eval[k], np.float64)
+        out[pre + "none"] = np.asarray([e is None for e in E.evalImgs], np.uint8)
+        for i, e in enumerate(E.evalImgs):
+            if e is None:
+                continue
+            out[pre + "img%d/dtm" % i] = np.asarray(e["dtMatches"], np.float64)
+            out[pre + "img%d/gtm" % i] = np.asarray(e["gtMatches"], np.float64)
+            out[pre + "img%d/dtig" % i] = np.asarray(e["dtIgnore"], np.uint8)
+            out[pre + "img%d/gtig" % i] = np.asarray(e["gtIgnore"], np.uint8)
+            out[pre + "img%d/ids" % i] = np.asarray(list(e["dtIds"]) + [-1] + list(e["gtIds"]), np.int64)
+        meta.append(dict(seed=100 + seed, kw=kw, max_dets=list(max_dets), area=area, use_cats=use_cats,
+                         n_eval=len(E.evalImgs)))
+    out["eval/meta"] = np.frombuffer(json.dumps(meta).encode(), np.uint8)
+    sys.modules.pop("pycocotools", None)
+    sys.modules.pop("pycocotools._mask", None)
+    np.savez_compressed(os.path.join(HERE, "eval_golden.npz"), **out)
+    print("eval:", len(cases), "cases,", os.path.getsize(os.path.join(HERE, "eval_golden.npz")), "bytes")
+
+
 def main():
+    if "--merge-eval-only" in sys.argv:
+        merge_cases()
+        eval_cases()
+        return
+    merge_cases()
+    eval_cases()
     ufp_cases()
     preprocess_cases()
     from models.base import yolox as ref_base

@@ -286,6 +286,10 @@ def test_result_merger_matches_batched_nms(tmp_path):
         kept = m.merge_rows(rows)
         want = O.batched_nms(rows[:, :4], rows[:, 4], rows[:, 5].astype(np.int64), 0.65)
         assert np.array_equal(kept, rows[want])
+    # a score of exactly 0 (the '0.0000' cut of the reference's 6-character score string) survives like any other row
+    rows = np.array([[10, 10, 50, 50, 0.0, 3], [200, 200, 260, 250, 0.0, 0], [11, 11, 51, 51, 0.4, 3]], np.float32)
+    kept = m.merge_rows(rows)
+    assert np.array_equal(kept, rows[[2, 1]])
     # file level: two result directories -> merged directory
     d1, d2, out = tmp_path / "a", tmp_path / "b", tmp_path / "o"
     d1.mkdir(); d2.mkdir()

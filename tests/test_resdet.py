@@ -584,8 +584,10 @@ def test_gl_fusion_detector_vs_oracle(mode):
     wc, wr = M.mpdet_forward(sd, x, pl, gl_fusion=True)
     bc, br = M.mpdet_forward({k: v for k, v in sd.items() if "gl_fusion" not in k}, x, pl)
     assert max(_err(a, b) for a, b in zip(wc, bc)) > 1e-2, "the plug-in must change the result"
+    tc, tr = M.mpdet_forward({k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}, x.double(), pl)
+    noise = max(_err(a, b.float()) for a, b in zip(wc + wr, tc + tr))
     det = HipGflDetector("mpdet", sd, dtype=mode)
     gc, gr = det.forward_raw(x.cuda())
     err = max(_err(g.cpu(), w) for g, w in zip(gc + gr, wc + wr))
-    print("mpdet + GL-fusion %s: hip-vs-oracle %.2e" % (mode, err))
-    assert err <= (2e-4 if mode == "f32" else 0.1)
+    print("mpdet + GL-fusion %s: hip-vs-oracle %.2e, oracle fp32-vs-fp64 %.2e" % (mode, err, noise))
+    assert err <= (max(2e-4, 3 * noise) if mode == "f32" else 0.1)
