@@ -10,7 +10,7 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "lib", "libglsdet_hip.so")
-ABI_VERSION = 5
+ABI_VERSION = 6
 CAPTURE_LOCK = threading.RLock()        # hipGraph captures are serialised across host threads
 
 F16, F32 = 0, 1
@@ -39,7 +39,15 @@ class ConvDesc(C.Structure):
                 ("act", C.c_int32), ("tile_hint", C.c_int32)]
 
 
+class ConvChain(C.Structure):
+    _fields_ = [("y2", View), ("w2", C.c_void_p), ("scale2", C.c_void_p), ("bias2", C.c_void_p),
+                ("act2", C.c_int32), ("c0", C.c_int32), ("cin2", C.c_int32), ("_pad", C.c_int32)]
+
+
 _SIGS = {
+    "glsdet_conv2d_chain": (C.c_int, [C.POINTER(ConvDesc), C.POINTER(ConvChain), C.c_void_p]),
+    "glsdet_conv2d_chain_tune": (C.c_int, [C.POINTER(ConvDesc), C.POINTER(ConvChain), C.c_void_p, C.POINTER(C.c_int32),
+                                           C.POINTER(C.c_float)]),
     "glsdet_conv2d": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
     "glsdet_conv2d_multi": (C.c_int, [C.POINTER(ConvDesc), C.c_int32, C.c_void_p]),
     "glsdet_conv2d_multi_tune": (C.c_int, [C.POINTER(ConvDesc), C.c_int32, C.c_void_p, C.POINTER(C.c_int32),

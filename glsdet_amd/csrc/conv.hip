@@ -277,6 +277,51 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
   __syncthreads();
   constexpr int VO = 16 / (int)sizeof(TO);
   constexpr int OCPR = CO_T / VO;                // 16-B chunks per pixel row of the tile
+  // chained 1x1 (glsdet_conv2d_chain): only the workgroup whose cout tile holds the chained conv's input channels
+  const bool chain = sizeof(T) == sizeof(TO) && a.w2 != nullptr && co0 <= a.c2_0 && a.c2_0 + a.cin2 <= co0 + CO_T;
+  auto y2pix = [&](int px_l, bool& ok) -> long {
+    const int p = px0 + px_l;
+    ok = p < a.M;
+    return ok ? gls_pix_off(p, HoWo, a.Wo, a.y2_sn, a.y2_sh, a.y2_sw, a.y2_lin, a) : 0;
+  };
+  if constexpr (sizeof(T) == sizeof(TO)) if (chain && a.res) {
+    // the FINAL tile (after the residual) must stand in LDS for the chained product: pass 1 computes every chunk in
+    // registers (and stores it to y), pass 2 writes the chunks back in the TO row layout
+    constexpr int NITC = (PX_T * OCPR + 255) / 256;
+    constexpr int ORSW = CO_T * 4 + 16;
+    u32x4 fin[NITC];
+    bool okc[NITC];
+#pragma unroll
+    for (int b = 0; b < NITC; ++b) {
+      const int q = tid + b * 256;
+      const int px_l = q / OCPR, cc = q - px_l * OCPR;
+      const int p = px0 + px_l, co = co0 + cc * VO;
+      okc[b] = q < PX_T * OCPR && p < a.M && co < a.Cout;
+      fin[b] = u32x4{0u, 0u, 0u, 0u};
+      if (okc[b]) {
+        const long ro = gls_pix_off(p, HoWo, a.Wo, a.r_sn, a.r_sh, a.r_sw, a.r_lin, a) + co;
+        const u32x4 rv = *reinterpret_cast<const u32x4*>(a.res + ro * (long)sizeof(TO));
+        if (wide) {
+          const f32x4 lo = *reinterpret_cast<const f32x4*>(smem + px_l * ORSW + cc * 32);
+          const f32x4 hi = *reinterpret_cast<const f32x4*>(smem + px_l * ORSW + cc * 32 + 16);
+          fin[b] = add_chunk_wide(lo, hi, rv, a.act_post);
+        } else {
+          fin[b] = add_chunk(*reinterpret_cast<const u32x4*>(smem + px_l * ORS + cc * 16), rv, (TO*)nullptr, a.act_post);
+        }
+        const long yo = gls_pix_off(p, HoWo, a.Wo, a.y_sn, a.y_sh, a.y_sw, a.y_lin, a) + co;
+        *reinterpret_cast<u32x4*>(a.y + yo * (long)sizeof(TO)) = fin[b];
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int b = 0; b < NITC; ++b) {
+      const int q = tid + b * 256;
+      const int px_l = q / OCPR, cc = q - px_l * OCPR;
+      if (q < PX_T * OCPR) *reinterpret_cast<u32x4*>(smem + px_l * ORS + cc * 16) = fin[b];
+    }
+    chain_1x1<T, CO_T, PX_T>(a, smem, smem + PX_T * ORS, co0, tid, y2pix);
+    return;
+  }
   if (wide) {                                    // residual loads batched four deep, fp32 add, one rounding
     constexpr int ORSW = CO_T * 4 + 16, NITW = (PX_T * OCPR + 255) / 256, EBW = NITW < 4 ? NITW : 4;
     for (int it0 = 0; it0 < NITW; it0 += EBW) {
@@ -328,6 +373,9 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
         *reinterpret_cast<u32x4*>(a.y + yo * (long)sizeof(TO)) = v;
       }
     }
+    if constexpr (sizeof(T) == sizeof(TO)) {
+      if (chain) chain_1x1<T, CO_T, PX_T>(a, smem, smem + PX_T * ORS, co0, tid, y2pix);
+    }
     return;
   }
   constexpr int EB = NIT <= 4 ? NIT : 1;
@@ -361,6 +409,9 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
       }
     }
   }
+  if constexpr (sizeof(T) == sizeof(TO)) {
+    if (chain) chain_1x1<T, CO_T, PX_T>(a, smem, smem + PX_T * ORS, co0, tid, y2pix);      // (chain && res returned above)
+  }
 }
 
 template <typename T, typename TO, int CO_T, int PX_T, int KB, int WCO, bool UT>
@@ -391,13 +442,14 @@ __global__ __launch_bounds__(256) void conv_igemm_multi_kernel(const ConvArgsN m
 // ---- host side --------------------------------------------------------------------------
 template <typename T, typename TO, int CO_T, int PX_T, int KB, int WCO, bool UT>
 static int launch_conv(const ConvArgs& a, hipStream_t st) {
-  const int lds = conv_lds_bytes<CO_T, PX_T, KB, TO>(a.res != nullptr);
-  static bool attr_set = false;
+  int lds = conv_lds_bytes<CO_T, PX_T, KB, TO>(a.res != nullptr);
+  if (a.w2 && chain_lds_bytes<T>(CO_T, PX_T, a) > lds) lds = chain_lds_bytes<T>(CO_T, PX_T, a);
+  static int attr_lds = 64 * 1024;
   auto kern = conv_igemm_kernel<T, TO, CO_T, PX_T, KB, WCO, UT>;
-  if (!attr_set && conv_lds_bytes<CO_T, PX_T, KB, TO>(true) > 64 * 1024) {
-    GLS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, conv_lds_bytes<CO_T, PX_T, KB, TO>(true)));
-    attr_set = true;
+  const int want_attr = lds > conv_lds_bytes<CO_T, PX_T, KB, TO>(true) ? lds : conv_lds_bytes<CO_T, PX_T, KB, TO>(true);
+  if (want_attr > attr_lds) {
+    GLS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, want_attr));
+    attr_lds = want_attr;
   }
   ConvArgs b = a;
   b.n_co_tiles = (a.cout_pad + CO_T - 1) / CO_T;
@@ -490,6 +542,7 @@ static void pick_tile(const ConvArgs& a, int elem, int hint, int* co_t, int* px_
     *co_t = 0;
     long best_blocks = -1;
     for (const Cand& c : cands) {
+      if (a.w2 && (c.co < 64 || a.c2_0 / c.co != (a.c2_0 + a.cin2 - 1) / c.co)) continue;   // chained 1x1: inputs in one cout tile
       if (c.co > 32 && a.cout_pad <= c.co / 2) continue;             // mostly padding
       if (c.co == 32 && a.cout_pad > 32) continue;
       if (c.co == 128 && (a.cout_pad % 128) == 64 && a.cout_pad <= 320) continue;   // 192, 320: 64-wide tiles waste nothing
@@ -567,6 +620,10 @@ static int make_conv_args(const glsdet_conv_desc* d, int hint, ConvArgs& a, doub
   gls_fastdiv(Ho * Wo, &a.howo_mul, &a.howo_sh);
   gls_fastdiv(Wo, &a.wo_mul, &a.wo_sh);
   a.n_co_tiles = a.n_px_tiles = 0;
+  a.w2 = nullptr; a.scale2 = a.bias2 = nullptr; a.y2 = nullptr;
+  a.y2_sn = a.y2_sh = a.y2_sw = 0;
+  a.c2_0 = a.cin2 = a.cout2 = a.cout2_pad = a.kpad2 = a.act2 = a.y2_lin = 0;
+  a.w2_bytes = 0;
   const int64_t xalloc = (const char*)x.alloc_hi - (const char*)x.alloc_lo;
   const int64_t wbytes = (int64_t)a.cout_pad * a.kpad * dtype_size(x.dtype);
   if (xalloc >= 0x7fffffffLL || wbytes >= 0x7fffffffLL)
@@ -587,12 +644,47 @@ static int make_conv_args(const glsdet_conv_desc* d, int hint, ConvArgs& a, doub
   return 0;
 }
 
+// chained 1x1 (glsdet_conv2d_chain): validate, fill the argument block, add its work to the op's counters
+static int add_chain(const glsdet_conv_desc* d, const glsdet_conv_chain* c, ConvArgs& a, double* flops, double* bytes) {
+  if (!c->w2 || !c->scale2 || !c->bias2) GLS_FAIL(GLSDET_E_ARG, "conv2d_chain: null weight/scale/bias");
+  if (((uintptr_t)c->w2 | (uintptr_t)c->scale2 | (uintptr_t)c->bias2) & 15) GLS_FAIL(GLSDET_E_ALIGN, "conv2d_chain: operands must be 16-byte aligned");
+  int rc;
+  if ((rc = check_view(c->y2, "conv2d_chain.y2"))) return rc;
+  const glsdet_view& y = d->y;
+  if (d->x.dtype != y.dtype || c->y2.dtype != y.dtype) GLS_FAIL(GLSDET_E_ARG, "conv2d_chain: x, y and y2 must share one dtype");
+  if (c->y2.n != y.n || c->y2.h != y.h || c->y2.w != y.w || c->y2.c % 8) GLS_FAIL(GLSDET_E_ARG, "conv2d_chain: y2 must have y's pixel extent");
+  const int es = dtype_size(y.dtype);
+  if (c->cin2 < 1 || c->c0 < 0 || c->c0 + c->cin2 > y.c || (c->cin2 * es) % 32 || (c->c0 * es) % 16)
+    GLS_FAIL(GLSDET_E_ARG, "conv2d_chain: input channel range [%d,%d) of y (%d channels) not usable", c->c0, c->c0 + c->cin2, y.c);
+  if (c->act2 < 0 || c->act2 > 5) GLS_FAIL(GLSDET_E_ARG, "conv2d_chain: bad act2 %d", c->act2);
+  a.cout2 = c->y2.c;
+  a.cout2_pad = glsdet_conv_cout_pad(c->y2.c);
+  if (a.cout2_pad > 128) GLS_FAIL(GLSDET_E_ARG, "conv2d_chain: at most 128 chained output channels");
+  a.w2 = (const unsigned char*)c->w2;
+  a.scale2 = c->scale2;
+  a.bias2 = c->bias2;
+  a.y2 = (unsigned char*)c->y2.base;
+  a.y2_sn = c->y2.sn; a.y2_sh = c->y2.sh; a.y2_sw = c->y2.sw;
+  a.c2_0 = c->c0; a.cin2 = c->cin2; a.act2 = c->act2;
+  a.kpad2 = glsdet_conv_kpad(1, 1, c->cin2, y.dtype);
+  a.w2_bytes = (unsigned)((int64_t)a.cout2_pad * a.kpad2 * es);
+  a.y2_lin = (c->y2.sh == (int64_t)y.w * c->y2.sw && c->y2.sn == (int64_t)y.h * c->y2.sh) ? 1 : 0;
+  *flops += 2.0 * (double)a.M * c->y2.c * c->cin2;
+  *bytes += (double)a.M * c->y2.c * es + (double)a.cout2_pad * a.kpad2 * es;
+  return 0;
+}
+// the chained product runs in the workgroup whose cout tile holds its input channels: one tile must hold them all
+static bool chain_fits(const ConvArgs& a, int co_t) {
+  return a.w2 == nullptr || (a.c2_0 / co_t == (a.c2_0 + a.cin2 - 1) / co_t);
+}
+
 // validate the descriptor and build the op for `hint` (d->tile_hint is ignored here)
-static int build_conv_op(const glsdet_conv_desc* d, int hint, OpRecord& op) {
+static int build_conv_op(const glsdet_conv_desc* d, int hint, OpRecord& op, const glsdet_conv_chain* chain = nullptr) {
   ConvArgs a;
   op.kind = 0;
   int rc = make_conv_args(d, hint, a, &op.flops, &op.bytes);
   if (rc) return rc;
+  if (chain && (rc = add_chain(d, chain, a, &op.flops, &op.bytes))) return rc;
   const glsdet_view &x = d->x, &y = d->y;
   const int xdt = x.dtype, ydt = y.dtype;
   // tile_hint: 0 auto, 1 generic kernel, 2 halo kernel, 4 halo kernel with wave-private weight staging,
@@ -601,7 +693,7 @@ static int build_conv_op(const glsdet_conv_desc* d, int hint, OpRecord& op) {
   // 1x1 kernel (6 / 7 were the persistent LDS-DMA halo kernel, removed in round 2: 1.3-1.9x slower),
   // else co<<16|px (generic)
   if (hint == 3) {
-    if (conv1x1_ws_try(a, xdt, ydt, &op) == 0) return 0;
+    if (!a.w2 && conv1x1_ws_try(a, xdt, ydt, &op) == 0) return 0;
     GLS_FAIL(GLSDET_E_ARG, "conv2d: the weight-stationary 1x1 kernel does not apply to this problem");
   }
   if (hint == 6 || hint == 7) GLS_FAIL(GLSDET_E_ARG, "conv2d: tile_hint 6 / 7 (persistent LDS-DMA halo kernel) no longer exist");
@@ -611,9 +703,11 @@ static int build_conv_op(const glsdet_conv_desc* d, int hint, OpRecord& op) {
   int co_t, px_t, kb;
   pick_tile(a, dtype_size(x.dtype), hint >= 0x10000 ? hint : 0, &co_t, &px_t, &kb);
   if (hint >= 0x10000 && co_t > 32 && a.cout_pad <= co_t / 2) GLS_FAIL(GLSDET_E_ARG, "conv2d: tile %dx%d is mostly padding here", co_t, px_t);
-  char nm[96];
-  snprintf(nm, sizeof nm, "conv_igemm<%s,%s,%dx%d,kb%d> %dx%d s%d cin%d cout%d", xdt ? "f32" : "f16",
-           ydt ? "f32" : "f16", co_t, px_t, kb, d->R, d->S, d->stride, x.c, y.c);
+  if (co_t == 0 || (a.w2 && co_t == 32)) GLS_FAIL(GLSDET_E_ARG, "conv2d_chain: no tile of the generic kernel takes this chained problem");
+  if (!chain_fits(a, co_t)) GLS_FAIL(GLSDET_E_ARG, "conv2d_chain: the chained input channels straddle two cout tiles of %d", co_t);
+  char nm[112];
+  snprintf(nm, sizeof nm, "conv_igemm<%s,%s,%dx%d,kb%d> %dx%d s%d cin%d cout%d%s", xdt ? "f32" : "f16",
+           ydt ? "f32" : "f16", co_t, px_t, kb, d->R, d->S, d->stride, x.c, y.c, a.w2 ? " +1x1" : "");
   op.name = nm;
   op.launch = [a, co_t, px_t, kb, xdt, ydt](hipStream_t st) -> int {
     if (xdt == GLSDET_F16 && ydt == GLSDET_F16) return dispatch_tile<f16, f16>(a, co_t, px_t, kb, st);
@@ -739,11 +833,28 @@ extern "C" int glsdet_conv2d(const glsdet_conv_desc* d, void* stream) {
   return submit(std::move(op), stream);
 }
 
+extern "C" int glsdet_conv2d_chain(const glsdet_conv_desc* d, const glsdet_conv_chain* c, void* stream) {
+  if (!d || !c) GLS_FAIL(GLSDET_E_ARG, "conv2d_chain: null argument");
+  OpRecord op;
+  int rc = build_conv_op(d, d->tile_hint, op, c);
+  if (rc) return rc;
+  return submit(std::move(op), stream);
+}
+
 // Measure every kernel/tile variant that applies to this exact problem on the device (its
 // real buffers; launches immediately, never recorded) and report the fastest hint.  Build-time
 // only: it synchronises.  The conv writes its real output, so callers tune before the first
 // real run (contents are overwritten by it).
+static int conv_tune(const glsdet_conv_desc* d, const glsdet_conv_chain* c, void* stream, int32_t* best_hint, float* best_us);
 extern "C" int glsdet_conv2d_tune(const glsdet_conv_desc* d, void* stream, int32_t* best_hint, float* best_us) {
+  return conv_tune(d, nullptr, stream, best_hint, best_us);
+}
+extern "C" int glsdet_conv2d_chain_tune(const glsdet_conv_desc* d, const glsdet_conv_chain* c, void* stream, int32_t* best_hint,
+                                        float* best_us) {
+  if (!c) GLS_FAIL(GLSDET_E_ARG, "conv2d_chain_tune: null argument");
+  return conv_tune(d, c, stream, best_hint, best_us);
+}
+static int conv_tune(const glsdet_conv_desc* d, const glsdet_conv_chain* c, void* stream, int32_t* best_hint, float* best_us) {
   if (!d || !best_hint) GLS_FAIL(GLSDET_E_ARG, "conv2d_tune: null argument");
   hipStream_t st = (hipStream_t)stream;
   // (6 / 7, the persistent LDS-DMA halo kernel, is not offered: slower than 8 / 9 on every layer measured)
@@ -753,7 +864,7 @@ extern "C" int glsdet_conv2d_tune(const glsdet_conv_desc* d, void* stream, int32
   std::vector<int> ids;
   for (int h : hints) {
     OpRecord op;
-    if (build_conv_op(d, h, op)) continue;             // variant does not apply
+    if (build_conv_op(d, h, op, c)) continue;          // variant does not apply
     if ((h >> 16) == 32 && d->y.c > 32) continue;
     ops.push_back(std::move(op));
     ids.push_back(h);

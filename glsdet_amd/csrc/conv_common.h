@@ -41,6 +41,15 @@ struct ConvArgs {
   // n_co_tiles, and tiles_x / tiles_y of the pixel-tile kernels
   unsigned nco_mul, tx_mul, ty_mul;
   int nco_sh, tx_sh, ty_sh;
+  // chained 1x1 conv (glsdet_conv2d_chain): y2 = act2(scale2 * W2 . y[.., c2_0 : c2_0 + cin2] + bias2), computed by the
+  // workgroup from the tile it just stored (w2 == nullptr: none).  y2 has y's pixel geometry.
+  const unsigned char* w2;
+  const float* scale2;
+  const float* bias2;
+  unsigned char* y2;
+  long y2_sn, y2_sh, y2_sw;
+  int c2_0, cin2, cout2, cout2_pad, kpad2, act2, y2_lin;
+  unsigned w2_bytes;
 };
 
 // host: mul, sh with floor(n / d) == umulhi(n, mul) >> sh for 0 <= n < 2^31, 2 <= d < 2^31; d == 1 -> sh = -1
@@ -276,6 +285,146 @@ __device__ __forceinline__ void halo_store_tile(const unsigned char* stile, cons
       *reinterpret_cast<u32x4*>(a.y + yo * (long)sizeof(TO)) = v;
     }
   }
+}
+
+// ---- chained 1x1 conv on the tile a workgroup has just produced (CSPLayer: conv1|conv2 -> m.0.conv1, Bottleneck i ->
+// Bottleneck i+1 conv1).  `tile`: the FINAL output tile (after residual / post activation) in LDS, PX_T rows of
+// ORS = CO_T * sizeof(TO) + 16 bytes, TO == T.  `wbuf`: LDS for W2 (cout2_pad rows of cin2 * sizeof(T) + 16 bytes), later
+// reused for the staged y2 tile.  The product reads the stored (rounded) values in the k order of the stand-alone 1x1
+// kernels, so the result equals a separate launch bit for bit.  All 256 threads call it; it starts and ends with a barrier.
+// pix(px_l, &ok) -> element offset of tile pixel px_l in y2's view (ok = false: outside the image).
+template <typename T, int CO_T, int PX_T, typename PixFn>
+__device__ __forceinline__ void chain_1x1(const ConvArgs& a, unsigned char* tile, unsigned char* wbuf, int co0, int tid, PixFn pix) {
+  constexpr int ES = (int)sizeof(T), VEC = 16 / ES;
+  constexpr int ORS = CO_T * ES + 16;
+  const int lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
+  const int rs2 = a.cin2 * ES + 16;                       // W2 row pitch in LDS
+  const int cpr = a.cin2 * ES / 16;                       // 16-byte chunks per W2 row
+  const auto wrs = gls_make_rsrc(a.w2, a.w2_bytes);
+  for (int q = tid; q < a.cout2_pad * cpr; q += 256) {
+    const int row = q / cpr, c = q - row * cpr;
+    *reinterpret_cast<u32x4*>(wbuf + row * rs2 + c * 16) = gls_buf_load16(wrs, (unsigned)(row * a.kpad2 * ES + c * 16));
+  }
+  __syncthreads();
+  constexpr int NPB = PX_T / 32, WPB = 4 / NPB;           // pixel blocks of 32; waves per pixel block
+  const int pb = wave % NPB, rb0 = wave / NPB;
+  const int nrb = a.cout2_pad / 32;
+  f32x16 acc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[i][e] = 0.0f;
+  const unsigned char* brow = tile + (pb * 32 + l31) * ORS + (a.c2_0 - co0) * ES + lh * 16;
+  const int nk = a.cin2 * ES / 32;
+  for (int kk = 0; kk < nk; ++kk) {
+    const u32x4 bf = *reinterpret_cast<const u32x4*>(brow + kk * 32);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int rb = rb0 + i * WPB;
+      if (rb < nrb) {
+        const u32x4 af = *reinterpret_cast<const u32x4*>(wbuf + (rb * 32 + l31) * rs2 + kk * 32 + lh * 16);
+        MMA<T>::run(af, bf, acc[i]);
+      }
+    }
+  }
+  __syncthreads();                                        // every wave is done with W2: its LDS becomes the y2 stage
+  const int ors2 = a.cout2_pad * ES + 16;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int rb = rb0 + i * WPB;
+    if (rb < nrb) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int co_l = rb * 32 + 8 * g + 4 * lh;
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(a.scale2 + co_l), bi = *reinterpret_cast<const f32x4*>(a.bias2 + co_l);
+        const f32x4 xv = {acc[i][4 * g], acc[i][4 * g + 1], acc[i][4 * g + 2], acc[i][4 * g + 3]};
+        const f32x4 yv = scale_bias_act4<T>(xv, sc, bi, a.act2);
+        const float v[4] = {yv[0], yv[1], yv[2], yv[3]};
+        store4(wbuf + (pb * 32 + l31) * ors2 + co_l * ES, v, (T*)nullptr);
+      }
+    }
+  }
+  __syncthreads();
+  const int ocpr = a.cout2_pad / VEC;
+  for (int q = tid; q < PX_T * ocpr; q += 256) {
+    const int px_l = q / ocpr, cq = q - px_l * ocpr;
+    bool ok;
+    const long po = pix(px_l, ok);
+    if (ok && cq * VEC < a.cout2)
+      *reinterpret_cast<u32x4*>(a.y2 + (po + cq * VEC) * (long)ES) = *reinterpret_cast<const u32x4*>(wbuf + px_l * ors2 + cq * 16);
+  }
+}
+// LDS bytes a kernel needs for the chained 1x1 on a CO_T x PX_T tile: the final tile + max(W2, staged y2)
+template <typename T>
+inline int chain_lds_bytes(int co_t, int px_t, const ConvArgs& a) {
+  const int es = (int)sizeof(T);
+  const int tile = px_t * (co_t * es + 16);
+  const int w2 = a.cout2_pad * (a.cin2 * es + 16), st = px_t * (a.cout2_pad * es + 16);
+  return tile + (w2 > st ? w2 : st);
+}
+
+// Store phase of the pixel-tile kernels when a chained 1x1 follows AND the layer has a residual: the final values are
+// computed in registers (pass 1, stored to y), then written back to LDS in the TO row layout (pass 2) for chain_1x1.
+template <typename TO, int CO_T, int PW>
+__device__ __forceinline__ void halo_store_tile_keep(unsigned char* stile, const ConvArgs& a, int img, int ty0, int tx0, int co0,
+                                                     int tid) {
+  constexpr int PX_T = 128, ORS = CO_T * (int)sizeof(TO) + 16, ORSW = CO_T * 4 + 16;
+  constexpr int VO = 16 / (int)sizeof(TO), OCPR = CO_T / VO, NIT = PX_T * OCPR / 256;
+  const bool wide = sizeof(TO) == 2;
+  u32x4 fin[NIT];
+#pragma unroll
+  for (int b = 0; b < NIT; ++b) {
+    const int q = tid + b * 256;
+    const int px_l = q / OCPR, cq = q - px_l * OCPR;
+    int oy, ox;
+    pix_to_xy16<PW>(px_l, oy, ox);
+    const int ho = ty0 + oy, wo = tx0 + ox, co = co0 + cq * VO;
+    fin[b] = u32x4{0u, 0u, 0u, 0u};
+    if (ho < a.Ho && wo < a.Wo && co < a.Cout) {
+      const long ro = (long)img * a.r_sn + (long)ho * a.r_sh + (long)wo * a.r_sw + co;
+      const u32x4 rv = *reinterpret_cast<const u32x4*>(a.res + ro * (long)sizeof(TO));
+      if (wide) {
+        const f32x4 lo = *reinterpret_cast<const f32x4*>(stile + px_l * ORSW + cq * 32);
+        const f32x4 hi = *reinterpret_cast<const f32x4*>(stile + px_l * ORSW + cq * 32 + 16);
+        fin[b] = add_chunk_wide(lo, hi, rv, a.act_post);
+      } else {
+        fin[b] = add_chunk(*reinterpret_cast<const u32x4*>(stile + px_l * ORS + cq * 16), rv, (TO*)nullptr, a.act_post);
+      }
+      const long yo = (long)img * a.y_sn + (long)ho * a.y_sh + (long)wo * a.y_sw + co;
+      *reinterpret_cast<u32x4*>(a.y + yo * (long)sizeof(TO)) = fin[b];
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int b = 0; b < NIT; ++b) {
+    const int q = tid + b * 256;
+    const int px_l = q / OCPR, cq = q - px_l * OCPR;
+    *reinterpret_cast<u32x4*>(stile + px_l * ORS + cq * 16) = fin[b];
+  }
+}
+
+// epilogue tail shared by the pixel-tile kernels: store the staged tile, then the chained 1x1 if this workgroup's cout tile
+// holds its input channels
+template <typename T, typename TO, int CO_T, int PW>
+__device__ __forceinline__ void halo_store_and_chain(unsigned char* smem, const ConvArgs& a, int img, int ty0, int tx0, int co0,
+                                                     int tid) {
+  if constexpr (sizeof(T) == sizeof(TO)) {
+    const bool chain = a.w2 != nullptr && co0 <= a.c2_0 && a.c2_0 + a.cin2 <= co0 + CO_T;
+    if (chain) {
+      if (a.res) halo_store_tile_keep<TO, CO_T, PW>(smem, a, img, ty0, tx0, co0, tid);
+      else halo_store_tile<TO, CO_T, PW>(smem, a, img, ty0, tx0, co0, tid);
+      auto y2pix = [&](int px_l, bool& ok) -> long {
+        int oy, ox;
+        pix_to_xy16<PW>(px_l, oy, ox);
+        const int ho = ty0 + oy, wo = tx0 + ox;
+        ok = ho < a.Ho && wo < a.Wo;
+        return (long)img * a.y2_sn + (long)ho * a.y2_sh + (long)wo * a.y2_sw;
+      };
+      chain_1x1<T, CO_T, 128>(a, smem, smem + 128 * (CO_T * (int)sizeof(TO) + 16), co0, tid, y2pix);
+      return;
+    }
+  }
+  halo_store_tile<TO, CO_T, PW>(smem, a, img, ty0, tx0, co0, tid);
 }
 
 // host-side dispatch of the halo kernel (conv_halo.hip); returns 1 if it does not apply

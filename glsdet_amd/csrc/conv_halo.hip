@@ -218,7 +218,7 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const ConvArgs a, const 
     }
   }
   __syncthreads();
-  halo_store_tile<TO, CO_T, PW>(smem, a, img, ty0, tx0, co0, tid);
+  halo_store_and_chain<T, TO, CO_T, PW>(smem, a, img, ty0, tx0, co0, tid);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -240,7 +240,11 @@ __device__ __forceinline__ void halo_lds_barrier() {
 }
 
 // KB = bytes of channels per chunk: 128, or 64 (half the LDS per workgroup: more workgroups per CU, a barrier every 4 MFMAs)
-template <typename T, typename TO, int CO_T, int KS, int RING, int KB = 128>
+// STR = 2 (3x3 only): the stride-2 downsampling convs.  The patch is (2*8+1) x (2*16+1) input pixels; its columns are
+// stored DE-INTERLEAVED (even columns first, then the odd ones), so that the 16 pixels of a fragment read, which are two
+// input columns apart, are consecutive LDS rows again: tap (r, s) of output pixel (oy, ox) is slot
+// (2*oy + r) * PW + ox + (s & 1 ? HALF : s >> 1) -- a per-lane base plus a per-tap constant, exactly as for stride 1.
+template <typename T, typename TO, int CO_T, int KS, int RING, int KB = 128, int STR = 1>
 __global__ __launch_bounds__(256) void conv_halo_ring_kernel(const ConvArgs a, const int tiles_x, const int tiles_y) {
   constexpr int TH = 8, TW = 16, WCO = 2;
   constexpr int RS = KB + 16;
@@ -249,7 +253,10 @@ __global__ __launch_bounds__(256) void conv_halo_ring_kernel(const ConvArgs a, c
   constexpr int VEC = 16 / (int)sizeof(T);
   constexpr int KE = KB / (int)sizeof(T);
   constexpr int PX_T = TH * TW;
-  constexpr int PH = HaloGeom<KS, TH, TW>::PH, PW = HaloGeom<KS, TH, TW>::PW;
+  constexpr int PH = (TH - 1) * STR + KS, PW = (TW - 1) * STR + KS;
+  constexpr int HALF = (PW + 1) / 2;               // STR 2: even columns occupy slots [0, HALF), odd ones [HALF, PW)
+  constexpr int PITCH = STR * PW;                  // slots between two output rows
+  static_assert(STR == 1 || (STR == 2 && KS == 3), "stride 2 is built for 3x3");
   constexpr int NP = (PH * PW * CPRW + 255) / 256;
   constexpr int WPX = 4 / WCO;
   constexpr int WT_CO = CO_T / WCO, WT_PX = PX_T / WPX;
@@ -294,9 +301,10 @@ __global__ __launch_bounds__(256) void conv_halo_ring_kernel(const ConvArgs a, c
 #pragma unroll
   for (int i = 0; i < NP; ++i) {
     const int q = tid + i * 256;
-    const int pp = q / CPRW;
-    const int py = pp / PW, px = pp - py * PW;
-    const int hi = ty0 - pad + py, wi = tx0 - pad + px;
+    const int pp = q / CPRW;                       // patch slot
+    const int py = pp / PW, ps = pp - py * PW;
+    const int px = STR == 1 ? ps : (ps < HALF ? 2 * ps : 2 * (ps - HALF) + 1);
+    const int hi = ty0 * STR - pad + py, wi = tx0 * STR - pad + px;
     const bool ok = pp < PH * PW && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
     poff[i] = ok ? a.x_off + (unsigned)(((long)img * a.x_sn + (long)hi * a.x_sh + (long)wi * a.x_sw + kc * VEC) * (long)sizeof(T))
                  : GLS_OOB;
@@ -360,8 +368,8 @@ __global__ __launch_bounds__(256) void conv_halo_ring_kernel(const ConvArgs a, c
   for (int j = 0; j < TN; ++j) {
     const int pix = wpx * WT_PX + j * 32 + l31;
     int oy, ox;
-    pix_to_xy16<PW>(pix, oy, ox);
-    b_off[j] = PATCH_OFF + (oy * PW + ox) * RS + lh * 16;
+    pix_to_xy16<PITCH>(pix, oy, ox);
+    b_off[j] = PATCH_OFF + (oy * PITCH + ox) * RS + lh * 16;
   }
 
   load_patch(0);
@@ -393,7 +401,11 @@ __global__ __launch_bounds__(256) void conv_halo_ring_kernel(const ConvArgs a, c
       mma_tap(tap_off);
       g = g + 1 == RING ? 0 : g + 1;
       ++ts;
-      tap_off += (ts == KS) ? (PW - KS + 1) * RS : RS;
+      if (STR == 1) {
+        tap_off += (ts == KS) ? (PW - KS + 1) * RS : RS;
+      } else {                                      // slots of s = 0, 1, 2: 0, HALF, 1; then the next patch row
+        tap_off += (ts == 1) ? HALF * RS : (ts == 2 ? -(HALF - 1) * RS : (PW - 1) * RS);
+      }
       ts = (ts == KS) ? 0 : ts;
     }
     halo_wait_vm_barrier<NI * (RING - 2)>();
@@ -432,21 +444,23 @@ __global__ __launch_bounds__(256) void conv_halo_ring_kernel(const ConvArgs a, c
     }
   }
   __syncthreads();
-  halo_store_tile<TO, CO_T, PW>(smem, a, img, ty0, tx0, co0, tid);
+  halo_store_and_chain<T, TO, CO_T, PITCH>(smem, a, img, ty0, tx0, co0, tid);
 }
 
-template <typename T, typename TO, int CO_T, int KS, int RING, int KB = 128>
+template <typename T, typename TO, int CO_T, int KS, int RING, int KB = 128, int STR = 1>
 static int launch_halo_ring(const ConvArgs& a, hipStream_t st) {
-  constexpr int PH = 8 + KS - 1, PW = 16 + KS - 1;
+  constexpr int PH = 7 * STR + KS, PW = 15 * STR + KS;
   constexpr int stage = RING * CO_T * KB + PH * PW * (KB + 16);
   constexpr int epiw = epi_bytes<TO>(CO_T, 128, true), ldsw = stage > epiw ? stage : epiw;
   const int epi = epi_bytes<TO>(CO_T, 128, a.res != nullptr);
-  const int lds = stage > epi ? stage : epi;
-  auto kern = conv_halo_ring_kernel<T, TO, CO_T, KS, RING, KB>;
-  static bool attr_set = false;
-  if (!attr_set && ldsw > 64 * 1024) {
-    GLS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, ldsw));
-    attr_set = true;
+  int lds = stage > epi ? stage : epi;
+  if (a.w2 && chain_lds_bytes<T>(CO_T, 128, a) > lds) lds = chain_lds_bytes<T>(CO_T, 128, a);
+  auto kern = conv_halo_ring_kernel<T, TO, CO_T, KS, RING, KB, STR>;
+  static int attr_lds = 64 * 1024;
+  const int want_attr = lds > ldsw ? lds : ldsw;
+  if (want_attr > attr_lds) {
+    GLS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, want_attr));
+    attr_lds = want_attr;
   }
   ConvArgs b = a;
   b.n_co_tiles = (a.Cout + CO_T - 1) / CO_T;
@@ -477,12 +491,14 @@ static int launch_halo(const ConvArgs& a, hipStream_t st) {
   constexpr int stage = 2 * CO_T * 144 + PH * PW * 144;
   constexpr int epiw = epi_bytes<TO>(CO_T, TH * TW, true), ldsw = stage > epiw ? stage : epiw;
   const int epi = epi_bytes<TO>(CO_T, TH * TW, a.res != nullptr);
-  const int lds = stage > epi ? stage : epi;
+  int lds = stage > epi ? stage : epi;
+  if (a.w2 && chain_lds_bytes<T>(CO_T, TH * TW, a) > lds) lds = chain_lds_bytes<T>(CO_T, TH * TW, a);
   auto kern = conv_halo_kernel<T, TO, CO_T, WCO, KS, TH, TW>;
-  static bool attr_set = false;
-  if (!attr_set && ldsw > 64 * 1024) {
-    GLS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, ldsw));
-    attr_set = true;
+  static int attr_lds = 64 * 1024;
+  const int want_attr = lds > ldsw ? lds : ldsw;
+  if (want_attr > attr_lds) {
+    GLS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, want_attr));
+    attr_lds = want_attr;
   }
   ConvArgs b = a;
   b.n_co_tiles = (a.Cout + CO_T - 1) / CO_T;
@@ -521,8 +537,24 @@ static int halo_ring_k64_by_ks(const ConvArgs& a, hipStream_t st) {
 // 0 when `op` was filled in.
 int conv_halo_try(const ConvArgs& a, int xdt, int ydt, int hint, OpRecord* op) {
   if (hint == 1 || hint == 3 || (hint > 5 && hint != 8 && hint != 9 && hint != 10 && hint != 11)) return 1;          // hint 1 / explicit tile = the generic kernel
-  if (a.stride != 1 || a.R != a.S || (a.R != 3 && a.R != 5 && a.R != 7) || a.pad != a.R / 2) return 1;
   const int es = dtype_size(xdt);
+  if (a.stride == 2) {            // 3x3 stride 2: the de-interleaved-patch form of the ring kernel, 64-byte channel chunks
+    if (a.R != 3 || a.S != 3 || a.pad != 1 || xdt != ydt || (a.Cin * es) % 64 || (hint != 0 && hint != 10 && hint != 11)) return 1;
+    if (hint == 11 && a.cout_pad <= 64) return 1;
+    const long tiles = (long)((a.Ho + 7) / 8) * ((a.Wo + 15) / 16);
+    if (hint == 0 && (double)tiles * 128.0 / ((double)a.Ho * a.Wo) > 1.30) return 1;
+    const int co_t = (a.cout_pad <= 64 || hint == 10) ? 64 : 128;
+    if (a.w2 && a.c2_0 / co_t != (a.c2_0 + a.cin2 - 1) / co_t) return 1;
+    char nm[96];
+    snprintf(nm, sizeof nm, "conv_halo_ring_k64_s2<%s,%dx8x16> 3x3 s2 cin%d cout%d%s", xdt ? "f32" : "f16", co_t, a.Cin, a.Cout, a.w2 ? " +1x1" : "");
+    op->name = nm;
+    op->launch = [a, co_t, xdt](hipStream_t st) -> int {
+      if (xdt == GLSDET_F16) return co_t == 128 ? launch_halo_ring<f16, f16, 128, 3, 4, 64, 2>(a, st) : launch_halo_ring<f16, f16, 64, 3, 4, 64, 2>(a, st);
+      return co_t == 128 ? launch_halo_ring<float, float, 128, 3, 4, 64, 2>(a, st) : launch_halo_ring<float, float, 64, 3, 4, 64, 2>(a, st);
+    };
+    return 0;
+  }
+  if (a.stride != 1 || a.R != a.S || (a.R != 3 && a.R != 5 && a.R != 7) || a.pad != a.R / 2) return 1;
   if ((a.Cin * es) % ((hint == 10 || hint == 11) ? 64 : 128)) return 1;      // whole channel chunks (hint 10 works on 64-byte chunks)
   if (xdt != ydt) return 1;
   // wasted MFMA work on partial tiles: prefer the flat-pixel kernel when it is large
@@ -535,9 +567,10 @@ int conv_halo_try(const ConvArgs& a, int xdt, int ydt, int hint, OpRecord* op) {
   const int co_t = (a.cout_pad <= 64 || hint == 5 || hint == 8 || hint == 10) ? 64 : 128;     // hint 5 / 8 / 10: 64-row cout tiles also for wide layers
   const bool wpriv = hint == 4;                     // wave-private weight staging (128-row cout tile only)
   if (wpriv && co_t != 128) return 1;
+  if (a.w2 && a.c2_0 / co_t != (a.c2_0 + a.cin2 - 1) / co_t) return 1;      // chained 1x1: its input channels in ONE cout tile
   char nm[96];
-  snprintf(nm, sizeof nm, "conv_halo%s<%s,%dx8x16> %dx%d s1 cin%d cout%d", wpriv ? "_wp" : (ring ? (ring_k64 ? "_ring_k64" : "_ring") : ""), xdt ? "f32" : "f16", co_t, a.R,
-           a.S, a.Cin, a.Cout);
+  snprintf(nm, sizeof nm, "conv_halo%s<%s,%dx8x16> %dx%d s1 cin%d cout%d%s", wpriv ? "_wp" : (ring ? (ring_k64 ? "_ring_k64" : "_ring") : ""), xdt ? "f32" : "f16", co_t, a.R,
+           a.S, a.Cin, a.Cout, a.w2 ? " +1x1" : "");
   op->name = nm;
   op->launch = [a, co_t, xdt, wpriv, ring, ring_k64](hipStream_t st) -> int {
     if (ring_k64) {

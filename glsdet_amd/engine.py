@@ -14,7 +14,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import F16, F32, ACT, View, ConvDesc, check
+from ._lib import F16, F32, ACT, View, ConvChain, ConvDesc, check
 
 _TORCH_DT = {F16: torch.float16, F32: torch.float32}
 _ESIZE = {F16: 2, F32: 4}
@@ -247,6 +247,52 @@ class Engine:
         check(self.lib.glsdet_conv2d(C.byref(d), _stream_ptr(self.stream)), "conv2d")
         self._shadow_end(sh)
         return out
+
+    def conv_chain(self, x: TView, packed, stride: int, pad: int, act: str, out: TView, res: Optional[TView],
+                   packed2, act2: str, c0: int, cin2: int, out2: TView, res_first: bool = False) -> bool:
+        """conv (as Engine.conv) + in the same launch a 1x1 conv (packed2, act2) on channels [c0, c0 + cin2) of its result
+        -> out2 (glsdet_conv2d_chain).  Returns False, having launched nothing, when no kernel takes the fused problem
+        (the caller then emits the two convs)."""
+        wdev, sdev, bdev, cout, R, S = packed
+        w2, s2, b2, cout2, R2, S2 = packed2
+        assert R2 == 1 and S2 == 1 and out2.c == ceil_to(cout2, 8)
+        d = ConvDesc()
+        d.x, d.y = x.as_c(), out.as_c()
+        d.res = res.as_c() if res is not None else View()
+        d.w, d.scale, d.bias = wdev.data_ptr(), sdev.data_ptr(), bdev.data_ptr()
+        d.R, d.S, d.stride, d.pad, d.act, d.tile_hint = R, S, stride, pad, ACT[act], 0
+        if res_first and res is not None:
+            d.act |= 0x100
+        c = ConvChain()
+        c.y2 = out2.as_c()
+        c.w2, c.scale2, c.bias2 = w2.data_ptr(), s2.data_ptr(), b2.data_ptr()
+        c.act2, c.c0, c.cin2 = ACT[act2], c0, cin2
+        st = _stream_ptr(self.stream)
+        if self.autotune:
+            key = ("chain", x.n, x.h, x.w, x.c, x.sn, x.sh, x.sw, out.c, out.sn, out.sh, out.sw, R, S, stride, pad,
+                   res is not None, out.dtype, c0, c.cin2, out2.c, out2.sn, out2.sh, out2.sw)
+            if key not in self._tuned:
+                best, us = C.c_int32(0), C.c_float(0)
+                rc = self.lib.glsdet_conv2d_chain_tune(C.byref(d), C.byref(c), st, C.byref(best), C.byref(us))
+                self._tuned[key] = best.value if rc == 0 else -1
+                self._tune_dirty = True
+            if self._tuned[key] < 0:
+                return False
+            d.tile_hint = self._tuned[key]
+        sh = None
+        if self.shadow is not None and self.shadow.get("hint"):           # the variant under test computes y (unfused) first
+            sh = self._shadow_begin([d], [out], self.shadow["hint"], multi=False)
+        ok = self.lib.glsdet_conv2d_chain(C.byref(d), C.byref(c), st) == 0
+        if ok and self.shadow is not None:
+            self._shadow_end(sh)
+            # and the chained product against a stand-alone 1x1 on the stored y: bit for bit
+            ref = self.tensor(out2.n, out2.h, out2.w, out2.c, out2.dtype)
+            self.conv(out.channels(c0, c0 + cin2), packed2, 1, 0, act2, out=ref, tile_hint=1)
+            a, b = out2.to_nchw(), ref.to_nchw()
+            self.shadow["log"].append({"shape": (x.n, out.h, out.w, cin2, out2.c, 1, 1), "scale": float(a.abs().max()),
+                                       "err": float((a - b).abs().max()), "nan": bool(torch.isnan(a).any()),
+                                       "differ": float((a != b).float().mean())})
+        return ok
 
     def conv_multi(self, xs: Sequence[TView], packs, stride: int, pad: int, act: str,
                    outs: Optional[Sequence[Optional[TView]]] = None, ress: Optional[Sequence[Optional[TView]]] = None,

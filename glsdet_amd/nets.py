@@ -142,16 +142,54 @@ class NetBuilder:
         return self.sd[p + ".conv.weight"].shape[0]
 
     # ------------------------------------------------------------------ blocks
+    def _cba_chain(self, prefixes, x: TView, nxt: str, cin2: int, out: TView, res: Optional[TView] = None) -> Optional[TView]:
+        """BaseConv(s) `prefixes` (as cba, written to `out`) with the 1x1 BaseConv `nxt` chained onto channels [0, cin2) of
+        the result in the same launch (Engine.conv_chain).  -> nxt's output, or None when the fused form does not apply
+        (nothing was emitted then)."""
+        if isinstance(prefixes, str):
+            prefixes = [prefixes]
+        if os.environ.get("GLSDET_NO_CHAIN") or any(self.is_depthwise(q) for q in list(prefixes) + [nxt]):
+            return None
+        parts = [self._bn_part(q) for q in prefixes]
+        k = parts[0][0].shape[-1]
+        pk = self._pack("+".join(prefixes), parts, x.c)
+        w2 = self.sd[nxt + ".conv.weight"]
+        if w2.shape[-1] != 1 or w2.shape[1] != cin2:
+            return None
+        pk2 = self._pack(nxt, [self._bn_part(nxt)], cin2)
+        t = self.e.tensor(x.n, out.h, out.w, w2.shape[0])
+        if not self.e.conv_chain(x, pk, 1, (k - 1) // 2, "silu", out, res, pk2, "silu", 0, cin2, t):
+            return None
+        c0 = 0
+        for q, pt in zip(prefixes, parts):
+            self._rec(q, out, c0, c0 + pt[0].shape[0])
+            c0 += pt[0].shape[0]
+        self._rec(nxt, t, 0, w2.shape[0])
+        return t
+
     def csp(self, p: str, x: TView, shortcut: bool, out: Optional[TView] = None) -> TView:
+        """CSPLayer (darknet.py:66-112).  Every 1x1 `m.i.conv1` rides in the launch of the conv that produces its input
+        (conv1|conv2 for i = 0, Bottleneck i-1's 3x3 otherwise) where the fused kernel applies: the hidden tensor of a
+        Bottleneck is then written once and the 1x1 costs neither a launch nor a re-read of `a`."""
         hid = self.conv_out_channels(p + ".conv1")
         cat = self.e.tensor(x.n, x.h, x.w, 2 * hid)
-        self.cba([p + ".conv1", p + ".conv2"], x, out=cat)          # [main | short]
+        n = 0
+        while self.has("%s.m.%d.conv1.conv.weight" % (p, n)):
+            n += 1
+        t = self._cba_chain([p + ".conv1", p + ".conv2"], x, "%s.m.0.conv1" % p, hid, cat) if n else None
+        if t is None:
+            self.cba([p + ".conv1", p + ".conv2"], x, out=cat)          # [main | short]
         a = cat.channels(0, hid)
-        i = 0
-        while self.has("%s.m.%d.conv1.conv.weight" % (p, i)):
-            t = self.cba("%s.m.%d.conv1" % (p, i), a)
-            self.cba("%s.m.%d.conv2" % (p, i), t, out=a, res=a if shortcut else None)   # in place
-            i += 1
+        for i in range(n):
+            if t is None:
+                t = self.cba("%s.m.%d.conv1" % (p, i), a)
+            t_next = None
+            if i + 1 < n:
+                t_next = self._cba_chain("%s.m.%d.conv2" % (p, i), t, "%s.m.%d.conv1" % (p, i + 1), hid, a,
+                                         res=a if shortcut else None)
+            if t_next is None:
+                self.cba("%s.m.%d.conv2" % (p, i), t, out=a, res=a if shortcut else None)   # in place
+            t = t_next
         return self.cba(p + ".conv3", cat, out=out)
 
     def spp(self, p: str, x: TView, out: Optional[TView] = None) -> TView:

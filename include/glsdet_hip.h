@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GLSDET_ABI_VERSION 5
+#define GLSDET_ABI_VERSION 6
 
 enum { GLSDET_F16 = 0, GLSDET_F32 = 1 };
 enum { GLSDET_ACT_NONE = 0, GLSDET_ACT_SILU = 1, GLSDET_ACT_RELU = 2, GLSDET_ACT_LRELU = 3,
@@ -104,6 +104,25 @@ int     glsdet_conv2d_multi_tune(const glsdet_conv_desc* d, int32_t n, void* str
  * problem on the device (synchronises; never recorded into a plan) and returns the fastest
  * tile_hint.  The output view is written with the conv result. */
 int     glsdet_conv2d_tune(const glsdet_conv_desc* d, void* stream, int32_t* best_hint, float* best_us);
+/* A conv (exactly as glsdet_conv2d, residual included) followed IN THE SAME LAUNCH by a 1x1 conv + folded BN + act on a
+ * channel range of its result -- the two back-to-back BaseConvs of a CSPLayer / Bottleneck chain
+ * (drone/models/base/darknet.py:58-63: `y = conv2(conv1(x))`; :96-107: conv1 -> m[0].conv1):
+ *     y  = glsdet_conv2d(d)
+ *     y2 = act2( scale2 * sum_{c < cin2} y[.., c0 + c] * w2[co2][c] + bias2 )          (w2 packed as for a 1x1 conv)
+ * The workgroup that produced a tile multiplies it from LDS while it is still there: the 1x1 costs no launch and no
+ * re-read of y.  It consumes the STORED (rounded) values in the k order of the stand-alone kernels, so y2 equals what
+ * glsdet_conv2d on y would give, bit for bit.  Limits: x, y, y2 one dtype; y2.c <= 128; the channels [c0, c0+cin2) must
+ * lie inside one cout tile of the kernel that runs d (else GLSDET_E_ARG: callers fall back to two launches).          */
+typedef struct glsdet_conv_chain {
+  glsdet_view y2;          /* y's n, h, w                                                        */
+  const void*  w2;         /* [cout_pad(y2.c)][kpad(1,1,cin2)] elements of y.dtype               */
+  const float* scale2;
+  const float* bias2;
+  int32_t act2, c0, cin2, _pad;
+} glsdet_conv_chain;
+int     glsdet_conv2d_chain(const glsdet_conv_desc* d, const glsdet_conv_chain* c, void* stream);
+int     glsdet_conv2d_chain_tune(const glsdet_conv_desc* d, const glsdet_conv_chain* c, void* stream, int32_t* best_hint,
+                                 float* best_us);
 /* Depthwise k x k conv + folded BN + act (`dconv` of DWConv, drone/models/base/baseConv.py:22-30;
  * mmcv DepthwiseSeparableConvModule).  Same descriptor; x.c == y.c; w = [R*S][x.c] elements of
  * x.dtype (tap-major), scale/bias fp32 [x.c]; res must be empty. */

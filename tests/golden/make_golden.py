@@ -200,7 +200,7 @@ def merge_cases():
     for case in range(12):
         r = np.random.default_rng([case, 0x2C5])
         n = int(r.integers(1, 90)) if case else 1
-        centres = r.uniform(20, 400, (max(1, n // 6), 2))
+        centres = r.uniform(120, 400, (max(1, n // 6), 2))        # boxes stay at positive coordinates (wh <= 90, jitter 6 sigma)
         c = centres[r.integers(0, len(centres), n)] + r.normal(0, 6, (n, 2))
         wh = r.uniform(8, 90, (n, 2))
         sc = r.uniform(0.05, 1.0, n)

@@ -399,3 +399,38 @@ def test_detections_scored_against_the_reference_detections_with_cocoeval(golden
     assert ap >= (0.98 if mode == "f32" else 0.70)
     assert E.stats[1] >= (0.995 if mode == "f32" else 0.88)
     assert abs(len(res) - len(anns)) <= max(2, len(anns) // 50)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["f32", "f16"])
+@pytest.mark.parametrize("hid,n,shortcut,hw", [(32, 1, True, (20, 24)), (64, 3, True, (19, 23)), (128, 3, True, (12, 21)),
+                                              (128, 1, False, (9, 10)), (64, 2, False, (33, 17))])
+def test_csp_with_chained_1x1_equals_the_unfused_launches_bit_for_bit(engines, monkeypatch, mode, hid, n, shortcut, hw):
+    """CSPLayer with every `m.i.conv1` chained into the launch that produces its input (glsdet_conv2d_chain) vs the same
+    layer as separate launches: identical bits in both precisions (the chained product reads the stored tile in the k
+    order of the stand-alone kernel), fewer launches."""
+    from glsdet_amd.arch import _Table
+    from glsdet_amd.nets import NetBuilder
+    from glsdet_amd.synth import synth_input, synth_state_dict
+    eng = engines[mode]
+    t = _Table()
+    t.csp("m", 2 * hid, 2 * hid, n, False)
+    sd = synth_state_dict(t, 5)
+    x = synth_input((2, 2 * hid, hw[0], hw[1]), 9)
+    outs, nops = [], []
+    for no_chain in (True, False):
+        if no_chain:
+            monkeypatch.setenv("GLSDET_NO_CHAIN", "1")
+        else:
+            monkeypatch.delenv("GLSDET_NO_CHAIN", raising=False)
+        plan = eng.new_plan()
+        with plan:
+            out = NetBuilder(eng, sd).csp("m", _upload(eng, x), shortcut)
+        plan.run()
+        torch.cuda.synchronize()
+        outs.append(out.to_nchw().cpu())
+        nops.append(plan.num_ops)
+    want = O.csp_layer(sd, "m", x if mode == "f32" else x.half().float(), shortcut)
+    assert float((outs[0] - want).abs().max()) <= (5e-5 if mode == "f32" else 2e-2) * max(1.0, float(want.abs().max()))
+    assert torch.equal(outs[0], outs[1])
+    assert nops[1] == nops[0] - n, nops

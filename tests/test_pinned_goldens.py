@@ -120,11 +120,15 @@ def test_hip_merge_nms_equals_the_reference_py_cpu_nms(merge_golden, case):
     dets = np.asarray(g["nms/%d/dets" % case])
     thr = float(g["nms/%d/thr" % case])
     d32 = dets.astype(np.float32)
-    keep = list(g["nms/%d/keep" % case]) if dets.dtype == np.float32 else U.py_cpu_nms(d32, thr)
+    # the back-mapping rebuilds the far corner as x + (x2 - x1) (ufpmp_det_eval.py:291-295), in float32 on the device
+    d32[:, 2] = d32[:, 0] + (d32[:, 2] - d32[:, 0])
+    d32[:, 3] = d32[:, 1] + (d32[:, 3] - d32[:, 1])
+    assert d32[:, :2].min() > 0
+    keep = U.py_cpu_nms(d32, thr)             # the oracle is pinned to the reference's keep lists by the CPU test above
     want = d32[keep]
     max_det = len(d32)
     rows = np.zeros((max_det, 7), np.float32)
-    rows[:, :5] = d32
+    rows[:, :5] = dets.astype(np.float32)
     rows[:, 5] = d32[:, 4]
     count = torch.tensor([max_det, max_det], dtype=torch.int32).cuda()
     chip = [[0, 0, 4096, 4096, 0, 0, 1]]

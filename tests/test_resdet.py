@@ -589,5 +589,11 @@ def test_gl_fusion_detector_vs_oracle(mode):
     det = HipGflDetector("mpdet", sd, dtype=mode)
     gc, gr = det.forward_raw(x.cuda())
     err = max(_err(g.cpu(), w) for g, w in zip(gc + gr, wc + wr))
-    print("mpdet + GL-fusion %s: hip-vs-oracle %.2e, oracle fp32-vs-fp64 %.2e" % (mode, err, noise))
-    assert err <= (max(2e-4, 3 * noise) if mode == "f32" else 0.1)
+    scale = max(float(w.abs().max()) for w in wc + wr)
+    abs_err = max(float((g.cpu() - w).abs().max()) for g, w in zip(gc + gr, wc + wr))
+    print("mpdet + GL-fusion %s: hip-vs-oracle %.2e per tensor, %.2e of max |logit| %.2f; oracle fp32-vs-fp64 %.2e"
+          % (mode, err, abs_err / scale, scale, noise))
+    if mode == "f32":
+        assert err <= max(2e-4, 3 * noise)
+    else:
+        assert abs_err <= 0.15 * scale          # the bar of test_detector_f16_vs_oracle_and_graph
