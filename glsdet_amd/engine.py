@@ -467,6 +467,18 @@ class Engine:
                                          _stream_ptr(self.stream)), "focus_pack")
         return out
 
+    def focus_conv(self, img: torch.Tensor, packed, act: str, out: Optional[TView] = None) -> TView:
+        """Focus + its 3x3 conv in one launch (glsdet_focus_conv); packed = pack_conv(..., cin_pad=16)."""
+        assert img.dtype == torch.float32 and img.is_contiguous() and img.device.type == "cuda"
+        n, cin, H, W = img.shape
+        wdev, sdev, bdev, cout, R, S = packed
+        assert (R, S) == (3, 3)
+        if out is None:
+            out = self.tensor(n, H // 2, W // 2, cout)
+        check(self.lib.glsdet_focus_conv(img.data_ptr(), n, cin, H, W, wdev.data_ptr(), sdev.data_ptr(), bdev.data_ptr(),
+                                         ACT[act], C.byref(out.as_c()), _stream_ptr(self.stream)), "focus_conv")
+        return out
+
     def channel_maxmean(self, x: TView, out: Optional[TView] = None) -> TView:
         if out is None:
             out = self.tensor(x.n, x.h, x.w, 8, x.dtype)

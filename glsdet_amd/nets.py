@@ -203,8 +203,15 @@ class NetBuilder:
     def darknet(self, p: str, img: torch.Tensor, homes: Dict[str, Optional[TView]]) -> Dict[str, TView]:
         """CSPDarknet.  homes[name] = view the named output must be written to (or None)."""
         f = {}
-        x = self.e.focus_pack(img)
-        x = self.cba(p + ".stem.conv", x)
+        q = p + ".stem.conv"
+        w0 = self.sd.get(q + ".conv.weight")
+        if w0 is not None and img.shape[1] == 3 and tuple(w0.shape[1:]) == (12, 3, 3) and w0.shape[0] <= 64 and \
+                not os.environ.get("GLSDET_NO_STEM_FUSION"):
+            # Focus + stem conv in one launch: the packed tensor is never written (glsdet_focus_conv)
+            x = self.e.focus_conv(img, self._pack(q, [self._bn_part(q)], 16), "silu")
+            self._rec(q, x, 0, w0.shape[0])
+        else:
+            x = self.cba(q, self.e.focus_pack(img))
         att = lambda i: self.has("%s.lsk%d.proj_1.weight" % (p, i))     # new/darknet_att.py:161-201
         for i, name in enumerate(("dark2", "dark3", "dark4")):
             x = self.cba("%s.%s.0" % (p, name), x, 2)

@@ -140,6 +140,12 @@ int32_t glsdet_conv_cout_pad(int32_t cout);
 int glsdet_focus_pack(const float* img, int32_t n, int32_t cin, int32_t H, int32_t W,
                       const glsdet_view* y, void* stream);
 
+/* Focus AND its 3x3 BaseConv in one launch (drone/models/base/darknet.py:10-21: `self.conv(cat(TL, BL, TR, BR))`): the
+ * fp32 NCHW image is read directly, the packed tensor never exists.  w / scale / bias: as glsdet_conv2d for a 3x3 conv
+ * over 16 input channels (12 real), packed for y's dtype.  y: NHWC view [n, H/2, W/2, <= 64 channels].                */
+int glsdet_focus_conv(const float* img, int32_t n, int32_t cin, int32_t H, int32_t W, const void* w, const float* scale,
+                      const float* bias, int32_t act, const glsdet_view* y, void* stream);
+
 /* max pool k x k, stride 1, pad k/2 (-inf padding)   drone/models/base/darknet.py:29,35 */
 int glsdet_maxpool2d(const glsdet_view* x, const glsdet_view* y, int32_t k, void* stream);
 

@@ -96,3 +96,26 @@ def _kxk_cases(n, seed):
 @pytest.mark.parametrize("case", _kxk_cases(16, 11), ids=lambda c: "n%d_ci%d_co%d_k%d_s%d_%dx%d_%s_r%d_e%d" % c)
 def test_conv2d_random_kxk_problem_halo_family(engines, mode, case):
     _run_case(engines, mode, case, [0, 1, 2, 4, 5, 8, 9, 10, 11])
+
+
+def _s2_cases(n, seed):
+    """3x3 stride-2 problems (the downsampling convs: dark{2..5}.0, bu_conv, ResNet layer{2..4}.0.conv2, FPN extras):
+    many tiles, several channel chunks, odd and even extents, ragged borders -- the de-interleaved-patch ring kernel."""
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(n):
+        cin = int(rng.choice([32, 64, 96, 128, 256]))
+        cout = int(rng.choice([32, 64, 72, 128, 136, 256]))
+        h, w = int(rng.integers(9, 110)), int(rng.integers(17, 130))
+        n_img = int(rng.choice([1, 2, 3]))
+        act = str(rng.choice(["silu", "relu", "none"]))
+        res = int(rng.choice([0, 0, 1, 2]))
+        embed = bool(rng.integers(0, 2))
+        out.append((n_img, cin, cout, 3, 2, h, w, act, res, embed))
+    return out
+
+
+@pytest.mark.parametrize("mode", ["f16", "f32"])
+@pytest.mark.parametrize("case", _s2_cases(14, 23), ids=lambda c: "n%d_ci%d_co%d_k%d_s%d_%dx%d_%s_r%d_e%d" % c)
+def test_conv2d_random_stride2_problem_halo_family(engines, mode, case):
+    _run_case(engines, mode, case, [0, 1, 10, 11, (64 << 16) | 128])

@@ -80,6 +80,33 @@ def test_focus_stem_vs_reference_golden(engines, golden):
     assert float((out.to_nchw(want.shape[1]).cpu() - want).abs().max()) <= 5e-5 * max(1.0, float(want.abs().max()))
 
 
+@pytest.mark.parametrize("mode", ["f32", "f16"])
+@pytest.mark.parametrize("cout,hw", [(16, (32, 40)), (32, (70, 132)), (48, (18, 34)), (64, (64, 96))])
+def test_fused_focus_stem_vs_reference_golden_and_oracle(engines, golden, mode, cout, hw):
+    """glsdet_focus_conv (Focus + its 3x3 BaseConv in one launch, fp32 NCHW image in): the reference's own Focus golden
+    (cout 16) and the oracle on other widths / ragged tile borders; bit-identical to focus_pack + conv in both modes."""
+    from glsdet_amd.arch import _Table
+    from glsdet_amd.nets import NetBuilder
+    from glsdet_amd.synth import synth_input, synth_state_dict
+    eng = engines[mode]
+    if cout == 16:
+        sd, x, want = block_case(golden, "focus")
+    else:
+        t = _Table()
+        t.conv_bn("m.conv", 12, cout, 3)
+        sd = synth_state_dict(t, 4)
+        x = synth_input((2, 3, hw[0], hw[1]), 21)
+        want = O.focus(sd, "m", x if mode == "f32" else x.half().float())
+    b = NetBuilder(eng, sd)
+    fused = eng.focus_conv(x.cuda(), b._pack("m.conv", [b._bn_part("m.conv")], 16), "silu")
+    two = b.cba("m.conv", eng.focus_pack(x.cuda()))
+    torch.cuda.synchronize()
+    got = fused.to_nchw(want.shape[1]).cpu()
+    tol = 5e-5 if mode == "f32" else 4e-3
+    assert float((got - want).abs().max()) <= tol * max(1.0, float(want.abs().max()))
+    assert torch.equal(got, two.to_nchw(want.shape[1]).cpu())
+
+
 MODELS = ["base_tiny_seed0", "base_tiny_seed1", "base_s_seed0", "gl_tiny_seed0", "gl_tiny_seed1", "gl_s_seed0",
           "base_nano_seed0", "base_nano_seed1", "gl_nano_seed0", "gl_nano_seed1"]     # nano = depthwise towers
 
