@@ -10,6 +10,8 @@
 //     flight, also across the epilogue of the previous tile,
 //   * reads every input byte once per cout tile of 128 (one tile for Cout <= 128).
 // Fragment layout / epilogue as in conv.hip.
+#include <stdlib.h>
+
 #include "conv_common.h"
 
 namespace glsdet {
@@ -203,7 +205,13 @@ static int launch_ws(const ConvArgs& a, hipStream_t st) {
   ConvArgs b = a;
   b.n_co_tiles = (a.Cout + CO_T - 1) / CO_T;
   const int n_px_tiles = (a.M + 63) / 64;
-  const int per_cu = lds <= 80 * 1024 ? 2 : 1;
+  // workgroups resident per CU (LDS bound; 160 KiB per CU): each keeps ~3 chunks of 8 KB in flight, and an HBM-bound layer
+  // wants ~50 KB per CU outstanding (6 TB/s x ~2 us / 256 CUs)
+  static const int per_cu_env = getenv("GLSDET_WS_PER_CU") ? atoi(getenv("GLSDET_WS_PER_CU")) : 0;
+  int per_cu = (160 * 1024) / (lds + 1024);
+  if (per_cu > 6) per_cu = 6;
+  if (per_cu < 1) per_cu = 1;
+  if (per_cu_env > 0 && per_cu_env < per_cu) per_cu = per_cu_env;
   int groups = 256 * per_cu / b.n_co_tiles;          // pixel-tile walkers per cout tile
   if (groups > n_px_tiles) groups = n_px_tiles;
   if (groups < 1) groups = 1;

@@ -67,29 +67,46 @@ __global__ __launch_bounds__(256) void focus_stem_kernel(const StemArgs a) {
   const long plane = (long)a.H * a.W;
   const float* ibase = a.img + (long)img * 3 * plane;
 
+  // image loads of one tile: NL float2 per thread (channel, image row, packed column), held in registers so that the
+  // NEXT tile's loads are in flight while the current tile is multiplied and stored
+  constexpr int NQ = 3 * (2 * PH) * PW, NL = (NQ + 255) / 256;
+  float2 pre[NL];
+  auto issue_loads = [&](int tx0) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      const int q = tid + i * 256;
+      const int px = q % PW, r = q / PW;
+      const int iy_l = r % (2 * PH), c = r / (2 * PH);
+      const int Y = ty0 - 1 + (iy_l >> 1), X = tx0 - 1 + px;   // packed coordinates; outside the packed image: zero padding
+      pre[i] = float2{0.f, 0.f};
+      if (q < NQ && (unsigned)Y < (unsigned)a.Ho && (unsigned)X < (unsigned)a.Wo)
+        pre[i] = *reinterpret_cast<const float2*>(ibase + c * plane + (long)(2 * Y + (iy_l & 1)) * a.W + 2 * X);
+    }
+  };
+  issue_loads(sx * STRIP * TW);
   for (int s = 0; s < STRIP; ++s) {
     const int tx = sx * STRIP + s;
     if (tx >= a.tiles_x) break;                     // uniform
     const int tx0 = tx * TW;
     __syncthreads();                                // the previous tile's store phase is done with sP
-    // ---- packed patch: one float2 per (channel, image row, packed column) = the dx = 0 | 1 pair of one packed pixel
-    for (int q = tid; q < 3 * (2 * PH) * PW; q += 256) {
-      const int px = q % PW;
-      const int r = q / PW;
-      const int iy_l = r % (2 * PH), c = r / (2 * PH);
-      const int py = iy_l >> 1, dy = iy_l & 1;
-      const int Y = ty0 - 1 + py, X = tx0 - 1 + px;   // packed coordinates; outside the packed image: zero padding
-      float2 v = {0.f, 0.f};
-      if ((unsigned)Y < (unsigned)a.Ho && (unsigned)X < (unsigned)a.Wo)
-        v = *reinterpret_cast<const float2*>(ibase + c * plane + (long)(2 * Y + dy) * a.W + 2 * X);
-      T* dst = reinterpret_cast<T*>(sP + (py * PW + px) * PRS);
-      dst[dy * 3 + c] = (T)v.x;                     // TL (dy 0) / BL (dy 1): channels 0..2 / 3..5
-      dst[6 + dy * 3 + c] = (T)v.y;                 // TR / BR: channels 6..8 / 9..11
+    // ---- packed patch: one float2 = the dx = 0 | 1 pair of one packed pixel
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      const int q = tid + i * 256;
+      if (q < NQ) {
+        const int px = q % PW, r = q / PW;
+        const int iy_l = r % (2 * PH), c = r / (2 * PH);
+        const int py = iy_l >> 1, dy = iy_l & 1;
+        T* dst = reinterpret_cast<T*>(sP + (py * PW + px) * PRS);
+        dst[dy * 3 + c] = (T)pre[i].x;              // TL (dy 0) / BL (dy 1): channels 0..2 / 3..5
+        dst[6 + dy * 3 + c] = (T)pre[i].y;          // TR / BR: channels 6..8 / 9..11
+      }
     }
     for (int q = tid; q < PH * PW; q += 256) {      // channels 12..15
       T* dst = reinterpret_cast<T*>(sP + q * PRS) + 12;
       dst[0] = dst[1] = dst[2] = dst[3] = (T)0.f;
     }
+    if (s + 1 < STRIP && tx + 1 < a.tiles_x) issue_loads(tx0 + TW);
     __syncthreads();
     // ---- nine taps: wave w owns pixel block w (32 pixels = two tile rows), all cout rows
     f32x16 acc[TM];

@@ -274,7 +274,20 @@ class Engine:
             if key not in self._tuned:
                 best, us = C.c_int32(0), C.c_float(0)
                 rc = self.lib.glsdet_conv2d_chain_tune(C.byref(d), C.byref(c), st, C.byref(best), C.byref(us))
-                self._tuned[key] = best.value if rc == 0 else -1
+                hint = best.value if rc == 0 else -1
+                if hint >= 0:
+                    # fused only where it beats the two launches it replaces (each tuned on its own): the chained product
+                    # runs in the tail of the producing workgroups, which costs more than a launch on some shapes
+                    b1, u1, b2h, u2 = C.c_int32(0), C.c_float(0), C.c_int32(0), C.c_float(0)
+                    d2 = ConvDesc()
+                    d2.x, d2.y, d2.res = out.channels(c0, c0 + cin2).as_c(), out2.as_c(), View()
+                    d2.w, d2.scale, d2.bias = w2.data_ptr(), s2.data_ptr(), b2.data_ptr()
+                    d2.R, d2.S, d2.stride, d2.pad, d2.act, d2.tile_hint = 1, 1, 1, 0, ACT[act2], 0
+                    if self.lib.glsdet_conv2d_tune(C.byref(d), st, C.byref(b1), C.byref(u1)) == 0 and \
+                            self.lib.glsdet_conv2d_tune(C.byref(d2), st, C.byref(b2h), C.byref(u2)) == 0 and \
+                            us.value > 0.97 * (u1.value + u2.value):
+                        hint = -1
+                self._tuned[key] = hint
                 self._tune_dirty = True
             if self._tuned[key] < 0:
                 return False

@@ -309,6 +309,32 @@ class NetBuilder:
             return self.plain(p + ".channel_conv", Z, out=out)
         return self.cba(p + ".channel_conv", Z, out=out)
 
+    def patch_conv_nonlocal_44(self, p: str, x: TView, out: Optional[TView] = None) -> TView:
+        """Patch_Conv_NonLocal_44 (new/Non_local_family.py:359-421): a stride-2 Patch_Conv_NonLocal per quadrant, each
+        writing its window of ONE buffer whose left / right / top / bottom halves are the reference's l / r / t / b
+        stitches; a 1x1 BaseConv per half; channel_conv over [lr | tb]."""
+        inner = lambda v: (v // 2 + 2 - 3) // 2 + 1 + ((v - v // 2) + 2 - 3) // 2 + 1      # patch_conv(stride 2) output extent
+        hh, hw = x.h // 2, x.w // 2
+        ht, hb, wl, wr = inner(hh), inner(x.h - hh), inner(hw), inner(x.w - hw)
+        cq = self.sd[p + ".feat_patchconv_l.conv.weight"].shape[1]
+        m = self.conv_out_channels(p + ".feat_patchconv_l")
+        Q = self.e.tensor(x.n, ht + hb, wl + wr, cq)
+        for nm, xin, dst in (("lt", x.window(0, hh, 0, hw), Q.window(0, ht, 0, wl)),
+                             ("lb", x.window(hh, x.h, 0, hw), Q.window(ht, ht + hb, 0, wl)),
+                             ("rt", x.window(0, hh, hw, x.w), Q.window(0, ht, wl, wl + wr)),
+                             ("rb", x.window(hh, x.h, hw, x.w), Q.window(ht, ht + hb, wl, wl + wr))):
+            self.patch_conv("%s.patchconv_%s_nonlocal" % (p, nm), xin, 2, True, out=dst)
+        H, W = ht + hb, wl + wr
+        Z = self.e.tensor(x.n, H, W, 2 * m)
+        lr, tb = Z.channels(0, m), Z.channels(m, 2 * m)
+        self.cba_group([p + ".feat_patchconv_l", p + ".feat_patchconv_r"], [Q.window(0, H, 0, wl), Q.window(0, H, wl, W)],
+                       outs=[lr.window(0, H, 0, wl), lr.window(0, H, wl, W)])
+        self.cba_group([p + ".feat_patchconv_t", p + ".feat_patchconv_b"], [Q.window(0, ht, 0, W), Q.window(ht, H, 0, W)],
+                       outs=[tb.window(0, ht, 0, W), tb.window(ht, H, 0, W)])
+        if self.has(p + ".channel_conv.weight"):
+            return self.plain(p + ".channel_conv", Z, out=out)
+        return self.cba(p + ".channel_conv", Z, out=out)
+
     def patch_conv_nonlocal_new(self, p: str, x: TView, out: Optional[TView] = None) -> TView:
         """Patch_Conv_NonLocal_new (new/Non_local_family.py:208-252).  The four quadrant
         non-local blocks run IN PLACE on windows of x (x is consumed), so the re-stitch is free."""

@@ -277,6 +277,23 @@ def patch_conv_nonlocal_new(sd: SD, p: str, x: Tensor) -> Tensor:
     return base_conv(sd, p + ".channel_conv", both)
 
 
+def patch_conv_nonlocal_44(sd: SD, p: str, x: Tensor) -> Tensor:
+    """Patch_Conv_NonLocal_44 (drone/models/new/Non_local_family.py:359-421): a Patch_Conv_NonLocal (stride 2, with its own
+    2x2 split) on each quadrant, the four results re-stitched into halves l/r/t/b, a 1x1 BaseConv on each, lr (along W)
+    and tb (along H) concatenated on channels, channel_conv."""
+    lt, lb, rt, rb = _quadrants(x)
+    q = {name: patch_conv(sd, "{}.patchconv_{}_nonlocal".format(p, name), t, 2, True)
+         for name, t in (("lt", lt), ("lb", lb), ("rt", rt), ("rb", rb))}
+    l = base_conv(sd, p + ".feat_patchconv_l", torch.cat((q["lt"], q["lb"]), 2))
+    r = base_conv(sd, p + ".feat_patchconv_r", torch.cat((q["rt"], q["rb"]), 2))
+    t = base_conv(sd, p + ".feat_patchconv_t", torch.cat((q["lt"], q["rt"]), 3))
+    b = base_conv(sd, p + ".feat_patchconv_b", torch.cat((q["lb"], q["rb"]), 3))
+    both = torch.cat((torch.cat((l, r), 3), torch.cat((t, b), 2)), 1)
+    if p + ".channel_conv.weight" in sd:
+        return plain_conv(sd, p + ".channel_conv", both)
+    return base_conv(sd, p + ".channel_conv", both)
+
+
 def attention(sd: SD, p: str, x: Tensor) -> Tensor:
     """Attention (Non_local_family.py:254-272): proj_1 1x1 -> exact GELU -> quadrant non-local
     gating unit -> proj_2 1x1 -> + shortcut."""

@@ -68,6 +68,22 @@ def calibrate_bn(net, x, seed):
             if k.endswith("running_mean") or k.endswith("running_var")}
 
 
+def make_block(out):
+    """-> block(tag, ctor, in_shape, seed=0, calibrate=False): run a reference module on seeded data into `out`."""
+    def block(tag, ctor, in_shape, seed=0, calibrate=False):
+        m = ctor()
+        shapes = fill(m, seed)
+        x = synth_input(in_shape, seed + 100)
+        if calibrate:
+            for k, v in calibrate_bn(m, x, seed).items():
+                out["block/%s/bn/%s" % (tag, k)] = v
+        y = m(x)
+        out["block/%s/y" % tag] = y.numpy()
+        out["block/%s/meta" % tag] = np.frombuffer(json.dumps(
+            {"shapes": shapes, "in_shape": list(in_shape), "seed": seed}).encode(), np.uint8)
+    return block
+
+
 def attention_cases(block):
     """SURVEY section 8a row A6': the other GL attention variants the tree holds
     (drone/models/new/Non_local_family.py, new/darknet_att.py)."""
@@ -79,6 +95,9 @@ def attention_cases(block):
     block("att_attention_c32", lambda: Attention(32), (2, 32, 20, 24))
     block("att_attention_c48_odd", lambda: Attention(48), (1, 48, 17, 23))
     block("att_spatial_attention", lambda: SpatialAttention(7), (2, 32, 20, 24))
+    from models.new.Non_local_family import Patch_Conv_NonLocal_44
+    block("att_pcnl_44", lambda: Patch_Conv_NonLocal_44(32, 64, channel_scale=0.5), (2, 32, 40, 48))
+    block("att_pcnl_44_odd", lambda: Patch_Conv_NonLocal_44(16, 32, channel_scale=0.5), (1, 16, 36, 44))
 
     class Outs(torch.nn.Module):            # dict -> tuple so that block() can store it
         def __init__(self):
@@ -311,6 +330,12 @@ def main():
         merge_cases()
         eval_cases()
         return
+    if "--attention-only" in sys.argv:
+        att = {}
+        attention_cases(make_block(att))
+        np.savez_compressed(os.path.join(HERE, "attention_golden.npz"), **att)
+        print("attention:", len(att), "arrays,", os.path.getsize(os.path.join(HERE, "attention_golden.npz")), "bytes")
+        return
     merge_cases()
     eval_cases()
     ufp_cases()
@@ -336,17 +361,7 @@ def main():
     out = {}
 
     # ------------------------------------------------------------------ blocks
-    def block(tag, ctor, in_shape, seed=0, calibrate=False):
-        m = ctor()
-        shapes = fill(m, seed)
-        x = synth_input(in_shape, seed + 100)
-        if calibrate:
-            for k, v in calibrate_bn(m, x, seed).items():
-                out["block/%s/bn/%s" % (tag, k)] = v
-        y = m(x)
-        out["block/%s/y" % tag] = y.numpy()
-        out["block/%s/meta" % tag] = np.frombuffer(json.dumps(
-            {"shapes": shapes, "in_shape": list(in_shape), "seed": seed}).encode(), np.uint8)
+    block = make_block(out)
 
     for k in (1, 3):
         for s in (1, 2):

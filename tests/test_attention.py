@@ -25,6 +25,8 @@ ORACLE = {
     "att_attention_c32": lambda sd, x: O.attention(sd, "m", x),
     "att_attention_c48_odd": lambda sd, x: O.attention(sd, "m", x),
     "att_spatial_attention": lambda sd, x: O.spatial_attention(sd, "m", x),
+    "att_pcnl_44": lambda sd, x: O.patch_conv_nonlocal_44(sd, "m", x),
+    "att_pcnl_44_odd": lambda sd, x: O.patch_conv_nonlocal_44(sd, "m", x),
     "att_darknet_tiny": _dark,
 }
 
@@ -63,6 +65,8 @@ HIP = {
     "att_attention_c32": lambda b, x: b.attention("m", x),
     "att_attention_c48_odd": lambda b, x: b.attention("m", x),
     "att_spatial_attention": lambda b, x: b.spatial_attention("m", x),
+    "att_pcnl_44": lambda b, x: b.patch_conv_nonlocal_44("m", x),
+    "att_pcnl_44_odd": lambda b, x: b.patch_conv_nonlocal_44("m", x),
 }
 
 
