@@ -543,7 +543,7 @@ int conv_halo_try(const ConvArgs& a, int xdt, int ydt, int hint, OpRecord* op) {
     if (hint == 11 && a.cout_pad <= 64) return 1;
     const long tiles = (long)((a.Ho + 7) / 8) * ((a.Wo + 15) / 16);
     if (hint == 0 && (double)tiles * 128.0 / ((double)a.Ho * a.Wo) > 1.30) return 1;
-    const int co_t = (a.cout_pad <= 64 || hint == 10) ? 64 : 128;
+    const int co_t = (a.cout_pad <= 64 || hint != 11) ? 64 : 128;      // measured: 64-row tiles win unless the tuner says otherwise
     if (a.w2 && a.c2_0 / co_t != (a.c2_0 + a.cin2 - 1) / co_t) return 1;
     char nm[96];
     snprintf(nm, sizeof nm, "conv_halo_ring_k64_s2<%s,%dx8x16> 3x3 s2 cin%d cout%d%s", xdt ? "f32" : "f16", co_t, a.Cin, a.Cout, a.w2 ? " +1x1" : "");
