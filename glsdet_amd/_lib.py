@@ -62,6 +62,7 @@ _SIGS = {
     "glsdet_focus_conv": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                                     C.c_int32, C.POINTER(View), C.c_void_p]),
     "glsdet_channel_maxmean": (C.c_int, [C.POINTER(View), C.POINTER(View), C.c_void_p]),
+    "glsdet_spp_pools": (C.c_int, [C.POINTER(View), C.POINTER(View), C.POINTER(View), C.POINTER(View), C.c_void_p]),
     "glsdet_maxpool2d": (C.c_int, [C.POINTER(View), C.POINTER(View), C.c_int32, C.c_void_p]),
     "glsdet_resample_copy": (C.c_int, [C.POINTER(View), C.POINTER(View), C.c_int32, C.c_void_p]),
     "glsdet_nonlocal": (C.c_int, [C.POINTER(View), C.POINTER(View), C.c_int32, C.c_void_p, C.c_void_p,

@@ -94,6 +94,71 @@ __global__ __launch_bounds__(256) void maxpool_kernel(const unsigned char* x, lo
   }
 }
 
+// ---------------------------------------------------------------- SPP: the 5 / 9 / 13 max pools in one launch
+// SPPBottleneck (drone/models/base/darknet.py:29,35): cat(x, pool5(x), pool9(x), pool13(x)).  A stride-1 max pool of 9 is
+// pool5 of pool5, 13 is pool5 of pool9 (exact, -inf padding each time): a workgroup takes an 8 x 16 output tile of one
+// 16-byte channel chunk, stages the (8+12) x (16+12) input patch in LDS and runs the three pools as separable row / column
+// passes on shrinking regions, writing each pool's centre 8 x 16 to its output.  One read of x instead of three chained
+// launches each re-reading the previous pool through L2.
+template <typename T>
+__global__ __launch_bounds__(256) void spp_pools_kernel(const unsigned char* x, long xsn, long xsh, long xsw, unsigned char* y5,
+                                                        unsigned char* y9, unsigned char* y13, long ysn, long ysh, long ysw, int H,
+                                                        int W, int cchunks, int tiles_x, int tiles_y) {
+  typedef typename Vec16<T>::type V;
+  constexpr int VN = Vec16<T>::N;
+  constexpr int TH = 8, TW = 16, R = 6, PH = TH + 2 * R, PW = TW + 2 * R;
+  __shared__ V sA[PH * PW], sB[PH * PW];
+  int t = blockIdx.x;
+  const int cc = t % cchunks;
+  t /= cchunks;
+  const int tx = t % tiles_x;
+  t /= tiles_x;
+  const int ty = t % tiles_y, b = t / tiles_y;
+  const int y0 = ty * TH - R, x0 = tx * TW - R;            // image coordinates of patch (0, 0)
+  V ninf;
+#pragma unroll
+  for (int e = 0; e < VN; ++e) ninf[e] = (T)(-INFINITY);
+  auto vmax = [](V a, V c) { V r; for (int e = 0; e < VN; ++e) r[e] = a[e] > c[e] ? a[e] : c[e]; return r; };
+  for (int q = threadIdx.x; q < PH * PW; q += 256) {
+    const int py = q / PW, px = q - py * PW;
+    const int h = y0 + py, w = x0 + px;
+    V v = ninf;
+    if ((unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W)
+      v = *reinterpret_cast<const V*>(x + (b * xsn + h * xsh + w * xsw + cc * VN) * (long)sizeof(T));
+    sA[q] = v;
+  }
+  __syncthreads();
+  unsigned char* outs[3] = {y5, y9, y13};
+#pragma unroll
+  for (int stage = 0; stage < 3; ++stage) {
+    const int m = 2 * (stage + 1);                          // the valid region shrinks by 2 on every side per pool
+    // rows: sB[py][px] = max over px-2..px+2 of sA, for py in [m-2, PH-m+2), px in [m, PW-m)
+    for (int q = threadIdx.x; q < PH * PW; q += 256) {
+      const int py = q / PW, px = q - py * PW;
+      if (py >= m - 2 && py < PH - m + 2 && px >= m && px < PW - m) {
+        V v = sA[q - 2];
+        v = vmax(v, sA[q - 1]); v = vmax(v, sA[q]); v = vmax(v, sA[q + 1]); v = vmax(v, sA[q + 2]);
+        sB[q] = v;
+      }
+    }
+    __syncthreads();
+    // columns, and -inf outside the image (the next pool pads with -inf again)
+    for (int q = threadIdx.x; q < PH * PW; q += 256) {
+      const int py = q / PW, px = q - py * PW;
+      if (py >= m && py < PH - m && px >= m && px < PW - m) {
+        V v = sB[q - 2 * PW];
+        v = vmax(v, sB[q - PW]); v = vmax(v, sB[q]); v = vmax(v, sB[q + PW]); v = vmax(v, sB[q + 2 * PW]);
+        const int h = y0 + py, w = x0 + px;
+        const bool inside = (unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W;
+        sA[q] = inside ? v : ninf;
+        if (inside && py >= R && py < R + TH && px >= R && px < R + TW)
+          *reinterpret_cast<V*>(outs[stage] + (b * ysn + h * ysh + w * ysw + cc * VN) * (long)sizeof(T)) = v;
+      }
+    }
+    __syncthreads();
+  }
+}
+
 // ---------------------------------------------------------------- channel max / mean
 // SpatialAttention (Non_local_family.py:429-432).  One wave per pixel: lanes stride the
 // channel chunks (16 B each), max and sum reduced across the wave with shuffles.
@@ -407,6 +472,38 @@ extern "C" int glsdet_maxpool2d(const glsdet_view* x, const glsdet_view* y, int3
       hipLaunchKernelGGL(maxpool_kernel<f16>, dim3(g), dim3(256), 0, st, (const unsigned char*)a.base, a.sn, a.sh, a.sw, (unsigned char*)b.base, b.sn, b.sh, b.sw, a.n, a.h, a.w, a.c, k);
     else
       hipLaunchKernelGGL(maxpool_kernel<float>, dim3(g), dim3(256), 0, st, (const unsigned char*)a.base, a.sn, a.sh, a.sw, (unsigned char*)b.base, b.sn, b.sh, b.sw, a.n, a.h, a.w, a.c, k);
+    GLS_HIP(hipGetLastError());
+    return 0;
+  };
+  return submit(std::move(op), stream);
+}
+
+extern "C" int glsdet_spp_pools(const glsdet_view* x, const glsdet_view* y5, const glsdet_view* y9, const glsdet_view* y13, void* stream) {
+  if (!x || !y5 || !y9 || !y13) GLS_FAIL(GLSDET_E_ARG, "spp_pools: null argument");
+  int rc;
+  if ((rc = check_view(*x, "spp_pools.x"))) return rc;
+  const glsdet_view* ys[3] = {y5, y9, y13};
+  for (int i = 0; i < 3; ++i) {
+    if ((rc = check_view(*ys[i], "spp_pools.y"))) return rc;
+    if (!same_extent(*x, *ys[i]) || ys[i]->dtype != x->dtype || ys[i]->sn != y5->sn || ys[i]->sh != y5->sh || ys[i]->sw != y5->sw)
+      GLS_FAIL(GLSDET_E_ARG, "spp_pools: outputs must have x's extent and dtype and share one set of strides");
+  }
+  if (x->c % 8) GLS_FAIL(GLSDET_E_ARG, "spp_pools: channels must be a multiple of 8");
+  const glsdet_view a = *x, b5 = *y5, b9 = *y9, b13 = *y13;
+  OpRecord op;
+  op.kind = 2;
+  op.flops = 0;
+  op.bytes = 4.0 * a.n * a.h * a.w * a.c * dtype_size(a.dtype);
+  op.name = "spp_pools(5,9,13)";
+  op.launch = [=](hipStream_t st) -> int {
+    const int vn = 16 / dtype_size(a.dtype);
+    const int tiles_x = (a.w + 15) / 16, tiles_y = (a.h + 7) / 8, cch = a.c / vn;
+    const long g = (long)a.n * tiles_y * tiles_x * cch;
+    if (g <= 0 || g > 0x7fffffffL) GLS_FAIL(GLSDET_E_ARG, "spp_pools: grid out of range");
+    if (a.dtype == GLSDET_F16)
+      hipLaunchKernelGGL(spp_pools_kernel<f16>, dim3((unsigned)g), dim3(256), 0, st, (const unsigned char*)a.base, a.sn, a.sh, a.sw, (unsigned char*)b5.base, (unsigned char*)b9.base, (unsigned char*)b13.base, b5.sn, b5.sh, b5.sw, a.h, a.w, cch, tiles_x, tiles_y);
+    else
+      hipLaunchKernelGGL(spp_pools_kernel<float>, dim3((unsigned)g), dim3(256), 0, st, (const unsigned char*)a.base, a.sn, a.sh, a.sw, (unsigned char*)b5.base, (unsigned char*)b9.base, (unsigned char*)b13.base, b5.sn, b5.sh, b5.sw, a.h, a.w, cch, tiles_x, tiles_y);
     GLS_HIP(hipGetLastError());
     return 0;
   };

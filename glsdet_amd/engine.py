@@ -505,6 +505,10 @@ class Engine:
         check(self.lib.glsdet_maxpool2d(C.byref(x.as_c()), C.byref(out.as_c()), k, _stream_ptr(self.stream)), "maxpool2d")
         return out
 
+    def spp_pools(self, x: TView, y5: TView, y9: TView, y13: TView):
+        check(self.lib.glsdet_spp_pools(C.byref(x.as_c()), C.byref(y5.as_c()), C.byref(y9.as_c()), C.byref(y13.as_c()),
+                                        _stream_ptr(self.stream)), "spp_pools")
+
     def resample(self, x: TView, factor: int, out: Optional[TView] = None) -> TView:
         if out is None:
             out = self.tensor(x.n, x.h * factor, x.w * factor, x.c, x.dtype)

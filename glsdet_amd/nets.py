@@ -196,8 +196,11 @@ class NetBuilder:
         hid = self.conv_out_channels(p + ".conv1")
         cat = self.e.tensor(x.n, x.h, x.w, 4 * hid)
         self.cba(p + ".conv1", x, out=cat.channels(0, hid))
-        for i in range(3):      # 5 -> 9 -> 13 by chaining 5x5 pools
-            self.e.maxpool(cat.channels(i * hid, (i + 1) * hid), 5, out=cat.channels((i + 1) * hid, (i + 2) * hid))
+        if os.environ.get("GLSDET_NO_SPP_FUSION"):
+            for i in range(3):      # 5 -> 9 -> 13 by chaining 5x5 pools
+                self.e.maxpool(cat.channels(i * hid, (i + 1) * hid), 5, out=cat.channels((i + 1) * hid, (i + 2) * hid))
+        else:                       # the same three pools in one launch (glsdet_spp_pools)
+            self.e.spp_pools(cat.channels(0, hid), cat.channels(hid, 2 * hid), cat.channels(2 * hid, 3 * hid), cat.channels(3 * hid, 4 * hid))
         return self.cba(p + ".conv2", cat, out=out)
 
     def darknet(self, p: str, img: torch.Tensor, homes: Dict[str, Optional[TView]]) -> Dict[str, TView]:

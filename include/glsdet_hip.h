@@ -149,6 +149,11 @@ int glsdet_focus_conv(const float* img, int32_t n, int32_t cin, int32_t H, int32
 /* max pool k x k, stride 1, pad k/2 (-inf padding)   drone/models/base/darknet.py:29,35 */
 int glsdet_maxpool2d(const glsdet_view* x, const glsdet_view* y, int32_t k, void* stream);
 
+/* The three pools of SPPBottleneck (darknet.py:29,35: kernel sizes 5, 9, 13, stride 1, pad k/2) in one launch: x is read once,
+ * pool9 = pool5(pool5), pool13 = pool5(pool9) are formed in LDS.  y5 / y9 / y13: x's extent and dtype, one common set of
+ * strides (the channel slices of the concat buffer the SPP conv2 reads).                                                */
+int glsdet_spp_pools(const glsdet_view* x, const glsdet_view* y5, const glsdet_view* y9, const glsdet_view* y13, void* stream);
+
 /* SpatialAttention front half (drone/models/new/Non_local_family.py:429-432): per pixel the max
  * and the mean over channels.  y: view [n,h,w,8] of x.dtype, channel 0 = max, 1 = mean, 2..7 = 0
  * (the 7x7 2->1 conv + sigmoid that follows is a glsdet_conv2d with GLSDET_ACT_SIGMOID).     */

@@ -102,6 +102,14 @@ def test_the_scripts_call_sequence_through_the_shim(shim_path, tmp_path):
         with torch.no_grad():
             return model(return_loss=False, rescale=True, **data)[0]
 
+    def set_thr(model, img, keep):
+        """random-init heads fire everywhere: raise test_cfg.score_thr so that ~keep (position, class) pairs pass"""
+        data = Compose(model.cfg.data.test.pipeline[1:])(dict(img=img))
+        cls, _ = model._detector().forward_raw(data["img"][0][None])
+        p = torch.sigmoid(torch.cat([c.flatten() for c in cls]))
+        model.bbox_head.test_cfg["score_thr"] = float(torch.topk(p, keep).values[-1])
+        return model.bbox_head.test_cfg["score_thr"]
+    t1 = set_thr(coarse, mmcv.imread(img_path), 60)
     first = infer(coarse, mmcv.imread(img_path))
     assert len(first) == 10 and all(r.shape[1] == 5 for r in first)
     boxes = np.concatenate(first)
@@ -116,13 +124,14 @@ def test_the_scripts_call_sequence_through_the_shim(shim_path, tmp_path):
         if cw == 0 or ch == 0:
             continue
         canvas[ny:ny + ch * s, nx:nx + cw * s, :] = cv2.resize(img_data[y1:y1 + ch, x1:x1 + cw, :], (cw * s, ch * s))
+    t2 = set_thr(fine, canvas, 400)
     second = infer(fine, canvas)
     assert len(second) == 10
     # the same frame through glsdet_amd's own two-stage driver: same mosaic, same fine detections
     from glsdet_amd.ufp import UfpSecondStage, two_stage_detect
     _, info = two_stage_detect(coarse._detector(), fine._detector(), img_data, UfpSecondStage(),
-                               dict(score_thr=0.05, iou_thr=0.6, nms_pre=1000, max_per_img=100),
-                               dict(score_thr=0.05, iou_thr=0.6, nms_pre=1000, max_per_img=500))
+                               dict(score_thr=t1, iou_thr=0.6, nms_pre=1000, max_per_img=100),
+                               dict(score_thr=t2, iou_thr=0.6, nms_pre=1000, max_per_img=500))
     assert np.array_equal(info["canvas"].cpu().numpy(), canvas.astype(np.float32))
     # COCO hand-off (:326-338)
     res = [dict(image_id=0, category_id=c, score=float(r[4]), bbox=[int(r[0]), int(r[1]), int(r[2]) - int(r[0]), int(r[3]) - int(r[1])])

@@ -351,3 +351,24 @@ def test_nonlocal_multi_unequal_sets(engines, mode):
     b.nonlocal_blocks(names, [xv.window(h0, h1, w0, w1) for (h0, h1, w0, w1) in wins])
     torch.cuda.synchronize()
     _cmp(xv.to_nchw(), ref, 1e-4 if mode == "f32" else 2e-2, "nonlocal multi")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["f32", "f16"])
+@pytest.mark.parametrize("c,hw", [(32, (20, 24)), (256, (25, 42)), (8, (7, 50)), (64, (33, 17))])
+def test_spp_pools_equal_three_max_pools(engines, mode, c, hw):
+    """glsdet_spp_pools (5 / 9 / 13 in one launch, pool9 = pool5 o pool5, pool13 = pool5 o pool9 in LDS) vs
+    F.max_pool2d(k, 1, k // 2) of darknet.py:29,35 and vs the chained single-pool launches: exact."""
+    eng = engines[mode]
+    x = torch.randn(2, c, hw[0], hw[1], generator=torch.Generator().manual_seed(c + hw[0]))
+    if mode == "f16":
+        x = x.half().float()
+    cat = eng.tensor(2, hw[0], hw[1], 4 * c)
+    xv = _to_view(eng, x)
+    eng.resample(xv, 1, out=cat.channels(0, c))
+    eng.spp_pools(cat.channels(0, c), cat.channels(c, 2 * c), cat.channels(2 * c, 3 * c), cat.channels(3 * c, 4 * c))
+    torch.cuda.synchronize()
+    got = cat.to_nchw().cpu()
+    for i, k in enumerate((5, 9, 13)):
+        want = F.max_pool2d(x, k, 1, k // 2)
+        assert torch.equal(got[:, (i + 1) * c:(i + 2) * c], want), k
