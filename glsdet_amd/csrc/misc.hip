@@ -250,22 +250,49 @@ struct NlSet {
 struct NlArgs {
   NlSet s[GLS_NL_SETS];
   int n, nimg, ci, cx, kc;
+  // data-dependent quadrants (Patch_Conv_NonLocal_adapt_new): split = device int32 {row split, column split of the top
+  // part, of the bottom part} written by glsdet_attn_split; every set's views then span the FULL FH x FW map and the
+  // kernels cut their own window (sets in the order lt, lb, rt, rb).  nullptr: the static windows of the views.
+  const int* split;
+  int FH, FW;
 };
+struct NlWin { int H, W, nsplit, jchunk; long xo, to, oo; float invN; };
+__device__ __forceinline__ NlWin nl_window(const NlArgs& a, int q) {
+  const NlSet& S = a.s[q];
+  NlWin w = {S.H, S.W, S.nsplit, S.jchunk, 0, 0, 0, S.invN};
+  if (a.split) {
+    const int cx = a.split[0], cyl = a.split[1], cyr = a.split[2];
+    const bool bottom = q & 1, right = q >> 1;
+    const int c = bottom ? cyr : cyl;
+    const int r0 = bottom ? cx : 0, c0 = right ? c : 0;
+    w.H = bottom ? a.FH - cx : cx;
+    w.W = right ? a.FW - c : c;
+    w.xo = r0 * S.xsh + c0 * S.xsw;
+    w.to = r0 * S.tsh + c0 * S.tsw;
+    w.oo = r0 * S.osh + c0 * S.osw;
+    const int N = w.H * w.W;
+    w.nsplit = 8;
+    w.jchunk = (((N + 7) / 8) + 63) / 64 * 64;
+    w.invN = 1.0f / (float)N;
+  }
+  return w;
+}
 
 template <typename T>
 __global__ __launch_bounds__(256) void nl_gram_kernel(const NlArgs a) {
   __shared__ float ph[64][17], gg[64][17];
   const int q = blockIdx.z >> 3, z = blockIdx.z & 7;
   const NlSet& S = a.s[q];
-  if (z >= S.nsplit) return;
+  const NlWin wn = nl_window(a, q);
+  if (z >= wn.nsplit) return;
   const int ci = a.ci;
   const int nb = (ci + 15) / 16;
   const int c1_0 = (blockIdx.x / nb) * 16, c2_0 = (blockIdx.x % nb) * 16;
   const int b = blockIdx.y;
   const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
-  const int W = S.W, N = S.H * W;
-  const int jbeg = z * S.jchunk, jend = min(N, jbeg + S.jchunk);
-  const T* base = reinterpret_cast<const T*>(S.tpg) + b * S.tsn;
+  const int W = wn.W, N = wn.H * W;
+  const int jbeg = z * wn.jchunk, jend = min(N, jbeg + wn.jchunk);
+  const T* base = reinterpret_cast<const T*>(S.tpg) + b * S.tsn + wn.to;
   float acc = 0.f;
   for (int j0 = jbeg; j0 < jend; j0 += 64) {
 #pragma unroll
@@ -306,8 +333,9 @@ __global__ __launch_bounds__(256) void nl_fold_kernel(const NlArgs a) {
   const float* __restrict__ Gp = S.gram;
   const float* __restrict__ wout = S.wout;
   float* P = S.P;
-  const int nsplit = S.nsplit, nimg = a.nimg, ci = a.ci, cx = a.cx, kc = a.kc;
-  const float invN = S.invN;
+  const NlWin wn = nl_window(a, q);
+  const int nsplit = wn.nsplit, nimg = a.nimg, ci = a.ci, cx = a.cx, kc = a.kc;
+  const float invN = wn.invN;
   const int co0 = blockIdx.y * GLS_FOLD_CO, c1_0 = blockIdx.z * 64, ld = kc + 1;
   const long slice = (long)nimg * ci * ci;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -368,8 +396,9 @@ __global__ __launch_bounds__(256) void nl_apply_kernel(const NlArgs a) {
              osw = S.osw;
   const float* __restrict__ P = S.P;
   const float* __restrict__ bout = S.bout;
-  const int W = S.W, ci = a.ci, cx = a.cx, kc = a.kc;
-  const int N = S.H * W;
+  const NlWin wn = nl_window(a, q);
+  const int W = wn.W, ci = a.ci, cx = a.cx, kc = a.kc;
+  const int N = wn.H * W;
   const int j0 = blockIdx.x * 64, co0 = blockIdx.z * GLS_APPLY_CO;
   if (j0 >= N) return;            // block-uniform: this set is smaller than the largest one
   const int ld = kc + 1;
@@ -383,7 +412,7 @@ __global__ __launch_bounds__(256) void nl_apply_kernel(const NlArgs a) {
       const int r = idx / kn, c = idx - r * kn;
       const int jr = j0 + r;
       float v = 0.f;
-      if (jr < N) v = (float)(reinterpret_cast<const T*>(tpg) + b * tsn + (jr / W) * tsh + (jr % W) * tsw)[c0 + c];
+      if (jr < N) v = (float)(reinterpret_cast<const T*>(tpg) + b * tsn + wn.to + (jr / W) * tsh + (jr % W) * tsw)[c0 + c];
       th[r * ld + c] = v;
     }
     for (int idx = threadIdx.x; idx < GLS_APPLY_CO * kn; idx += 256) {
@@ -402,8 +431,8 @@ __global__ __launch_bounds__(256) void nl_apply_kernel(const NlArgs a) {
     __syncthreads();
   }
   if (j >= N) return;
-  const long poff_x = b * xsn + (j / W) * xsh + (j % W) * xsw;
-  const long poff_o = b * osn + (j / W) * osh + (j % W) * osw;
+  const long poff_x = b * xsn + wn.xo + (j / W) * xsh + (j % W) * xsw;
+  const long poff_o = b * osn + wn.oo + (j / W) * osh + (j % W) * osw;
 #pragma unroll
   for (int q = 0; q < 8; ++q) {
     const int co = co0 + grp * 8 + q;
@@ -610,6 +639,64 @@ extern "C" int glsdet_nonlocal_multi(const glsdet_view* x, const glsdet_view* tp
     op.bytes += (double)a.nimg * N * (3.0 * ci + 2.0 * a.cx) * dtype_size(dt);
   }
   op.name = n_sets > 1 ? "nonlocal_multi(gram+fold+apply)" : "nonlocal(gram+fold+apply)";
+  op.launch = [=](hipStream_t st) -> int {
+    const int nb = (a.ci + 15) / 16;
+    const dim3 g1(nb * nb, a.nimg, 8 * a.n), g2(a.nimg * a.n, (a.cx + GLS_FOLD_CO - 1) / GLS_FOLD_CO, (a.ci + 63) / 64),
+        g3((maxN + 63) / 64, a.nimg * a.n, (a.cx + GLS_APPLY_CO - 1) / GLS_APPLY_CO);
+    const size_t lds2 = (size_t)64 * (a.kc + 1) * 4;
+    const size_t lds3 = ((size_t)64 * (a.kc + 1) + (size_t)GLS_APPLY_CO * a.kc) * 4;
+    if (dt == GLSDET_F16) {
+      hipLaunchKernelGGL(nl_gram_kernel<f16>, g1, dim3(256), 0, st, a);
+      hipLaunchKernelGGL(nl_fold_kernel, g2, dim3(256), lds2, st, a);
+      hipLaunchKernelGGL(nl_apply_kernel<f16>, g3, dim3(256), lds3, st, a);
+    } else {
+      hipLaunchKernelGGL(nl_gram_kernel<float>, g1, dim3(256), 0, st, a);
+      hipLaunchKernelGGL(nl_fold_kernel, g2, dim3(256), lds2, st, a);
+      hipLaunchKernelGGL(nl_apply_kernel<float>, g3, dim3(256), lds3, st, a);
+    }
+    GLS_HIP(hipGetLastError());
+    return 0;
+  };
+  return submit(std::move(op), stream);
+}
+
+// Patch_Conv_NonLocal_adapt_new: the four quadrant blocks on windows whose extents live in DEVICE memory (`split`, written
+// by glsdet_attn_split): x / out are the full maps, tpg[q] the full-map projections with quadrant q's weights.
+extern "C" int glsdet_nonlocal_split(const glsdet_view* x, const glsdet_view* tpg, int32_t ci, const float* const* wout,
+                                     const float* const* bout, float* gram, const glsdet_view* out, const int32_t* split,
+                                     void* stream) {
+  if (!x || !tpg || !out || !wout || !bout || !gram || !split) GLS_FAIL(GLSDET_E_ARG, "nonlocal_split: null argument");
+  int rc;
+  if ((rc = check_view(*x, "nonlocal_split.x", false))) return rc;
+  if ((rc = check_view(*out, "nonlocal_split.out", false))) return rc;
+  if (!same_extent(*x, *out) || x->dtype != out->dtype) GLS_FAIL(GLSDET_E_ARG, "nonlocal_split: x/out mismatch");
+  NlArgs a = {};
+  a.n = 4; a.ci = ci; a.cx = x->c; a.nimg = x->n;
+  a.kc = ci < GLS_NL_KC ? ci : GLS_NL_KC;
+  a.split = split; a.FH = x->h; a.FW = x->w;
+  const int dt = x->dtype;
+  const long per_set = (long)a.nimg * (8L * ci * ci + (long)a.cx * ci);
+  for (int q = 0; q < 4; ++q) {
+    if ((rc = check_view(tpg[q], "nonlocal_split.tpg", false))) return rc;
+    if (tpg[q].n != x->n || tpg[q].h != x->h || tpg[q].w != x->w || ci < 1 || tpg[q].c < 3 * ci || tpg[q].dtype != dt)
+      GLS_FAIL(GLSDET_E_ARG, "nonlocal_split: theta|phi|g views must be [n,h,w,>=3*ci] of x's dtype");
+    if (!wout[q] || !bout[q]) GLS_FAIL(GLSDET_E_ARG, "nonlocal_split: null weight");
+    NlSet& S = a.s[q];
+    S.x = (const unsigned char*)x->base; S.tpg = (const unsigned char*)tpg[q].base; S.out = (unsigned char*)out->base;
+    S.xsn = x->sn; S.xsh = x->sh; S.xsw = x->sw;
+    S.tsn = tpg[q].sn; S.tsh = tpg[q].sh; S.tsw = tpg[q].sw;
+    S.osn = out->sn; S.osh = out->sh; S.osw = out->sw;
+    S.wout = wout[q]; S.bout = bout[q];
+    S.gram = gram + q * per_set;
+    S.P = S.gram + (long)a.nimg * 8 * ci * ci;
+    S.H = x->h; S.W = x->w; S.nsplit = 8; S.jchunk = 64; S.invN = 1.0f;        // overridden from `split` on the device
+  }
+  const int maxN = x->h * x->w;
+  OpRecord op;
+  op.kind = 4;
+  op.flops = 2.0 * 2.0 * (double)a.nimg * maxN * (double)maxN / 4.0 * ci;      // four quadrants of ~N/4 positions each
+  op.bytes = (double)a.nimg * maxN * (3.0 * ci + 2.0 * a.cx) * dtype_size(dt);
+  op.name = "nonlocal_split(gram+fold+apply, device-side quadrants)";
   op.launch = [=](hipStream_t st) -> int {
     const int nb = (a.ci + 15) / 16;
     const dim3 g1(nb * nb, a.nimg, 8 * a.n), g2(a.nimg * a.n, (a.cx + GLS_FOLD_CO - 1) / GLS_FOLD_CO, (a.ci + 63) / 64),

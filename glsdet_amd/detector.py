@@ -36,6 +36,7 @@ class HipDetector:
         consecutive batches can be in flight concurrently (see run_async)."""
         key = (n, H, W, tuple(sorted(post.items())) if post else None, use_graph, instance)
         if key in self._compiled:
+            self._compiled[key] = self._compiled.pop(key)          # most recently used last
             return self._compiled[key]
         if H % 32 or W % 32:
             raise ValueError("input H and W must be multiples of 32 (got %dx%d)" % (H, W))
@@ -73,6 +74,13 @@ class HipDetector:
                     c.plan.capture(c.graph_stream)
                 c.graph_stream.synchronize()
         self._compiled[key] = c
+        # LRU cap on resident plans (each holds its activations, an NMS workspace and, today, its own copy of the packed
+        # weights): the UFPMP fine stage compiles one plan per padded mosaic shape and lane -- without a cap HBM grows with
+        # every new shape over a data set.  GLSDET_MAX_PLANS (default 24) plans stay; evicted ones are rebuilt on demand.
+        import os as _os
+        cap = int(_os.environ.get("GLSDET_MAX_PLANS", "24"))
+        while len(self._compiled) > max(1, cap):
+            self._compiled.pop(next(iter(self._compiled)))
         return c
 
     # ------------------------------------------------------------------ run

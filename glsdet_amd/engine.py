@@ -537,6 +537,37 @@ class Engine:
               "nonlocal_multi")
         return list(xs)
 
+    # ---- Patch_Conv_NonLocal_adapt_new: device-side quadrant split
+    def attn_split(self, att: TView) -> torch.Tensor:
+        """-> device int32[4] {row split, column split above it, column split from it on, 0} (glsdet_attn_split)."""
+        split = torch.zeros(4, dtype=torch.int32, device=self.device)
+        self._keep.append(split)
+        check(self.lib.glsdet_attn_split(C.byref(att.as_c()), split.data_ptr(), _stream_ptr(self.stream)), "attn_split")
+        return split
+
+    def nonlocal_split(self, x: TView, tpgs: Sequence[TView], ci: int, wouts, bouts, out: TView, split: torch.Tensor) -> TView:
+        ws = self.raw(4 * x.n * (8 * ci * ci + x.c * ci) * 4)
+        ta = (View * 4)(*[t.as_c() for t in tpgs])
+        wa = (C.c_void_p * 4)(*[w.data_ptr() for w in wouts])
+        ba = (C.c_void_p * 4)(*[b.data_ptr() for b in bouts])
+        check(self.lib.glsdet_nonlocal_split(C.byref(x.as_c()), ta, ci, wa, ba, ws.data_ptr(), C.byref(out.as_c()),
+                                             split.data_ptr(), _stream_ptr(self.stream)), "nonlocal_split")
+        return out
+
+    def rowsplit(self, a: TView, b: Optional[TView], split: torch.Tensor, mode: int, out: Optional[TView] = None) -> TView:
+        if out is None:
+            out = self.tensor(a.n, a.h, a.w, a.c, a.dtype)
+        check(self.lib.glsdet_rowsplit(C.byref(a.as_c()), C.byref(b.as_c()) if b is not None else None, C.byref(out.as_c()),
+                                       split.data_ptr(), mode, _stream_ptr(self.stream)), "rowsplit")
+        return out
+
+    def scale_by_map(self, x: TView, m: TView, out: Optional[TView] = None) -> TView:
+        if out is None:
+            out = self.tensor(x.n, x.h, x.w, x.c, x.dtype)
+        check(self.lib.glsdet_scale_by_map(C.byref(x.as_c()), C.byref(m.as_c()), C.byref(out.as_c()), _stream_ptr(self.stream)),
+              "scale_by_map")
+        return out
+
     def decode(self, levels: Sequence[TView], num_classes: int, in_h: int, in_w: int,
                strides: Optional[Sequence[int]] = None, mode: int = 0, out: Optional[torch.Tensor] = None,
                scale_factors: Optional[torch.Tensor] = None) -> torch.Tensor:

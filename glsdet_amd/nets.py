@@ -349,6 +349,39 @@ class NetBuilder:
             return self.plain(p + ".channel_conv", x, out=out)
         return self.cba(p + ".channel_conv", x, out=out)
 
+    def patch_conv_nonlocal_adapt_new(self, p: str, x: TView, out: Optional[TView] = None) -> TView:
+        """Patch_Conv_NonLocal_adapt_new (new/Non_local_family.py:272-357).  The quadrant split is computed ON the device
+        from the thresholded attention map and stays there (Engine.attn_split): the four non-local blocks read their
+        windows from it, the top / bottom 3x3 convs run on row-masked copies (the zeros are the padding the reference's
+        sliced tensors see at the split) and a row select re-joins them -- no host synchronisation, where the reference
+        makes one per column and row."""
+        e = self.e
+        att = self.spatial_attention(p + ".attention_map", x)
+        split = e.attn_split(att)
+        self.last_split = split
+        names = ["%s.feat_patchconv_%s_nonlocal" % (p, q) for q in ("lt", "lb", "rt", "rb")]
+        ci = self.sd[names[0] + ".theta.weight"].shape[0]
+        packs, wouts, bouts = [], [], []
+        for q in names:
+            parts = [self._plain_part(q + ".theta"), self._plain_part(q + ".phi"), self._plain_part(q + ".g")]
+            packs.append(self._pack(q + ".tpg", parts, x.c))
+            key = q + ".tpg.out"
+            if key not in self._packed:
+                self._packed[key] = (e.upload(self.sd[q + ".conv_out.weight"].float().reshape(-1, ci)),
+                                     e.upload(self.sd[q + ".conv_out.bias"].float()))
+            wouts.append(self._packed[key][0])
+            bouts.append(self._packed[key][1])
+        tpgs = e.conv_group([x] * 4, packs, 1, 0, "none")       # every quadrant's projections over the full map
+        S = e.nonlocal_split(x, tpgs, ci, wouts, bouts, e.tensor(x.n, x.h, x.w, x.c), split)
+        T = self.cba(p + ".feat_patchconv_t", e.rowsplit(S, None, split, 0))
+        B = self.cba(p + ".feat_patchconv_b", e.rowsplit(S, None, split, 1))
+        Fm = e.rowsplit(T, B, split, 2)
+        if self.has(p + ".channel_conv.weight"):
+            y = self.plain(p + ".channel_conv", Fm)
+        else:
+            y = self.cba(p + ".channel_conv", Fm)
+        return e.scale_by_map(y, att, out)
+
     def attention(self, p: str, x: TView, out: Optional[TView] = None) -> TView:
         """Attention (new/Non_local_family.py:254-272): proj_1 + exact GELU fused in one 1x1
         GEMM epilogue, gating unit, proj_2 with the shortcut add fused as the residual."""

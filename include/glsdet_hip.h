@@ -185,6 +185,26 @@ int glsdet_nonlocal_multi(const glsdet_view* x, const glsdet_view* tpg, int32_t 
                           const glsdet_view* out, void* stream);
 
 /* ---------------------------------------------------------------------------------
+ * Patch_Conv_NonLocal_adapt_new: the data-dependent quadrant split (drone/models/new/Non_local_family.py:272-357)
+ * The reference thresholds its SpatialAttention map (values under min + 0.75 (max - min) -> 0) and walks columns / rows in
+ * Python until the running sum passes half of the total (`get_centroid`, :298-321: one device sync per step).  Here:
+ *   glsdet_attn_split   att = [n,h,w,>=1] view whose channel 0 is the map (n <= 16, one split for the whole batch as in the
+ *                       reference) -> split = DEVICE int32[4] {row split, column split above it, column split from it on, 0}
+ *   glsdet_nonlocal_split  the four Non_local_Blocks (sets lt, lb, rt, rb) on the windows `split` describes: x / out full
+ *                       maps, tpg[q] = [theta|phi|g] of the full map with quadrant q's weights, gram = 4 x the workspace of
+ *                       glsdet_nonlocal
+ *   glsdet_rowsplit     mode 0 / 1: y = a above / from the row split, zero elsewhere (the zero padding the top / bottom 3x3
+ *                       convs see at the split); mode 2: y = row < split ? a : b (`torch.cat((t, b), dim=2)`)
+ *   glsdet_scale_by_map y[..,c] = map[..,0] * x[..,c]                                  (:355-356)
+ * Nothing returns to the host: the block is recordable / capturable like any other op sequence.                       */
+int glsdet_attn_split(const glsdet_view* att, int32_t* split, void* stream);
+int glsdet_nonlocal_split(const glsdet_view* x, const glsdet_view* tpg /*[4]*/, int32_t ci, const float* const* wout /*[4]*/,
+                          const float* const* bout /*[4]*/, float* gram, const glsdet_view* out, const int32_t* split, void* stream);
+int glsdet_rowsplit(const glsdet_view* a, const glsdet_view* b /*mode 2*/, const glsdet_view* y, const int32_t* split, int32_t mode,
+                    void* stream);
+int glsdet_scale_by_map(const glsdet_view* x, const glsdet_view* map, const glsdet_view* y, void* stream);
+
+/* ---------------------------------------------------------------------------------
  * YOLOX decode        drone/models/core/utils_bbox.py:254-306  (mode 0, normalised cxcywh)
  *                     ufp/mmdet/models/dense_heads/yolox_head.py:298-308 (mode 1, xyxy px)
  * levels: fp32 views [n,H_l,W_l,>=5+nc] (channel order reg4, obj, cls..).

@@ -294,6 +294,57 @@ def patch_conv_nonlocal_44(sd: SD, p: str, x: Tensor) -> Tensor:
     return base_conv(sd, p + ".channel_conv", both)
 
 
+def get_centroid(x: Tensor) -> Tuple[int, int]:
+    """Patch_Conv_NonLocal_adapt_new.get_centroid (drone/models/new/Non_local_family.py:298-321): the first column /
+    row at which the running sum (over the WHOLE batch) exceeds half of the total, rounded down to even and clamped to
+    [4, size - 4].  -> (centroid_x: split along H, centroid_y: split along W)."""
+    x_2, x_3 = x.sum(2), x.sum(3)
+    total = x.sum()
+
+    def first(v, n):
+        d = 0
+        i = 0
+        for i in range(n):
+            d = v[:, :, i] + d
+            if d.sum() > 0.5 * total:
+                break
+        i = i // 2 * 2
+        i = 4 if i < 4 else i
+        return n - 4 if i > n - 4 else i
+    return first(x_3, x.shape[2]), first(x_2, x.shape[3])
+
+
+def adapt_split(att: Tensor) -> Tuple[int, int, int]:
+    """The data-dependent quadrant split of Patch_Conv_NonLocal_adapt_new.forward (:324-334) from the attention map:
+    values under min + 0.75 (max - min) are zeroed, then (row split, column split of the top part, of the bottom part)."""
+    a = att.clone()
+    mx, mn = a.max(), a.min()
+    a[a < mn + 0.75 * (mx - mn)] = 0
+    cx, _ = get_centroid(a)
+    _, cyl = get_centroid(a[:, :, :cx, :])
+    _, cyr = get_centroid(a[:, :, cx:, :])
+    return cx, cyl, cyr
+
+
+def patch_conv_nonlocal_adapt_new(sd: SD, p: str, x: Tensor) -> Tensor:
+    """Patch_Conv_NonLocal_adapt_new (Non_local_family.py:272-357): the quadrant split follows the thresholded spatial
+    attention map (one split for the whole batch, App. D.3), non-local per quadrant at the input resolution, a 3x3
+    BaseConv on the top and on the bottom part, channel_conv, and the result gated by the (unthresholded) attention map."""
+    att = spatial_attention(sd, p + ".attention_map", x)
+    cx, cyl, cyr = adapt_split(att)
+    nl = lambda name, t: non_local_block(sd, "{}.feat_patchconv_{}_nonlocal".format(p, name), t)
+    lt, lb = nl("lt", x[:, :, :cx, :cyl]), nl("lb", x[:, :, cx:, :cyr])
+    rt, rb = nl("rt", x[:, :, :cx, cyl:]), nl("rb", x[:, :, cx:, cyr:])
+    t = base_conv(sd, p + ".feat_patchconv_t", torch.cat((lt, rt), 3))
+    b = base_conv(sd, p + ".feat_patchconv_b", torch.cat((lb, rb), 3))
+    both = torch.cat((t, b), 2)
+    if p + ".channel_conv.weight" in sd:
+        y = plain_conv(sd, p + ".channel_conv", both)
+    else:
+        y = base_conv(sd, p + ".channel_conv", both)
+    return _q(spatial_attention(sd, p + ".attention_map", x) * y, p + ".gated")
+
+
 def attention(sd: SD, p: str, x: Tensor) -> Tensor:
     """Attention (Non_local_family.py:254-272): proj_1 1x1 -> exact GELU -> quadrant non-local
     gating unit -> proj_2 1x1 -> + shortcut."""

@@ -27,6 +27,8 @@ ORACLE = {
     "att_spatial_attention": lambda sd, x: O.spatial_attention(sd, "m", x),
     "att_pcnl_44": lambda sd, x: O.patch_conv_nonlocal_44(sd, "m", x),
     "att_pcnl_44_odd": lambda sd, x: O.patch_conv_nonlocal_44(sd, "m", x),
+    "att_pcnl_adapt_new": lambda sd, x: O.patch_conv_nonlocal_adapt_new(sd, "m", x),
+    "att_pcnl_adapt_new_linear": lambda sd, x: O.patch_conv_nonlocal_adapt_new(sd, "m", x),
     "att_darknet_tiny": _dark,
 }
 
@@ -67,6 +69,8 @@ HIP = {
     "att_spatial_attention": lambda b, x: b.spatial_attention("m", x),
     "att_pcnl_44": lambda b, x: b.patch_conv_nonlocal_44("m", x),
     "att_pcnl_44_odd": lambda b, x: b.patch_conv_nonlocal_44("m", x),
+    "att_pcnl_adapt_new": lambda b, x: b.patch_conv_nonlocal_adapt_new("m", x),
+    "att_pcnl_adapt_new_linear": lambda b, x: b.patch_conv_nonlocal_adapt_new("m", x),
 }
 
 
@@ -144,3 +148,41 @@ def test_detector_with_attention_backbone_vs_oracle():
     for g, w in zip(got, want):
         assert g.shape == w.shape
         assert _err(g, w) <= max(1e-4, 2 * noise), (_err(g, w), noise)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["f32", "f16"])
+@pytest.mark.parametrize("tag", ["att_pcnl_adapt_new", "att_pcnl_adapt_new_linear"])
+def test_adaptive_split_is_found_on_the_device_and_survives_graph_capture(engines, att_golden, mode, tag):
+    """The data-dependent split of Patch_Conv_NonLocal_adapt_new: the indices the device kernel leaves in device memory are
+    the ones the reference's Python loops find (oracle.adapt_split on the same attention map), and the whole block --
+    non-local windows, masked convs, select -- replays from a captured hipGraph with a DIFFERENT input (hence another
+    split) without touching the host."""
+    from glsdet_amd.nets import NetBuilder
+    from tests.test_hip_ops import _to_view
+    eng = engines[mode]
+    sd, x, want = block_case(att_golden, tag)
+    r = (lambda t: t.half().float()) if mode == "f16" else (lambda t: t)
+    b = NetBuilder(eng, sd)
+    xv = _to_view(eng, x)
+    plan = eng.new_plan()
+    with plan:
+        out = b.patch_conv_nonlocal_adapt_new("m", xv)
+    plan.run()
+    torch.cuda.synchronize()
+    assert b.last_split.cpu().tolist()[:3] == list(O.adapt_split(O.spatial_attention(sd, "m.attention_map", r(x))))
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        plan.capture(st)
+    x2 = torch.roll(x, shifts=(7, 11), dims=(2, 3)) * 1.3            # another input: another split
+    t = torch.zeros(x2.shape[0], x2.shape[2], x2.shape[3], xv.c)
+    t[..., : x2.shape[1]] = x2.permute(0, 2, 3, 1)
+    flat = xv.buf.view(torch.float16 if mode == "f16" else torch.float32)
+    flat[: t.numel()] = t.flatten().to(flat.dtype).cuda()
+    with torch.cuda.stream(st):
+        plan.launch(st)
+    st.synchronize()
+    want2 = O.patch_conv_nonlocal_adapt_new(sd, "m", r(x2))
+    split2 = list(O.adapt_split(O.spatial_attention(sd, "m.attention_map", r(x2))))
+    assert b.last_split.cpu().tolist()[:3] == split2
+    assert _err(out.to_nchw(want2.shape[1]).cpu(), want2) <= (5e-5 if mode == "f32" else 2e-2)

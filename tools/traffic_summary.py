@@ -12,7 +12,7 @@ def per_launch(sub, counter):
     tot, n = 0.0, 0
     for f in glob.glob("%s/%s/**/*counter_collection.csv" % (d, sub), recursive=True):
         for r in csv.DictReader(open(f)):
-            if r["Counter_Name"] == counter and "conv" in r["Kernel_Name"]:
+            if r["Counter_Name"] == counter and ("conv" in r["Kernel_Name"] or "focus_stem" in r["Kernel_Name"]):
                 tot += float(r["Counter_Value"]); n += 1
     return tot, n
 
