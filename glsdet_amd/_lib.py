@@ -71,7 +71,7 @@ _SIGS = {
                                         C.POINTER(C.c_void_p), C.c_void_p, C.POINTER(View), C.c_void_p]),
     "glsdet_attn_split": (C.c_int, [C.POINTER(View), C.c_void_p, C.c_void_p]),
     "glsdet_nonlocal_split": (C.c_int, [C.POINTER(View), C.POINTER(View), C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
-                                        C.c_void_p, C.POINTER(View), C.c_void_p, C.c_void_p]),
+                                        C.c_void_p, C.POINTER(View), C.c_void_p, C.c_int32, C.c_void_p]),
     "glsdet_rowsplit": (C.c_int, [C.POINTER(View), C.POINTER(View), C.POINTER(View), C.c_void_p, C.c_int32, C.c_void_p]),
     "glsdet_scale_by_map": (C.c_int, [C.POINTER(View), C.POINTER(View), C.POINTER(View), C.c_void_p]),
     "glsdet_yolox_decode": (C.c_int, [C.POINTER(View), C.c_int32, C.c_int32, C.c_int32, C.c_int32,

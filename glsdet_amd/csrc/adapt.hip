@@ -97,12 +97,15 @@ __global__ __launch_bounds__(1024) void attn_split_kernel(const unsigned char* a
   }
 }
 
-// mode 0: y = x on the rows above the split, 0 below; 1: y = x from the split on, 0 above; 2: y = row < split ? a : b
+// Region masks / selects by the device-side split (indices >> shift: the regions of the stride-2 map).
+// mode 0: y = a on the rows above the row split, 0 below; 1: y = a from the split on, 0 above; 2: y = row < split ? a : b;
+// 3: y = a inside quadrant q (0 lt, 1 lb, 2 rt, 3 rb), 0 outside; 4: y = a inside quadrant q, y unchanged outside.
 template <typename T>
 __global__ __launch_bounds__(256) void rowsplit_kernel(const unsigned char* a, long asn, long ash, long asw, const unsigned char* b,
                                                        long bsn, long bsh, long bsw, unsigned char* y, long ysn, long ysh, long ysw,
-                                                       int n, int H, int W, int cch, const int* __restrict__ split, int mode) {
-  const int cx = split[0];
+                                                       int n, int H, int W, int cch, const int* __restrict__ split, int mode, int q,
+                                                       int shift) {
+  const int cx = split[0] >> shift, cyl = split[1] >> shift, cyr = split[2] >> shift;
   const long total = (long)n * H * W * cch;
   constexpr int VN = 16 / (int)sizeof(T);
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
@@ -112,14 +115,20 @@ __global__ __launch_bounds__(256) void rowsplit_kernel(const unsigned char* a, l
     p /= W;
     const int h = (int)(p % H), img = (int)(p / H);
     const bool top = h < cx;
+    const int quad = (top ? 0 : 1) + (w >= (top ? cyl : cyr) ? 2 : 0);
     uint4 v = {0u, 0u, 0u, 0u};
+    const long ao = (img * asn + h * ash + w * asw + cc * VN) * (long)sizeof(T);
+    const long yo = (img * ysn + h * ysh + w * ysw + cc * VN) * (long)sizeof(T);
     if (mode == 2) {
-      v = top ? *reinterpret_cast<const uint4*>(a + (img * asn + h * ash + w * asw + cc * VN) * (long)sizeof(T))
+      v = top ? *reinterpret_cast<const uint4*>(a + ao)
               : *reinterpret_cast<const uint4*>(b + (img * bsn + h * bsh + w * bsw + cc * VN) * (long)sizeof(T));
-    } else if ((mode == 0) == top) {
-      v = *reinterpret_cast<const uint4*>(a + (img * asn + h * ash + w * asw + cc * VN) * (long)sizeof(T));
+    } else if (mode <= 1) {
+      if ((mode == 0) == top) v = *reinterpret_cast<const uint4*>(a + ao);
+    } else {
+      if (quad == q) v = *reinterpret_cast<const uint4*>(a + ao);
+      else if (mode == 4) continue;
     }
-    *reinterpret_cast<uint4*>(y + (img * ysn + h * ysh + w * ysw + cc * VN) * (long)sizeof(T)) = v;
+    *reinterpret_cast<uint4*>(y + yo) = v;
   }
 }
 
@@ -180,7 +189,9 @@ extern "C" int glsdet_attn_split(const glsdet_view* att, int32_t* split, void* s
 
 extern "C" int glsdet_rowsplit(const glsdet_view* a, const glsdet_view* b, const glsdet_view* y, const int32_t* split, int32_t mode,
                                void* stream) {
-  if (!a || !y || !split || mode < 0 || mode > 2 || (mode == 2 && !b)) GLS_FAIL(GLSDET_E_ARG, "rowsplit: bad argument");
+  const int q = (mode >> 4) & 3, shift = (mode >> 8) & 1;
+  mode &= 15;
+  if (!a || !y || !split || mode < 0 || mode > 4 || (mode == 2 && !b)) GLS_FAIL(GLSDET_E_ARG, "rowsplit: bad argument");
   int rc;
   if ((rc = check_view(*a, "rowsplit.a"))) return rc;
   if ((rc = check_view(*y, "rowsplit.y"))) return rc;
@@ -196,14 +207,14 @@ extern "C" int glsdet_rowsplit(const glsdet_view* a, const glsdet_view* b, const
   op.kind = 3;
   op.flops = 0;
   op.bytes = 2.0 * va.n * va.h * va.w * va.c * dtype_size(va.dtype);
-  op.name = mode == 2 ? "rowsplit(select)" : "rowsplit(mask)";
+  op.name = mode == 2 ? "rowsplit(select)" : (mode == 4 ? "rowsplit(merge quadrant)" : "rowsplit(mask)");
   op.launch = [=](hipStream_t st) -> int {
     const int vn = 16 / dtype_size(va.dtype);
     const unsigned g = grid_of((long)va.n * va.h * va.w * (va.c / vn));
     if (va.dtype == GLSDET_F16)
-      hipLaunchKernelGGL(rowsplit_kernel<f16>, dim3(g), dim3(256), 0, st, (const unsigned char*)va.base, va.sn, va.sh, va.sw, (const unsigned char*)vb.base, vb.sn, vb.sh, vb.sw, (unsigned char*)vy.base, vy.sn, vy.sh, vy.sw, va.n, va.h, va.w, va.c / vn, split, mode);
+      hipLaunchKernelGGL(rowsplit_kernel<f16>, dim3(g), dim3(256), 0, st, (const unsigned char*)va.base, va.sn, va.sh, va.sw, (const unsigned char*)vb.base, vb.sn, vb.sh, vb.sw, (unsigned char*)vy.base, vy.sn, vy.sh, vy.sw, va.n, va.h, va.w, va.c / vn, split, mode, q, shift);
     else
-      hipLaunchKernelGGL(rowsplit_kernel<float>, dim3(g), dim3(256), 0, st, (const unsigned char*)va.base, va.sn, va.sh, va.sw, (const unsigned char*)vb.base, vb.sn, vb.sh, vb.sw, (unsigned char*)vy.base, vy.sn, vy.sh, vy.sw, va.n, va.h, va.w, va.c / vn, split, mode);
+      hipLaunchKernelGGL(rowsplit_kernel<float>, dim3(g), dim3(256), 0, st, (const unsigned char*)va.base, va.sn, va.sh, va.sw, (const unsigned char*)vb.base, vb.sn, vb.sh, vb.sw, (unsigned char*)vy.base, vy.sn, vy.sh, vy.sw, va.n, va.h, va.w, va.c / vn, split, mode, q, shift);
     GLS_HIP(hipGetLastError());
     return 0;
   };

@@ -254,14 +254,14 @@ struct NlArgs {
   // part, of the bottom part} written by glsdet_attn_split; every set's views then span the FULL FH x FW map and the
   // kernels cut their own window (sets in the order lt, lb, rt, rb).  nullptr: the static windows of the views.
   const int* split;
-  int FH, FW;
+  int FH, FW, shift;          // shift 1: the windows live on the stride-2 map of the split's map (indices halved)
 };
 struct NlWin { int H, W, nsplit, jchunk; long xo, to, oo; float invN; };
 __device__ __forceinline__ NlWin nl_window(const NlArgs& a, int q) {
   const NlSet& S = a.s[q];
   NlWin w = {S.H, S.W, S.nsplit, S.jchunk, 0, 0, 0, S.invN};
   if (a.split) {
-    const int cx = a.split[0], cyl = a.split[1], cyr = a.split[2];
+    const int cx = a.split[0] >> a.shift, cyl = a.split[1] >> a.shift, cyr = a.split[2] >> a.shift;
     const bool bottom = q & 1, right = q >> 1;
     const int c = bottom ? cyr : cyl;
     const int r0 = bottom ? cx : 0, c0 = right ? c : 0;
@@ -664,8 +664,9 @@ extern "C" int glsdet_nonlocal_multi(const glsdet_view* x, const glsdet_view* tp
 // by glsdet_attn_split): x / out are the full maps, tpg[q] the full-map projections with quadrant q's weights.
 extern "C" int glsdet_nonlocal_split(const glsdet_view* x, const glsdet_view* tpg, int32_t ci, const float* const* wout,
                                      const float* const* bout, float* gram, const glsdet_view* out, const int32_t* split,
-                                     void* stream) {
-  if (!x || !tpg || !out || !wout || !bout || !gram || !split) GLS_FAIL(GLSDET_E_ARG, "nonlocal_split: null argument");
+                                     int32_t split_shift, void* stream) {
+  if (!x || !tpg || !out || !wout || !bout || !gram || !split || split_shift < 0 || split_shift > 1)
+    GLS_FAIL(GLSDET_E_ARG, "nonlocal_split: bad argument");
   int rc;
   if ((rc = check_view(*x, "nonlocal_split.x", false))) return rc;
   if ((rc = check_view(*out, "nonlocal_split.out", false))) return rc;
@@ -673,7 +674,7 @@ extern "C" int glsdet_nonlocal_split(const glsdet_view* x, const glsdet_view* tp
   NlArgs a = {};
   a.n = 4; a.ci = ci; a.cx = x->c; a.nimg = x->n;
   a.kc = ci < GLS_NL_KC ? ci : GLS_NL_KC;
-  a.split = split; a.FH = x->h; a.FW = x->w;
+  a.split = split; a.FH = x->h; a.FW = x->w; a.shift = split_shift;
   const int dt = x->dtype;
   const long per_set = (long)a.nimg * (8L * ci * ci + (long)a.cx * ci);
   for (int q = 0; q < 4; ++q) {

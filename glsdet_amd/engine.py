@@ -545,20 +545,23 @@ class Engine:
         check(self.lib.glsdet_attn_split(C.byref(att.as_c()), split.data_ptr(), _stream_ptr(self.stream)), "attn_split")
         return split
 
-    def nonlocal_split(self, x: TView, tpgs: Sequence[TView], ci: int, wouts, bouts, out: TView, split: torch.Tensor) -> TView:
+    def nonlocal_split(self, x: TView, tpgs: Sequence[TView], ci: int, wouts, bouts, out: TView, split: torch.Tensor,
+                       shift: int = 0) -> TView:
         ws = self.raw(4 * x.n * (8 * ci * ci + x.c * ci) * 4)
         ta = (View * 4)(*[t.as_c() for t in tpgs])
         wa = (C.c_void_p * 4)(*[w.data_ptr() for w in wouts])
         ba = (C.c_void_p * 4)(*[b.data_ptr() for b in bouts])
         check(self.lib.glsdet_nonlocal_split(C.byref(x.as_c()), ta, ci, wa, ba, ws.data_ptr(), C.byref(out.as_c()),
-                                             split.data_ptr(), _stream_ptr(self.stream)), "nonlocal_split")
+                                             split.data_ptr(), shift, _stream_ptr(self.stream)), "nonlocal_split")
         return out
 
-    def rowsplit(self, a: TView, b: Optional[TView], split: torch.Tensor, mode: int, out: Optional[TView] = None) -> TView:
+    def rowsplit(self, a: TView, b: Optional[TView], split: torch.Tensor, mode: int, out: Optional[TView] = None, quadrant: int = 0,
+                 shift: int = 0) -> TView:
+        """glsdet_rowsplit: 0 / 1 keep the rows above / from the split, 2 select a | b by row, 3 keep quadrant, 4 merge quadrant"""
         if out is None:
             out = self.tensor(a.n, a.h, a.w, a.c, a.dtype)
         check(self.lib.glsdet_rowsplit(C.byref(a.as_c()), C.byref(b.as_c()) if b is not None else None, C.byref(out.as_c()),
-                                       split.data_ptr(), mode, _stream_ptr(self.stream)), "rowsplit")
+                                       split.data_ptr(), mode | (quadrant << 4) | (shift << 8), _stream_ptr(self.stream)), "rowsplit")
         return out
 
     def scale_by_map(self, x: TView, m: TView, out: Optional[TView] = None) -> TView:

@@ -382,6 +382,45 @@ class NetBuilder:
             y = self.cba(p + ".channel_conv", Fm)
         return e.scale_by_map(y, att, out)
 
+    def patch_conv_nonlocal_adapt(self, p: str, x: TView, out: Optional[TView] = None) -> TView:
+        """Patch_Conv_NonLocal_adapt (new/Non_local_family.py:112-206): as the _new form, with a stride-2 3x3 BaseConv per
+        quadrant in front of its non-local block and no gating.  The split indices are even (get_centroid rounds them), so a
+        quadrant of the input maps onto the region [split / 2) of the stride-2 map: each quadrant conv runs over the whole
+        map on a copy that is zero outside its quadrant (its padding at the split) and its region is merged into one buffer;
+        everything downstream works on the halved split in device memory."""
+        e = self.e
+        if x.h % 2 or x.w % 2:
+            raise ValueError("Patch_Conv_NonLocal_adapt needs even H and W (the reference's own torch.cat fails otherwise)")
+        att = self.spatial_attention(p + ".attention_map", x)
+        split = e.attn_split(att)
+        self.last_split = split
+        quads = ("lt", "lb", "rt", "rb")
+        masked = [e.rowsplit(x, None, split, 3, quadrant=i) for i in range(4)]
+        convs = self.cba_group(["%s.feat_patchconv_%s" % (p, q) for q in quads], masked, 2)
+        Q = e.tensor(convs[0].n, convs[0].h, convs[0].w, convs[0].c)
+        for i in range(4):
+            e.rowsplit(convs[i], None, split, 4, out=Q, quadrant=i, shift=1)
+        names = ["%s.feat_patchconv_%s_nonlocal" % (p, q) for q in quads]
+        ci = self.sd[names[0] + ".theta.weight"].shape[0]
+        packs, wouts, bouts = [], [], []
+        for q in names:
+            parts = [self._plain_part(q + ".theta"), self._plain_part(q + ".phi"), self._plain_part(q + ".g")]
+            packs.append(self._pack(q + ".tpg", parts, Q.c))
+            key = q + ".tpg.out"
+            if key not in self._packed:
+                self._packed[key] = (e.upload(self.sd[q + ".conv_out.weight"].float().reshape(-1, ci)),
+                                     e.upload(self.sd[q + ".conv_out.bias"].float()))
+            wouts.append(self._packed[key][0])
+            bouts.append(self._packed[key][1])
+        tpgs = e.conv_group([Q] * 4, packs, 1, 0, "none")
+        S = e.nonlocal_split(Q, tpgs, ci, wouts, bouts, e.tensor(Q.n, Q.h, Q.w, Q.c), split, shift=1)
+        T = self.cba(p + ".feat_patchconv_t", e.rowsplit(S, None, split, 0, shift=1))
+        B = self.cba(p + ".feat_patchconv_b", e.rowsplit(S, None, split, 1, shift=1))
+        Fm = e.rowsplit(T, B, split, 2, shift=1)
+        if self.has(p + ".channel_conv.weight"):
+            return self.plain(p + ".channel_conv", Fm, out=out)
+        return self.cba(p + ".channel_conv", Fm, out=out)
+
     def attention(self, p: str, x: TView, out: Optional[TView] = None) -> TView:
         """Attention (new/Non_local_family.py:254-272): proj_1 + exact GELU fused in one 1x1
         GEMM epilogue, gating unit, proj_2 with the shortcut add fused as the residual."""

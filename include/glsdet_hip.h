@@ -194,12 +194,16 @@ int glsdet_nonlocal_multi(const glsdet_view* x, const glsdet_view* tpg, int32_t 
  *                       maps, tpg[q] = [theta|phi|g] of the full map with quadrant q's weights, gram = 4 x the workspace of
  *                       glsdet_nonlocal
  *   glsdet_rowsplit     mode 0 / 1: y = a above / from the row split, zero elsewhere (the zero padding the top / bottom 3x3
- *                       convs see at the split); mode 2: y = row < split ? a : b (`torch.cat((t, b), dim=2)`)
+ *                       convs see at the split); mode 2: y = row < split ? a : b (`torch.cat((t, b), dim=2)`);
+ *                       mode 3 | q << 4: y = a inside quadrant q (0 lt, 1 lb, 2 rt, 3 rb), zero outside; mode 4 | q << 4: y = a
+ *                       inside quadrant q, y untouched outside; | 1 << 8: the split indices halved (regions of the stride-2
+ *                       map of Patch_Conv_NonLocal_adapt, :112-206, whose quadrant convs have stride 2)
  *   glsdet_scale_by_map y[..,c] = map[..,0] * x[..,c]                                  (:355-356)
  * Nothing returns to the host: the block is recordable / capturable like any other op sequence.                       */
 int glsdet_attn_split(const glsdet_view* att, int32_t* split, void* stream);
 int glsdet_nonlocal_split(const glsdet_view* x, const glsdet_view* tpg /*[4]*/, int32_t ci, const float* const* wout /*[4]*/,
-                          const float* const* bout /*[4]*/, float* gram, const glsdet_view* out, const int32_t* split, void* stream);
+                          const float* const* bout /*[4]*/, float* gram, const glsdet_view* out, const int32_t* split,
+                          int32_t split_shift /* 0, or 1: windows on the stride-2 map */, void* stream);
 int glsdet_rowsplit(const glsdet_view* a, const glsdet_view* b /*mode 2*/, const glsdet_view* y, const int32_t* split, int32_t mode,
                     void* stream);
 int glsdet_scale_by_map(const glsdet_view* x, const glsdet_view* map, const glsdet_view* y, void* stream);

@@ -345,6 +345,23 @@ def patch_conv_nonlocal_adapt_new(sd: SD, p: str, x: Tensor) -> Tensor:
     return _q(spatial_attention(sd, p + ".attention_map", x) * y, p + ".gated")
 
 
+def patch_conv_nonlocal_adapt(sd: SD, p: str, x: Tensor) -> Tensor:
+    """Patch_Conv_NonLocal_adapt (Non_local_family.py:112-206): the adaptive split as above, then per quadrant a stride-2
+    3x3 BaseConv and a non-local block, a 3x3 BaseConv on the re-joined top and bottom parts, channel_conv.  (No gating.)"""
+    att = spatial_attention(sd, p + ".attention_map", x)
+    cx, cyl, cyr = adapt_split(att)
+    q = {}
+    for name, t in (("lt", x[:, :, :cx, :cyl]), ("lb", x[:, :, cx:, :cyr]), ("rt", x[:, :, :cx, cyl:]), ("rb", x[:, :, cx:, cyr:])):
+        t = base_conv(sd, "{}.feat_patchconv_{}".format(p, name), t, 2)
+        q[name] = non_local_block(sd, "{}.feat_patchconv_{}_nonlocal".format(p, name), t)
+    t = base_conv(sd, p + ".feat_patchconv_t", torch.cat((q["lt"], q["rt"]), 3))
+    b = base_conv(sd, p + ".feat_patchconv_b", torch.cat((q["lb"], q["rb"]), 3))
+    both = torch.cat((t, b), 2)
+    if p + ".channel_conv.weight" in sd:
+        return plain_conv(sd, p + ".channel_conv", both)
+    return base_conv(sd, p + ".channel_conv", both)
+
+
 def attention(sd: SD, p: str, x: Tensor) -> Tensor:
     """Attention (Non_local_family.py:254-272): proj_1 1x1 -> exact GELU -> quadrant non-local
     gating unit -> proj_2 1x1 -> + shortcut."""

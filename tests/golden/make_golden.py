@@ -98,7 +98,10 @@ def attention_cases(block):
     from models.new.Non_local_family import Patch_Conv_NonLocal_44
     block("att_pcnl_44", lambda: Patch_Conv_NonLocal_44(32, 64, channel_scale=0.5), (2, 32, 40, 48))
     block("att_pcnl_44_odd", lambda: Patch_Conv_NonLocal_44(16, 32, channel_scale=0.5), (1, 16, 36, 44))
-    from models.new.Non_local_family import Patch_Conv_NonLocal_adapt_new
+    from models.new.Non_local_family import Patch_Conv_NonLocal_adapt, Patch_Conv_NonLocal_adapt_new
+    block("att_pcnl_adapt", lambda: Patch_Conv_NonLocal_adapt(32, 64, channel_scale=1), (2, 32, 24, 36))
+    block("att_pcnl_adapt_nonlinear", lambda: Patch_Conv_NonLocal_adapt(16, 32, channel_scale=1, channel_cat="non_linear"),
+          (3, 16, 32, 28), seed=1)
     block("att_pcnl_adapt_new", lambda: Patch_Conv_NonLocal_adapt_new(32, 64, channel_scale=0.5), (2, 32, 24, 36))
     block("att_pcnl_adapt_new_linear", lambda: Patch_Conv_NonLocal_adapt_new(16, 16, channel_scale=0.5, channel_cat="linear"),
           (3, 16, 30, 22), seed=1)

@@ -27,6 +27,8 @@ ORACLE = {
     "att_spatial_attention": lambda sd, x: O.spatial_attention(sd, "m", x),
     "att_pcnl_44": lambda sd, x: O.patch_conv_nonlocal_44(sd, "m", x),
     "att_pcnl_44_odd": lambda sd, x: O.patch_conv_nonlocal_44(sd, "m", x),
+    "att_pcnl_adapt": lambda sd, x: O.patch_conv_nonlocal_adapt(sd, "m", x),
+    "att_pcnl_adapt_nonlinear": lambda sd, x: O.patch_conv_nonlocal_adapt(sd, "m", x),
     "att_pcnl_adapt_new": lambda sd, x: O.patch_conv_nonlocal_adapt_new(sd, "m", x),
     "att_pcnl_adapt_new_linear": lambda sd, x: O.patch_conv_nonlocal_adapt_new(sd, "m", x),
     "att_darknet_tiny": _dark,
@@ -71,6 +73,8 @@ HIP = {
     "att_pcnl_44_odd": lambda b, x: b.patch_conv_nonlocal_44("m", x),
     "att_pcnl_adapt_new": lambda b, x: b.patch_conv_nonlocal_adapt_new("m", x),
     "att_pcnl_adapt_new_linear": lambda b, x: b.patch_conv_nonlocal_adapt_new("m", x),
+    "att_pcnl_adapt": lambda b, x: b.patch_conv_nonlocal_adapt("m", x),
+    "att_pcnl_adapt_nonlinear": lambda b, x: b.patch_conv_nonlocal_adapt("m", x),
 }
 
 
