@@ -421,11 +421,27 @@ class NetBuilder:
             return self.plain(p + ".channel_conv", Fm, out=out)
         return self.cba(p + ".channel_conv", Fm, out=out)
 
+    def gating_variant(self, p: str) -> str:
+        """Which member of the Patch_Conv_NonLocal family (new/Non_local_family.py:112-421) a checkpoint holds under p,
+        told from its parameter names: the reference swaps them by editing Attention.__init__ (:258), never by a config key."""
+        if self.has(p + ".patchconv_lt_nonlocal.feat_patchconv_lt.conv.weight"):
+            return "44"
+        if self.has(p + ".attention_map.conv.weight"):
+            return "adapt" if self.has(p + ".feat_patchconv_lt.conv.weight") else "adapt_new"
+        return "new"
+
     def attention(self, p: str, x: TView, out: Optional[TView] = None) -> TView:
         """Attention (new/Non_local_family.py:254-272): proj_1 + exact GELU fused in one 1x1
-        GEMM epilogue, gating unit, proj_2 with the shortcut add fused as the residual."""
+        GEMM epilogue, gating unit, proj_2 with the shortcut add fused as the residual.  The gating unit is the
+        reference's Patch_Conv_NonLocal_new unless the checkpoint holds one of its shape-preserving siblings."""
         t = self.plain(p + ".proj_1", x, act="gelu")
-        t = self.patch_conv_nonlocal_new(p + ".spatial_gating_unit", t)
+        kind = self.gating_variant(p + ".spatial_gating_unit")
+        if kind == "adapt_new":
+            t = self.patch_conv_nonlocal_adapt_new(p + ".spatial_gating_unit", t)
+        elif kind == "new":
+            t = self.patch_conv_nonlocal_new(p + ".spatial_gating_unit", t)
+        else:
+            raise ValueError("Attention cannot gate with Patch_Conv_NonLocal_%s: it halves the map (use it as a neck block)" % kind)
         return self.plain(p + ".proj_2", t, out=out, res=x)
 
     def spatial_attention(self, p: str, x: TView) -> TView:

@@ -190,3 +190,14 @@ def test_adaptive_split_is_found_on_the_device_and_survives_graph_capture(engine
     split2 = list(O.adapt_split(O.spatial_attention(sd, "m.attention_map", r(x2))))
     assert b.last_split.cpu().tolist()[:3] == split2
     assert _err(out.to_nchw(want2.shape[1]).cpu(), want2) <= (5e-5 if mode == "f32" else 2e-2)
+
+
+def test_gating_variant_is_told_from_the_checkpoint_keys(att_golden):
+    """the reference swaps family members by editing Attention.__init__; a checkpoint says which by its names"""
+    from glsdet_amd.nets import NetBuilder
+    want = {"att_pcnl_44": "44", "att_pcnl_adapt": "adapt", "att_pcnl_adapt_new": "adapt_new", "att_pcnl_new_linear": "new"}
+    for name, kind in want.items():
+        sd, _, _ = block_case(att_golden, name)
+        b = NetBuilder.__new__(NetBuilder)
+        b.sd = sd
+        assert b.gating_variant("m") == kind, name
