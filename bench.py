@@ -98,11 +98,11 @@ def resdet_algorithmic(kind, H, W, nc=10, proxies=42):
             conv(ho, wo, planes, planes * 4, 1)
             h, w, cin = ho, wo, planes * 4
         sizes.append((h, w, cin))
-    if kind == "mpdet_gl":          # GLFusionPlugin on C3..C5: 4 quadrant non-local blocks (inter = C/2) + 1x1 channel_conv
-        for (h, w, c) in sizes[1:]:
+    if kind == "mpdet_gl":          # GL-fusion plug-in on C3..C5: Patch_Conv_NonLocal_new(C, C, channel_scale=1): four quadrant
+        for (h, w, c) in sizes[1:]:  # non-local blocks with inter_channels = C (Non_local_family.py:208-228) + 1x1 channel_conv
             hh, hw = h // 2, w // 2
             for (qh, qw) in ((hh, hw), (h - hh, hw), (hh, w - hw), (h - hh, w - hw)):
-                ci = c // 2
+                ci = c
                 for _ in range(3):
                     conv(qh, qw, c, ci, 1)          # theta, phi, g
                 conv(qh, qw, ci, c, 1)              # conv_out
