@@ -10,7 +10,7 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "lib", "libglsdet_hip.so")
-ABI_VERSION = 6
+ABI_VERSION = 7
 CAPTURE_LOCK = threading.RLock()        # hipGraph captures are serialised across host threads
 
 F16, F32 = 0, 1
@@ -48,6 +48,9 @@ _SIGS = {
     "glsdet_conv2d_chain": (C.c_int, [C.POINTER(ConvDesc), C.POINTER(ConvChain), C.c_void_p]),
     "glsdet_conv2d_chain_tune": (C.c_int, [C.POINTER(ConvDesc), C.POINTER(ConvChain), C.c_void_p, C.POINTER(C.c_int32),
                                            C.POINTER(C.c_float)]),
+    "glsdet_bottleneck": (C.c_int, [C.POINTER(ConvDesc), C.POINTER(ConvDesc), C.c_int32, C.c_void_p]),
+    "glsdet_bottleneck_tune": (C.c_int, [C.POINTER(ConvDesc), C.POINTER(ConvDesc), C.c_void_p, C.POINTER(C.c_int32),
+                                         C.POINTER(C.c_float)]),
     "glsdet_conv2d": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
     "glsdet_conv2d_multi": (C.c_int, [C.POINTER(ConvDesc), C.c_int32, C.c_void_p]),
     "glsdet_conv2d_multi_tune": (C.c_int, [C.POINTER(ConvDesc), C.c_int32, C.c_void_p, C.POINTER(C.c_int32),

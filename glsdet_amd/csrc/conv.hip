@@ -841,6 +841,74 @@ extern "C" int glsdet_conv2d_chain(const glsdet_conv_desc* d, const glsdet_conv_
   return submit(std::move(op), stream);
 }
 
+// Bottleneck front: the 1x1 (c1) recomputed on the halo of the 3x3 (c2) in one launch (conv_bneck.hip)
+static int build_bneck_op(const glsdet_conv_desc* c1, const glsdet_conv_desc* c2, int hint, OpRecord& op) {
+  if (!c1 || !c2) GLS_FAIL(GLSDET_E_ARG, "bottleneck: null descriptor");
+  BneckArgs b;
+  ConvArgs a1;
+  double f1, b1, f2, b2;
+  int rc;
+  if ((rc = make_conv_args(c1, 0, a1, &f1, &b1))) return rc;
+  if ((rc = make_conv_args(c2, 0, b.c, &f2, &b2))) return rc;
+  const glsdet_view &m1 = c1->y, &m2 = c2->x;
+  if (c1->R != 1 || c1->S != 1 || c1->stride != 1 || c1->pad != 0 || c1->res.base || (c1->act & GLSDET_ACT_RES_FIRST))
+    GLS_FAIL(GLSDET_E_ARG, "bottleneck: the first conv must be a plain 1x1 (stride 1, no padding, no residual)");
+  if (m1.n != m2.n || m1.h != m2.h || m1.w != m2.w || m1.c != m2.c || m1.dtype != m2.dtype)
+    GLS_FAIL(GLSDET_E_ARG, "bottleneck: c1.y and c2.x must describe the same hidden tensor");
+  if (c1->x.dtype != m1.dtype || c2->y.dtype != m1.dtype) GLS_FAIL(GLSDET_E_ARG, "bottleneck: x, the hidden tensor and y share one dtype");
+  // in place is impossible: a workgroup reads the halo of x while its neighbours store their tiles of y
+  const char *xlo = (const char*)c1->x.base, *ylo = (const char*)c2->y.base;
+  const int es = dtype_size(m1.dtype);
+  const int64_t xspan = ((int64_t)(c1->x.n - 1) * c1->x.sn + (int64_t)(c1->x.h - 1) * c1->x.sh + (int64_t)(c1->x.w - 1) * c1->x.sw + c1->x.c) * es;
+  const int64_t yspan = ((int64_t)(c2->y.n - 1) * c2->y.sn + (int64_t)(c2->y.h - 1) * c2->y.sh + (int64_t)(c2->y.w - 1) * c2->y.sw + c2->y.c) * es;
+  if (xlo < ylo + yspan && ylo < xlo + xspan) {
+    // overlapping address ranges are fine only for disjoint channel slices of one pixel-interleaved buffer
+    const bool same_geom = c1->x.sn == c2->y.sn && c1->x.sh == c2->y.sh && c1->x.sw == c2->y.sw;
+    const int64_t d = (ylo - xlo) / es, sw = c1->x.sw;
+    const bool disjoint = same_geom && (d > 0 ? (d >= c1->x.c && d + c2->y.c <= sw) : (d < 0 && -d >= c2->y.c && -d + c1->x.c <= sw));
+    if (!disjoint) GLS_FAIL(GLSDET_E_ARG, "bottleneck: y overlaps x (the fused form cannot run in place)");
+  }
+  ConvArgs& a = b.c;
+  a.x = a1.x; a.x_sn = a1.x_sn; a.x_sh = a1.x_sh; a.x_sw = a1.x_sw;
+  a.x_lo = a1.x_lo; a.x_off = a1.x_off; a.x_bytes = a1.x_bytes; a.x_lin = 0;
+  b.w0 = a1.w; b.scale0 = a1.scale; b.bias0 = a1.bias;
+  b.cin0 = a1.Cin; b.kpad0 = a1.kpad; b.act0 = a1.act; b.w0_bytes = a1.w_bytes;
+  if (glsdet_conv_cout_pad(m1.c) != m1.c) GLS_FAIL(GLSDET_E_ARG, "bottleneck: hidden channels must be a multiple of 32");
+  op.kind = 0;
+  op.flops = f1 + f2;
+  op.bytes = b1 + b2 - 2.0 * (double)a.M * m1.c * es;      // the hidden tensor is neither written nor read
+  if (conv_bneck_try(b, m1.dtype, hint, &op)) GLS_FAIL(GLSDET_E_ARG, "bottleneck: the fused kernel does not apply to this problem");
+  return 0;
+}
+extern "C" int glsdet_bottleneck(const glsdet_conv_desc* c1, const glsdet_conv_desc* c2, int32_t hint, void* stream) {
+  OpRecord op;
+  int rc = build_bneck_op(c1, c2, hint, op);
+  if (rc) return rc;
+  return submit(std::move(op), stream);
+}
+extern "C" int glsdet_bottleneck_tune(const glsdet_conv_desc* c1, const glsdet_conv_desc* c2, void* stream, int32_t* best_hint,
+                                      float* best_us) {
+  if (!best_hint) GLS_FAIL(GLSDET_E_ARG, "bottleneck_tune: null argument");
+  std::vector<OpRecord> ops;
+  std::vector<int> ids;
+  for (int h : {0, 1}) {
+    OpRecord op;
+    if (build_bneck_op(c1, c2, h, op)) continue;
+    if (h == 1 && !ops.empty() && ops[0].name == op.name) continue;    // hint 1 fell back to the same kernel
+    ops.push_back(std::move(op));
+    ids.push_back(h);
+  }
+  float best = 1e30f;
+  int bh = 0, any = 0;
+  int rc = time_variants(ops, ids, (hipStream_t)stream, &bh, &best, &any);
+  if (rc) return rc;
+  if (!any) GLS_FAIL(GLSDET_E_ARG, "bottleneck_tune: the fused kernel does not apply");
+  *best_hint = bh;
+  if (best_us) *best_us = best;
+  set_error("");
+  return 0;
+}
+
 // Measure every kernel/tile variant that applies to this exact problem on the device (its
 // real buffers; launches immediately, never recorded) and report the fastest hint.  Build-time
 // only: it synchronises.  The conv writes its real output, so callers tune before the first

@@ -52,6 +52,17 @@ struct ConvArgs {
   unsigned w2_bytes;
 };
 
+// Bottleneck front (glsdet_bottleneck, conv_bneck.hip): `c` describes the 3x3 (weights, epilogue, output, residual,
+// Cin = hidden channels) except that its x fields address the INPUT of the 1x1 that produces the 3x3's input on the fly.
+struct BneckArgs {
+  ConvArgs c;
+  const unsigned char* w0;    // packed 1x1 weights [cout_pad(hidden)][kpad0]
+  const float* scale0;
+  const float* bias0;
+  int cin0, kpad0, act0;
+  unsigned w0_bytes;
+};
+
 // host: mul, sh with floor(n / d) == umulhi(n, mul) >> sh for 0 <= n < 2^31, 2 <= d < 2^31; d == 1 -> sh = -1
 inline void gls_fastdiv(int d, unsigned* mul, int* sh) {
   if (d <= 1) { *mul = 0; *sh = -1; return; }
@@ -429,6 +440,8 @@ __device__ __forceinline__ void halo_store_and_chain(unsigned char* smem, const 
 
 // host-side dispatch of the halo kernel (conv_halo.hip); returns 1 if it does not apply
 int conv_halo_try(const ConvArgs& a, int xdt, int ydt, int hint, OpRecord* op);
+// fused Bottleneck front (conv_bneck.hip); hint 0 / 1 = 128- / 64-byte channel chunks; returns 1 if it does not apply
+int conv_bneck_try(const BneckArgs& b, int dt, int hint, OpRecord* op);
 // weight-stationary persistent 1x1 kernel (conv1x1.hip), tile_hint 3; returns 1 if it does not apply
 int conv1x1_ws_try(const ConvArgs& a, int xdt, int ydt, OpRecord* op);
 

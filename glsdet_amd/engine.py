@@ -307,6 +307,56 @@ class Engine:
                                        "differ": float((a != b).float().mean())})
         return ok
 
+    def bottleneck(self, x: TView, packed1, act1: str, packed2, act2: str, out: TView, res: Optional[TView],
+                   hidden: TView) -> bool:
+        """y = act2(conv3x3(act1(conv1x1(x)))) (+ res) in ONE launch (glsdet_bottleneck): the 1x1 is recomputed on the
+        halo of the 3x3's tiles and the hidden tensor never exists in memory.  `out` must not alias x.  Returns False,
+        having launched nothing, when the fused kernel does not apply or (autotune) does not beat the two tuned launches
+        it replaces; `hidden` is the scratch tensor the comparison (and the caller's fallback) uses."""
+        w1, s1, b1, cm, R1, S1 = packed1
+        w2, s2, b2, cout, R2, S2 = packed2
+        if (R1, S1, R2, S2) != (1, 1, 3, 3) or cm != cout or cm not in (32, 64, 128) or x.dtype != out.dtype:
+            return False
+        hid = hidden
+        d1, d2 = ConvDesc(), ConvDesc()
+        d1.x, d1.y, d1.res = x.as_c(), hid.as_c(), View()
+        d1.w, d1.scale, d1.bias = w1.data_ptr(), s1.data_ptr(), b1.data_ptr()
+        d1.R, d1.S, d1.stride, d1.pad, d1.act, d1.tile_hint = 1, 1, 1, 0, ACT[act1], 0
+        d2.x, d2.y = hid.as_c(), out.as_c()
+        d2.res = res.as_c() if res is not None else View()
+        d2.w, d2.scale, d2.bias = w2.data_ptr(), s2.data_ptr(), b2.data_ptr()
+        d2.R, d2.S, d2.stride, d2.pad, d2.act, d2.tile_hint = 3, 3, 1, 1, ACT[act2], 0
+        st = _stream_ptr(self.stream)
+        hint = 0
+        if self.autotune:
+            key = ("bneck", x.n, x.h, x.w, x.c, x.sn, x.sh, x.sw, cm, out.sn, out.sh, out.sw, res is not None, out.dtype)
+            if key not in self._tuned:
+                best, us = C.c_int32(0), C.c_float(0)
+                hint = best.value if self.lib.glsdet_bottleneck_tune(C.byref(d1), C.byref(d2), st, C.byref(best), C.byref(us)) == 0 else -1
+                if hint >= 0:
+                    hint = best.value
+                    # against the two launches it replaces, each tuned on its own
+                    h1, u1, h2, u2 = C.c_int32(0), C.c_float(0), C.c_int32(0), C.c_float(0)
+                    if self.lib.glsdet_conv2d_tune(C.byref(d1), st, C.byref(h1), C.byref(u1)) == 0 and \
+                            self.lib.glsdet_conv2d_tune(C.byref(d2), st, C.byref(h2), C.byref(u2)) == 0 and \
+                            us.value > 0.97 * (u1.value + u2.value) and not os.environ.get("GLSDET_FORCE_BNECK"):
+                        hint = -1
+                self._tuned[key] = hint
+                self._tune_dirty = True
+            hint = self._tuned[key]
+            if hint < 0:
+                return False
+        ok = self.lib.glsdet_bottleneck(C.byref(d1), C.byref(d2), hint, st) == 0
+        if ok and self.shadow is not None:      # against the two-launch form on the same operands: bit for bit
+            ref = self.tensor(out.n, out.h, out.w, out.c, out.dtype)
+            self.conv(x, packed1, 1, 0, act1, out=hidden, tile_hint=1)
+            self.conv(hidden, packed2, 1, 1, act2, out=ref, res=res, tile_hint=1)
+            a, b = out.to_nchw(), ref.to_nchw()
+            self.shadow["log"].append({"shape": (x.n, out.h, out.w, cm, cm, 3, 3), "scale": float(a.abs().max()),
+                                       "err": float((a - b).abs().max()), "nan": bool(torch.isnan(a).any()),
+                                       "differ": float((a != b).float().mean())})
+        return ok
+
     def conv_multi(self, xs: Sequence[TView], packs, stride: int, pad: int, act: str,
                    outs: Optional[Sequence[Optional[TView]]] = None, ress: Optional[Sequence[Optional[TView]]] = None,
                    out_dtype: Optional[int] = None, tile_hint: int = 0) -> List[TView]:

@@ -168,14 +168,41 @@ class NetBuilder:
         return t
 
     def csp(self, p: str, x: TView, shortcut: bool, out: Optional[TView] = None) -> TView:
-        """CSPLayer (darknet.py:66-112).  Every 1x1 `m.i.conv1` rides in the launch of the conv that produces its input
-        (conv1|conv2 for i = 0, Bottleneck i-1's 3x3 otherwise) where the fused kernel applies: the hidden tensor of a
-        Bottleneck is then written once and the 1x1 costs neither a launch nor a re-read of `a`."""
+        """CSPLayer (darknet.py:66-112).  Where the fused kernel applies and pays, a Bottleneck (1x1 -> 3x3 [+ x],
+        darknet.py:61-64) is ONE launch that recomputes the 1x1 on the 3x3's halo (glsdet_bottleneck): the hidden tensor
+        never reaches memory.  That form cannot run in place, so the main branch ping-pongs between two channel slots
+        P | Q of one buffer [P | short | Q]; conv1|conv2 write [main | short] into [P | short] for an even number of
+        Bottlenecks and, with the two weight blocks swapped, [short | main] into [short | Q] for an odd one, so that the
+        last Bottleneck always lands in P and conv3 reads [P | short] as the reference's torch.cat.
+        Otherwise every 1x1 `m.i.conv1` rides in the launch of the conv that produces its input (conv1|conv2 for i = 0,
+        Bottleneck i-1's 3x3 otherwise) where the chained kernel applies (glsdet_conv2d_chain)."""
         hid = self.conv_out_channels(p + ".conv1")
-        cat = self.e.tensor(x.n, x.h, x.w, 2 * hid)
         n = 0
         while self.has("%s.m.%d.conv1.conv.weight" % (p, n)):
             n += 1
+        # (tracing keeps the unfused form: a trace holds EVERY stored tensor, and the fused form equals it bit for bit)
+        if n and hid in (32, 64, 128) and not os.environ.get("GLSDET_NO_BNECK_FUSION") and self.trace is None and \
+                self.sd["%s.m.0.conv2.conv.weight" % p].shape[-1] == 3 and not self.is_depthwise("%s.m.0.conv2" % p):
+            buf = self.e.tensor(x.n, x.h, x.w, 3 * hid)
+            P, Q = buf.channels(0, hid), buf.channels(2 * hid, 3 * hid)
+            scratch = self.e.tensor(x.n, x.h, x.w, hid)
+            cur, oth = (P, Q) if n % 2 == 0 else (Q, P)
+            probe = lambda i, src, dst: self.e.bottleneck(src, self._pack("%s.m.%d.conv1" % (p, i), [self._bn_part("%s.m.%d.conv1" % (p, i))], hid),
+                                                          "silu", self._pack("%s.m.%d.conv2" % (p, i), [self._bn_part("%s.m.%d.conv2" % (p, i))], hid),
+                                                          "silu", dst, src if shortcut else None, scratch)
+            if n % 2 == 0:
+                self.cba([p + ".conv1", p + ".conv2"], x, out=buf.channels(0, 2 * hid))          # [main | short] -> [P | short]
+            else:
+                self.cba([p + ".conv2", p + ".conv1"], x, out=buf.channels(hid, 3 * hid))        # [short | main] -> [short | Q]
+            for i in range(n):
+                if not probe(i, cur, oth):
+                    t = self.cba("%s.m.%d.conv1" % (p, i), cur, out=scratch)
+                    self.cba("%s.m.%d.conv2" % (p, i), t, out=oth, res=cur if shortcut else None)
+                else:
+                    self._rec("%s.m.%d.conv2" % (p, i), oth, 0, hid)
+                cur, oth = oth, cur
+            return self.cba(p + ".conv3", buf.channels(0, 2 * hid), out=out)
+        cat = self.e.tensor(x.n, x.h, x.w, 2 * hid)
         t = self._cba_chain([p + ".conv1", p + ".conv2"], x, "%s.m.0.conv1" % p, hid, cat) if n else None
         if t is None:
             self.cba([p + ".conv1", p + ".conv2"], x, out=cat)          # [main | short]

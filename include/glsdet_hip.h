@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GLSDET_ABI_VERSION 6
+#define GLSDET_ABI_VERSION 7
 
 enum { GLSDET_F16 = 0, GLSDET_F32 = 1 };
 enum { GLSDET_ACT_NONE = 0, GLSDET_ACT_SILU = 1, GLSDET_ACT_RELU = 2, GLSDET_ACT_LRELU = 3,
@@ -123,6 +123,16 @@ typedef struct glsdet_conv_chain {
 int     glsdet_conv2d_chain(const glsdet_conv_desc* d, const glsdet_conv_chain* c, void* stream);
 int     glsdet_conv2d_chain_tune(const glsdet_conv_desc* d, const glsdet_conv_chain* c, void* stream, int32_t* best_hint,
                                  float* best_us);
+/* Bottleneck front in ONE launch (drone/models/base/darknet.py:61-64 `y = self.conv2(self.conv1(x)); if self.use_add:
+ * y = y + x`): c1 = the 1x1 (c1->y describes the hidden tensor; its base is not touched), c2 = the 3x3 stride 1 pad 1 on
+ * that hidden tensor (c2->x must equal c1->y in extent and dtype), with c2's residual / activation as for glsdet_conv2d.
+ * The workgroup of an 8 x 16 output tile recomputes the 1x1 on the tile's halo into LDS; the hidden values are rounded
+ * to the storage dtype there, so y equals the two-launch form bit for bit.  Limits: hidden channels 32, 64 or 128 ==
+ * c2->y.c; one dtype; y must not overlap x other than as a disjoint channel slice of the same pixel-interleaved buffer
+ * (the fused form cannot run in place: GLSDET_E_ARG).  hint 0 / 1: 128- / 64-byte channel chunks.                      */
+int     glsdet_bottleneck(const glsdet_conv_desc* c1, const glsdet_conv_desc* c2, int32_t hint, void* stream);
+int     glsdet_bottleneck_tune(const glsdet_conv_desc* c1, const glsdet_conv_desc* c2, void* stream, int32_t* best_hint,
+                               float* best_us);
 /* Depthwise k x k conv + folded BN + act (`dconv` of DWConv, drone/models/base/baseConv.py:22-30;
  * mmcv DepthwiseSeparableConvModule).  Same descriptor; x.c == y.c; w = [R*S][x.c] elements of
  * x.dtype (tap-major), scale/bias fp32 [x.c]; res must be empty. */

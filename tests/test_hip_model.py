@@ -445,6 +445,7 @@ def test_csp_with_chained_1x1_equals_the_unfused_launches_bit_for_bit(engines, m
     sd = synth_state_dict(t, 5)
     x = synth_input((2, 2 * hid, hw[0], hw[1]), 9)
     outs, nops = [], []
+    monkeypatch.setenv("GLSDET_NO_BNECK_FUSION", "1")          # (the fused Bottleneck would take these layers: next test)
     for no_chain in (True, False):
         if no_chain:
             monkeypatch.setenv("GLSDET_NO_CHAIN", "1")
@@ -461,3 +462,87 @@ def test_csp_with_chained_1x1_equals_the_unfused_launches_bit_for_bit(engines, m
     assert float((outs[0] - want).abs().max()) <= (5e-5 if mode == "f32" else 2e-2) * max(1.0, float(want.abs().max()))
     assert torch.equal(outs[0], outs[1])
     assert nops[1] == nops[0] - n, nops
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["f32", "f16"])
+@pytest.mark.parametrize("hid,n,shortcut,hw", [(32, 1, True, (20, 24)), (64, 3, True, (19, 23)), (128, 3, True, (12, 21)),
+                                              (128, 1, False, (9, 10)), (64, 2, False, (33, 17)), (32, 2, True, (41, 70)),
+                                              (64, 1, True, (8, 16)), (64, 1, False, (7, 5))])
+def test_csp_with_fused_bottlenecks_equals_the_unfused_launches_bit_for_bit(engines, monkeypatch, mode, hid, n, shortcut, hw):
+    """CSPLayer with every Bottleneck as ONE launch (glsdet_bottleneck: the 1x1 recomputed on the halo of the 3x3's tiles,
+    the hidden tensor only in LDS) vs the same layer as separate launches: identical bits in both precisions (the hidden
+    values are rounded as a stored tensor would be, both products run in the stand-alone k order; the zero padding of
+    the 3x3 is applied to the HIDDEN tensor), n fewer launches.  Ragged maps, one tile, several tiles, odd / even n
+    (the main branch ping-pongs between two channel slots and must land left of the short branch)."""
+    from glsdet_amd.arch import _Table
+    from glsdet_amd.nets import NetBuilder
+    from glsdet_amd.synth import synth_input, synth_state_dict
+    eng = engines[mode]
+    t = _Table()
+    t.csp("m", 2 * hid, 2 * hid, n, False)
+    sd = synth_state_dict(t, 5)
+    x = synth_input((2, 2 * hid, hw[0], hw[1]), 9)
+    outs, nops = [], []
+    monkeypatch.setenv("GLSDET_NO_CHAIN", "1")
+    for unfused in (True, False):
+        if unfused:
+            monkeypatch.setenv("GLSDET_NO_BNECK_FUSION", "1")
+        else:
+            monkeypatch.delenv("GLSDET_NO_BNECK_FUSION", raising=False)
+        plan = eng.new_plan()
+        with plan:
+            out = NetBuilder(eng, sd).csp("m", _upload(eng, x), shortcut)
+        plan.run()
+        torch.cuda.synchronize()
+        outs.append(out.to_nchw().cpu())
+        nops.append(plan.num_ops)
+    want = O.csp_layer(sd, "m", x if mode == "f32" else x.half().float(), shortcut)
+    assert float((outs[0] - want).abs().max()) <= (5e-5 if mode == "f32" else 2e-2) * max(1.0, float(want.abs().max()))
+    assert torch.equal(outs[0], outs[1])
+    assert nops[1] == nops[0] - n, nops
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["f32", "f16"])
+@pytest.mark.parametrize("cin0,cm,hw,res,hint", [(64, 64, (30, 37), True, 0), (64, 64, (30, 37), True, 1), (128, 64, (17, 16), False, 0),
+                                                 (32, 32, (25, 50), True, 0), (128, 128, (16, 33), True, 0), (128, 128, (16, 33), False, 1),
+                                                 (256, 128, (9, 17), False, 0), (64, 32, (8, 16), True, 0)])
+def test_bottleneck_entry_point_equals_two_convs_bit_for_bit(engines, mode, cin0, cm, hw, res, hint):
+    """glsdet_bottleneck against glsdet_conv2d twice on the same operands (generic kernel), bit for bit: 1x1 inputs wider
+    than the hidden tensor (several channel chunks in phase A), both chunk sizes, with and without the residual; and
+    the in-place call is refused."""
+    import ctypes as C
+    from glsdet_amd._lib import ConvDesc, View
+    from glsdet_amd.engine import ACT, _stream_ptr
+    eng = engines[mode]
+    g = torch.Generator().manual_seed(cin0 * 131 + cm + hw[0])
+    x = torch.randn(2, cin0, hw[0], hw[1], generator=g)
+    w1 = torch.randn(cm, cin0, 1, 1, generator=g) / np.sqrt(cin0)
+    w2 = torch.randn(cm, cm, 3, 3, generator=g) / np.sqrt(9 * cm)
+    s1, b1 = torch.rand(cm, generator=g) + 0.5, torch.randn(cm, generator=g) * 0.3
+    s2, b2 = torch.rand(cm, generator=g) + 0.5, torch.randn(cm, generator=g) * 0.3
+    p1, p2 = eng.pack_conv([(w1, s1, b1)], cin0), eng.pack_conv([(w2, s2, b2)], cm)
+    xv = _upload(eng, x)
+    rv = _upload(eng, torch.randn(2, cm, hw[0], hw[1], generator=g)) if res else None
+    hid = eng.tensor(2, hw[0], hw[1], cm)
+    ref = eng.conv(eng.conv(xv, p1, 1, 0, "silu", out=hid, tile_hint=1), p2, 1, 1, "silu", res=rv, tile_hint=1)
+    out = eng.tensor(2, hw[0], hw[1], cm)
+
+    def desc(x_, y_, pk, k, res_):
+        d = ConvDesc()
+        d.x, d.y, d.res = x_.as_c(), y_.as_c(), (res_.as_c() if res_ is not None else View())
+        d.w, d.scale, d.bias = pk[0].data_ptr(), pk[1].data_ptr(), pk[2].data_ptr()
+        d.R, d.S, d.stride, d.pad, d.act, d.tile_hint = k, k, 1, k // 2, ACT["silu"], 0
+        return d
+    d1, d2 = desc(xv, hid, p1, 1, None), desc(hid, out, p2, 3, rv)
+    rc = eng.lib.glsdet_bottleneck(C.byref(d1), C.byref(d2), hint, _stream_ptr(eng.stream))
+    if mode == "f32" and cm == 128 and hint == 0:
+        pass                                            # (served by the 64-byte-chunk form)
+    assert rc == 0, eng.lib.glsdet_last_error().decode()
+    torch.cuda.synchronize()
+    assert torch.equal(out.to_nchw().cpu(), ref.to_nchw().cpu())
+    if cin0 == cm:                                      # in place: refused, nothing launched
+        d2b = desc(hid, xv, p2, 3, rv)
+        assert eng.lib.glsdet_bottleneck(C.byref(d1), C.byref(d2b), hint, _stream_ptr(eng.stream)) != 0
+        assert "in place" in eng.lib.glsdet_last_error().decode()
