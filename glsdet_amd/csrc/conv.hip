@@ -33,7 +33,10 @@ constexpr int conv_lds_bytes(bool wide) {        // wide: fp32 staging of an fp1
 // UT ("uniform tap"): Cin * sizeof(T) is a multiple of KB, so all chunks of a K step belong to ONE
 // filter tap and the tap walk (kr, ks, channel base) is scalar: a K step then costs one VALU add
 // per 16-byte chunk (plus the padding test when the conv pads) instead of ~10.
-template <typename T, typename TO, int CO_T, int PX_T, int KB, int WCO, bool UT>
+// CH: the chained 1x1 (glsdet_conv2d_chain) is compiled in.  A flag, not a runtime branch: with the chain code present
+// every instantiation carried its accumulators and staged chunks (64x64 tile: 60 -> 89 VGPRs, 6 -> 3 waves per SIMD;
+// the 128-row halo kernels 82-118 -> 238), which cost the plain launches 5-20 % (round 2 regression, found in the op table).
+template <typename T, typename TO, int CO_T, int PX_T, int KB, int WCO, bool UT, bool CH = false>
 __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid, const int nwg) {
   constexpr int RS = KB + 16;                    // LDS row stride, bytes
   constexpr int VEC = 16 / (int)sizeof(T);       // elements per 16-B chunk
@@ -278,13 +281,13 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
   constexpr int VO = 16 / (int)sizeof(TO);
   constexpr int OCPR = CO_T / VO;                // 16-B chunks per pixel row of the tile
   // chained 1x1 (glsdet_conv2d_chain): only the workgroup whose cout tile holds the chained conv's input channels
-  const bool chain = sizeof(T) == sizeof(TO) && a.w2 != nullptr && co0 <= a.c2_0 && a.c2_0 + a.cin2 <= co0 + CO_T;
+  const bool chain = CH && sizeof(T) == sizeof(TO) && a.w2 != nullptr && co0 <= a.c2_0 && a.c2_0 + a.cin2 <= co0 + CO_T;
   auto y2pix = [&](int px_l, bool& ok) -> long {
     const int p = px0 + px_l;
     ok = p < a.M;
     return ok ? gls_pix_off(p, HoWo, a.Wo, a.y2_sn, a.y2_sh, a.y2_sw, a.y2_lin, a) : 0;
   };
-  if constexpr (sizeof(T) == sizeof(TO)) if (chain && a.res) {
+  if constexpr (CH && sizeof(T) == sizeof(TO)) if (chain && a.res) {
     // the FINAL tile (after the residual) must stand in LDS for the chained product: pass 1 computes every chunk in
     // registers (and stores it to y), pass 2 writes the chunks back in the TO row layout
     constexpr int NITC = (PX_T * OCPR + 255) / 256;
@@ -373,7 +376,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
         *reinterpret_cast<u32x4*>(a.y + yo * (long)sizeof(TO)) = v;
       }
     }
-    if constexpr (sizeof(T) == sizeof(TO)) {
+    if constexpr (CH && sizeof(T) == sizeof(TO)) {
       if (chain) chain_1x1<T, CO_T, PX_T>(a, smem, smem + PX_T * ORS, co0, tid, y2pix);
     }
     return;
@@ -409,14 +412,14 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
       }
     }
   }
-  if constexpr (sizeof(T) == sizeof(TO)) {
+  if constexpr (CH && sizeof(T) == sizeof(TO)) {
     if (chain) chain_1x1<T, CO_T, PX_T>(a, smem, smem + PX_T * ORS, co0, tid, y2pix);      // (chain && res returned above)
   }
 }
 
-template <typename T, typename TO, int CO_T, int PX_T, int KB, int WCO, bool UT>
+template <typename T, typename TO, int CO_T, int PX_T, int KB, int WCO, bool UT, bool CH = false>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
-  conv_igemm_body<T, TO, CO_T, PX_T, KB, WCO, UT>(a, blockIdx.x, gridDim.x);
+  conv_igemm_body<T, TO, CO_T, PX_T, KB, WCO, UT, CH>(a, blockIdx.x, gridDim.x);
 }
 
 // Several independent convolutions of the SAME shape class (kernel size, stride, channels, dtypes:
@@ -440,12 +443,16 @@ __global__ __launch_bounds__(256) void conv_igemm_multi_kernel(const ConvArgsN m
 }
 
 // ---- host side --------------------------------------------------------------------------
-template <typename T, typename TO, int CO_T, int PX_T, int KB, int WCO, bool UT>
+template <typename T, typename TO, int CO_T, int PX_T, int KB, int WCO, bool UT, bool CH = false>
 static int launch_conv(const ConvArgs& a, hipStream_t st) {
+  if constexpr (!CH && UT && CO_T >= 64 && sizeof(T) == sizeof(TO)) {
+    if (a.w2) return launch_conv<T, TO, CO_T, PX_T, KB, WCO, UT, true>(a, st);
+  }
+  if (a.w2 && !CH) GLS_FAIL(GLSDET_E_ARG, "conv2d_chain: this tile of the generic kernel has no chained form");
   int lds = conv_lds_bytes<CO_T, PX_T, KB, TO>(a.res != nullptr);
   if (a.w2 && chain_lds_bytes<T>(CO_T, PX_T, a) > lds) lds = chain_lds_bytes<T>(CO_T, PX_T, a);
   static int attr_lds = 64 * 1024;
-  auto kern = conv_igemm_kernel<T, TO, CO_T, PX_T, KB, WCO, UT>;
+  auto kern = conv_igemm_kernel<T, TO, CO_T, PX_T, KB, WCO, UT, CH>;
   const int want_attr = lds > conv_lds_bytes<CO_T, PX_T, KB, TO>(true) ? lds : conv_lds_bytes<CO_T, PX_T, KB, TO>(true);
   if (want_attr > attr_lds) {
     GLS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, want_attr));

@@ -124,8 +124,34 @@ __global__ __launch_bounds__(256) void conv1x1_ws_kernel(const ConvArgs a, const
   __syncthreads();
 
   int ck = 0, ctile = first;    // compute-side position
+  // residual chunks of the tile being multiplied: requested when its LAST k chunk starts (before that step's input loads, so
+  // that waiting for them leaves the newer input loads in flight) and consumed after the staging barrier -- one batched
+  // round trip in the shadow of the MFMAs and the staging instead of one dependent trip per chunk in the store loop
+  // (the 64 -> 256 / 128 -> 512 / 256 -> 1024 expansions of ResNet move 4x more residual + output bytes than input)
+  constexpr int OCPR = CO_T / VEC, NQ = PX_T * OCPR / 256;
+  u32x4 rres[NQ];
+  long ryo[NQ];
+  const int e_cq = tid % OCPR, e_px0 = tid / OCPR;      // my output chunks: pixels e_px0 + j * (256 / OCPR), channel chunk e_cq
+  const bool e_cok = co0 + e_cq * VEC < a.Cout;
+  auto issue_res = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) {
+      const int p = ctile * PX_T + e_px0 + j * (256 / OCPR);
+      rres[j] = u32x4{0u, 0u, 0u, 0u};
+      ryo[j] = -1;
+      if (p < a.M && e_cok) {
+        const int co = co0 + e_cq * VEC;
+        ryo[j] = gls_pix_off(p, HoWo, a.Wo, a.y_sn, a.y_sh, a.y_sw, a.y_lin, a) + co;
+        if (a.res) {
+          const long ro = gls_pix_off(p, HoWo, a.Wo, a.r_sn, a.r_sh, a.r_sw, a.r_lin, a) + co;
+          rres[j] = *reinterpret_cast<const u32x4*>(a.res + ro * (long)sizeof(T));
+        }
+      }
+    }
+  };
   auto step = [&](int c, u32x4 (&nxt)[NB], u32x4 (&freeset)[NB]) __attribute__((always_inline)) {
     // nxt holds chunk c+1; freeset held chunk c (already in LDS): chunk c+4 goes there
+    if (ck == nk - 1) issue_res();
     issue(freeset);
     const unsigned char* bbuf = sB + (c & 1) * (PX_T * RS);
     const int kbase = ck * KB;
@@ -156,27 +182,21 @@ __global__ __launch_bounds__(256) void conv1x1_ws_kernel(const ConvArgs a, const
         }
       }
       __syncthreads();
-      constexpr int OCPR = CO_T / VEC;
-      for (int q = tid; q < PX_T * OCPR; q += 256) {
-        const int px_l = q / OCPR, cq = q - px_l * OCPR;
-        const int p = ctile * PX_T + px_l, co = co0 + cq * VEC;
-        if (p < a.M && co < a.Cout) {
+#pragma unroll
+      for (int j = 0; j < NQ; ++j) {
+        const int px_l = e_px0 + j * (256 / OCPR);
+        if (ryo[j] >= 0) {
+          u32x4 v;
           if (wide) {                      // fp32 staging: residual add in fp32, one rounding
             constexpr int ORSW = CO_T * 4 + 16;
-            const f32x4 lo = *reinterpret_cast<const f32x4*>(sE + px_l * ORSW + cq * 32);
-            const f32x4 hi = *reinterpret_cast<const f32x4*>(sE + px_l * ORSW + cq * 32 + 16);
-            const long ro = gls_pix_off(p, HoWo, a.Wo, a.r_sn, a.r_sh, a.r_sw, a.r_lin, a) + co;
-            const long yo = gls_pix_off(p, HoWo, a.Wo, a.y_sn, a.y_sh, a.y_sw, a.y_lin, a) + co;
-            *reinterpret_cast<u32x4*>(a.y + yo * 2) = add_chunk_wide(lo, hi, *reinterpret_cast<const u32x4*>(a.res + ro * 2), a.act_post);
-            continue;
+            const f32x4 lo = *reinterpret_cast<const f32x4*>(sE + px_l * ORSW + e_cq * 32);
+            const f32x4 hi = *reinterpret_cast<const f32x4*>(sE + px_l * ORSW + e_cq * 32 + 16);
+            v = add_chunk_wide(lo, hi, rres[j], a.act_post);
+          } else {
+            v = *reinterpret_cast<const u32x4*>(sE + px_l * ORS + e_cq * 16);
+            if (a.res) v = add_chunk(v, rres[j], (T*)nullptr, a.act_post);
           }
-          u32x4 v = *reinterpret_cast<const u32x4*>(sE + px_l * ORS + cq * 16);
-          if (a.res) {
-            const long ro = gls_pix_off(p, HoWo, a.Wo, a.r_sn, a.r_sh, a.r_sw, a.r_lin, a) + co;
-            v = add_chunk(v, *reinterpret_cast<const u32x4*>(a.res + ro * (long)sizeof(T)), (T*)nullptr, a.act_post);
-          }
-          const long yo = gls_pix_off(p, HoWo, a.Wo, a.y_sn, a.y_sh, a.y_sw, a.y_lin, a) + co;
-          *reinterpret_cast<u32x4*>(a.y + yo * (long)sizeof(T)) = v;
+          *reinterpret_cast<u32x4*>(a.y + ryo[j] * (long)sizeof(T)) = v;
         }
       }
       ctile += stride;

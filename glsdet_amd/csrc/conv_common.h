@@ -416,10 +416,10 @@ __device__ __forceinline__ void halo_store_tile_keep(unsigned char* stile, const
 
 // epilogue tail shared by the pixel-tile kernels: store the staged tile, then the chained 1x1 if this workgroup's cout tile
 // holds its input channels
-template <typename T, typename TO, int CO_T, int PW>
+template <typename T, typename TO, int CO_T, int PW, bool CH>
 __device__ __forceinline__ void halo_store_and_chain(unsigned char* smem, const ConvArgs& a, int img, int ty0, int tx0, int co0,
                                                      int tid) {
-  if constexpr (sizeof(T) == sizeof(TO)) {
+  if constexpr (CH && sizeof(T) == sizeof(TO)) {
     const bool chain = a.w2 != nullptr && co0 <= a.c2_0 && a.c2_0 + a.cin2 <= co0 + CO_T;
     if (chain) {
       if (a.res) halo_store_tile_keep<TO, CO_T, PW>(smem, a, img, ty0, tx0, co0, tid);

@@ -22,7 +22,7 @@ struct HaloGeom {
   static constexpr int NP = (PH * PW * 8 + 255) / 256;     // 16-B chunks per thread, one patch
 };
 
-template <typename T, typename TO, int CO_T, int WCO, int KS, int TH, int TW>
+template <typename T, typename TO, int CO_T, int WCO, int KS, int TH, int TW, bool CH = false>
 __global__ __launch_bounds__(256) void conv_halo_kernel(const ConvArgs a, const int tiles_x, const int tiles_y) {
   constexpr int KB = 128, RS = KB + 16;
   constexpr int VEC = 16 / (int)sizeof(T);
@@ -218,7 +218,7 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const ConvArgs a, const 
     }
   }
   __syncthreads();
-  halo_store_and_chain<T, TO, CO_T, PW>(smem, a, img, ty0, tx0, co0, tid);
+  halo_store_and_chain<T, TO, CO_T, PW, CH>(smem, a, img, ty0, tx0, co0, tid);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -244,7 +244,7 @@ __device__ __forceinline__ void halo_lds_barrier() {
 // stored DE-INTERLEAVED (even columns first, then the odd ones), so that the 16 pixels of a fragment read, which are two
 // input columns apart, are consecutive LDS rows again: tap (r, s) of output pixel (oy, ox) is slot
 // (2*oy + r) * PW + ox + (s & 1 ? HALF : s >> 1) -- a per-lane base plus a per-tap constant, exactly as for stride 1.
-template <typename T, typename TO, int CO_T, int KS, int RING, int KB = 128, int STR = 1>
+template <typename T, typename TO, int CO_T, int KS, int RING, int KB = 128, int STR = 1, bool CH = false>
 __global__ __launch_bounds__(256) void conv_halo_ring_kernel(const ConvArgs a, const int tiles_x, const int tiles_y) {
   constexpr int TH = 8, TW = 16, WCO = 2;
   constexpr int RS = KB + 16;
@@ -444,18 +444,23 @@ __global__ __launch_bounds__(256) void conv_halo_ring_kernel(const ConvArgs a, c
     }
   }
   __syncthreads();
-  halo_store_and_chain<T, TO, CO_T, PITCH>(smem, a, img, ty0, tx0, co0, tid);
+  halo_store_and_chain<T, TO, CO_T, PITCH, CH>(smem, a, img, ty0, tx0, co0, tid);
 }
 
-template <typename T, typename TO, int CO_T, int KS, int RING, int KB = 128, int STR = 1>
+// (the chained 1x1 exists for 3x3 stride 1 only: a CSP Bottleneck's conv2 -> the next Bottleneck's conv1)
+template <typename T, typename TO, int CO_T, int KS, int RING, int KB = 128, int STR = 1, bool CH = false>
 static int launch_halo_ring(const ConvArgs& a, hipStream_t st) {
+  if constexpr (!CH && KS == 3 && STR == 1) {
+    if (a.w2) return launch_halo_ring<T, TO, CO_T, KS, RING, KB, STR, true>(a, st);
+  }
+  if (a.w2 && !CH) GLS_FAIL(GLSDET_E_ARG, "conv2d_chain: this halo kernel has no chained form");
   constexpr int PH = 7 * STR + KS, PW = 15 * STR + KS;
   constexpr int stage = RING * CO_T * KB + PH * PW * (KB + 16);
   constexpr int epiw = epi_bytes<TO>(CO_T, 128, true), ldsw = stage > epiw ? stage : epiw;
   const int epi = epi_bytes<TO>(CO_T, 128, a.res != nullptr);
   int lds = stage > epi ? stage : epi;
   if (a.w2 && chain_lds_bytes<T>(CO_T, 128, a) > lds) lds = chain_lds_bytes<T>(CO_T, 128, a);
-  auto kern = conv_halo_ring_kernel<T, TO, CO_T, KS, RING, KB, STR>;
+  auto kern = conv_halo_ring_kernel<T, TO, CO_T, KS, RING, KB, STR, CH>;
   static int attr_lds = 64 * 1024;
   const int want_attr = lds > ldsw ? lds : ldsw;
   if (want_attr > attr_lds) {
@@ -485,15 +490,19 @@ static int halo_ring_by_ks(const ConvArgs& a, hipStream_t st) {
   GLS_FAIL(GLSDET_E_ARG, "conv2d(halo ring): unsupported kernel size %d", a.R);
 }
 
-template <typename T, typename TO, int CO_T, int WCO, int KS, int TH, int TW>
+template <typename T, typename TO, int CO_T, int WCO, int KS, int TH, int TW, bool CH = false>
 static int launch_halo(const ConvArgs& a, hipStream_t st) {
+  if constexpr (!CH && KS == 3) {
+    if (a.w2) return launch_halo<T, TO, CO_T, WCO, KS, TH, TW, true>(a, st);
+  }
+  if (a.w2 && !CH) GLS_FAIL(GLSDET_E_ARG, "conv2d_chain: this halo kernel has no chained form");
   constexpr int PH = TH + KS - 1, PW = TW + KS - 1;
   constexpr int stage = 2 * CO_T * 144 + PH * PW * 144;
   constexpr int epiw = epi_bytes<TO>(CO_T, TH * TW, true), ldsw = stage > epiw ? stage : epiw;
   const int epi = epi_bytes<TO>(CO_T, TH * TW, a.res != nullptr);
   int lds = stage > epi ? stage : epi;
   if (a.w2 && chain_lds_bytes<T>(CO_T, TH * TW, a) > lds) lds = chain_lds_bytes<T>(CO_T, TH * TW, a);
-  auto kern = conv_halo_kernel<T, TO, CO_T, WCO, KS, TH, TW>;
+  auto kern = conv_halo_kernel<T, TO, CO_T, WCO, KS, TH, TW, CH>;
   static int attr_lds = 64 * 1024;
   const int want_attr = lds > ldsw ? lds : ldsw;
   if (want_attr > attr_lds) {
@@ -538,6 +547,7 @@ static int halo_ring_k64_by_ks(const ConvArgs& a, hipStream_t st) {
 int conv_halo_try(const ConvArgs& a, int xdt, int ydt, int hint, OpRecord* op) {
   if (hint == 1 || hint == 3 || (hint > 5 && hint != 8 && hint != 9 && hint != 10 && hint != 11)) return 1;          // hint 1 / explicit tile = the generic kernel
   const int es = dtype_size(xdt);
+  if (a.w2 && (a.R != 3 || a.stride != 1)) return 1;      // chained 1x1: compiled into the 3x3 stride-1 forms only
   if (a.stride == 2) {            // 3x3 stride 2: the de-interleaved-patch form of the ring kernel, 64-byte channel chunks
     if (a.R != 3 || a.S != 3 || a.pad != 1 || xdt != ydt || (a.Cin * es) % 64 || (hint != 0 && hint != 10 && hint != 11)) return 1;
     if (hint == 11 && a.cout_pad <= 64) return 1;

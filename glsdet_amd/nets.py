@@ -182,7 +182,7 @@ class NetBuilder:
             n += 1
         # (tracing keeps the unfused form: a trace holds EVERY stored tensor, and the fused form equals it bit for bit)
         if n and hid in (32, 64, 128) and not os.environ.get("GLSDET_NO_BNECK_FUSION") and self.trace is None and \
-                self.sd["%s.m.0.conv2.conv.weight" % p].shape[-1] == 3 and not self.is_depthwise("%s.m.0.conv2" % p):
+                not self.is_depthwise("%s.m.0.conv2" % p) and self.sd["%s.m.0.conv2.conv.weight" % p].shape[-1] == 3:
             buf = self.e.tensor(x.n, x.h, x.w, 3 * hid)
             P, Q = buf.channels(0, hid), buf.channels(2 * hid, 3 * hid)
             scratch = self.e.tensor(x.n, x.h, x.w, hid)
