@@ -712,6 +712,9 @@ static int build_conv_op(const glsdet_conv_desc* d, int hint, OpRecord& op, cons
   if (hint >= 0x10000 && co_t > 32 && a.cout_pad <= co_t / 2) GLS_FAIL(GLSDET_E_ARG, "conv2d: tile %dx%d is mostly padding here", co_t, px_t);
   if (co_t == 0 || (a.w2 && co_t == 32)) GLS_FAIL(GLSDET_E_ARG, "conv2d_chain: no tile of the generic kernel takes this chained problem");
   if (!chain_fits(a, co_t)) GLS_FAIL(GLSDET_E_ARG, "conv2d_chain: the chained input channels straddle two cout tiles of %d", co_t);
+  // the chained form is compiled for K steps that stay inside one filter tap only (dispatch_tile: UT)
+  if (a.w2 && (((long)a.Cin * dtype_size(xdt)) % kb != 0 || getenv("GLSDET_NO_UT") != nullptr))
+    GLS_FAIL(GLSDET_E_ARG, "conv2d_chain: the generic kernel chains only when Cin is a whole number of K steps");
   char nm[112];
   snprintf(nm, sizeof nm, "conv_igemm<%s,%s,%dx%d,kb%d> %dx%d s%d cin%d cout%d%s", xdt ? "f32" : "f16",
            ydt ? "f32" : "f16", co_t, px_t, kb, d->R, d->S, d->stride, x.c, y.c, a.w2 ? " +1x1" : "");
