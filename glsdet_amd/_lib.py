@@ -10,7 +10,7 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "lib", "libglsdet_hip.so")
-ABI_VERSION = 7
+ABI_VERSION = 8
 CAPTURE_LOCK = threading.RLock()        # hipGraph captures are serialised across host threads
 
 F16, F32 = 0, 1
@@ -48,6 +48,10 @@ _SIGS = {
     "glsdet_conv2d_chain": (C.c_int, [C.POINTER(ConvDesc), C.POINTER(ConvChain), C.c_void_p]),
     "glsdet_conv2d_chain_tune": (C.c_int, [C.POINTER(ConvDesc), C.POINTER(ConvChain), C.c_void_p, C.POINTER(C.c_int32),
                                            C.POINTER(C.c_float)]),
+    "glsdet_conv2d_gnstats_bytes": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+    "glsdet_conv2d_gnstats": (C.c_int, [C.POINTER(ConvDesc), C.c_int32, C.c_void_p, C.c_void_p]),
+    "glsdet_conv2d_gnstats_tune": (C.c_int, [C.POINTER(ConvDesc), C.c_int32, C.c_void_p, C.c_void_p, C.POINTER(C.c_int32),
+                                             C.POINTER(C.c_float)]),
     "glsdet_bottleneck": (C.c_int, [C.POINTER(ConvDesc), C.POINTER(ConvDesc), C.c_int32, C.c_void_p]),
     "glsdet_bottleneck_tune": (C.c_int, [C.POINTER(ConvDesc), C.POINTER(ConvDesc), C.c_void_p, C.POINTER(C.c_int32),
                                          C.POINTER(C.c_float)]),
@@ -92,6 +96,9 @@ _SIGS = {
                                    C.c_int32, C.c_void_p, C.c_void_p]),
     "glsdet_groupnorm_multi": (C.c_int, [C.POINTER(View), C.POINTER(View), C.c_int32, C.c_int32, C.POINTER(C.c_void_p),
                                          C.POINTER(C.c_void_p), C.c_float, C.c_int32, C.c_void_p, C.c_void_p]),
+    "glsdet_groupnorm_multi_pre": (C.c_int, [C.POINTER(View), C.POINTER(View), C.c_int32, C.c_int32, C.POINTER(C.c_void_p),
+                                             C.POINTER(C.c_void_p), C.c_float, C.c_int32, C.c_void_p, C.POINTER(C.c_void_p),
+                                             C.c_void_p]),
     "glsdet_proxy_scores": (C.c_int, [C.POINTER(View), C.POINTER(View), C.POINTER(C.c_int32), C.c_int32, C.c_float,
                                       C.POINTER(View), C.c_void_p]),
     "glsdet_gfl_workspace_bytes": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),

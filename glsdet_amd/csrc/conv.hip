@@ -631,6 +631,7 @@ static int make_conv_args(const glsdet_conv_desc* d, int hint, ConvArgs& a, doub
   a.y2_sn = a.y2_sh = a.y2_sw = 0;
   a.c2_0 = a.cin2 = a.cout2 = a.cout2_pad = a.kpad2 = a.act2 = a.y2_lin = 0;
   a.w2_bytes = 0;
+  a.gn_part = nullptr; a.gn_cpg = a.gn_groups = 0;
   const int64_t xalloc = (const char*)x.alloc_hi - (const char*)x.alloc_lo;
   const int64_t wbytes = (int64_t)a.cout_pad * a.kpad * dtype_size(x.dtype);
   if (xalloc >= 0x7fffffffLL || wbytes >= 0x7fffffffLL)
@@ -686,12 +687,28 @@ static bool chain_fits(const ConvArgs& a, int co_t) {
 }
 
 // validate the descriptor and build the op for `hint` (d->tile_hint is ignored here)
-static int build_conv_op(const glsdet_conv_desc* d, int hint, OpRecord& op, const glsdet_conv_chain* chain = nullptr) {
+static int build_conv_op(const glsdet_conv_desc* d, int hint, OpRecord& op, const glsdet_conv_chain* chain = nullptr,
+                         int gn_groups = 0, void* gn_stats = nullptr) {
   ConvArgs a;
   op.kind = 0;
   int rc = make_conv_args(d, hint, a, &op.flops, &op.bytes);
   if (rc) return rc;
   if (chain && (rc = add_chain(d, chain, a, &op.flops, &op.bytes))) return rc;
+  if (gn_stats) {               // glsdet_conv2d_gnstats: GroupNorm partials of the stored output, halo ring kernels only
+    const int vo = 16 / dtype_size(d->y.dtype);
+    if (gn_groups < 1 || d->y.c % gn_groups || (d->y.c / gn_groups) % vo || 64 % (d->y.c / gn_groups) || ((uintptr_t)gn_stats & 7) ||
+        d->x.dtype != d->y.dtype || d->res.base)
+      GLS_FAIL(GLSDET_E_ARG, "conv2d_gnstats: need C %% groups == 0, whole 16-byte chunks per group, 8-byte aligned stats, no residual");
+    a.gn_part = (double*)gn_stats;
+    a.gn_groups = gn_groups;
+    a.gn_cpg = d->y.c / gn_groups;
+    if (hint < 8 || hint > 11) GLS_FAIL(GLSDET_E_ARG, "conv2d_gnstats: tile_hint must name a halo ring kernel (8..11)");
+    if (conv_halo_try(a, d->x.dtype, d->y.dtype, hint, &op) == 0) {
+      op.name += " +gn stats";
+      return 0;
+    }
+    GLS_FAIL(GLSDET_E_ARG, "conv2d_gnstats: the halo ring kernel does not apply to this problem");
+  }
   const glsdet_view &x = d->x, &y = d->y;
   const int xdt = x.dtype, ydt = y.dtype;
   // tile_hint: 0 auto, 1 generic kernel, 2 halo kernel, 4 halo kernel with wave-private weight staging,
@@ -913,6 +930,41 @@ extern "C" int glsdet_bottleneck_tune(const glsdet_conv_desc* c1, const glsdet_c
   int rc = time_variants(ops, ids, (hipStream_t)stream, &bh, &best, &any);
   if (rc) return rc;
   if (!any) GLS_FAIL(GLSDET_E_ARG, "bottleneck_tune: the fused kernel does not apply");
+  *best_hint = bh;
+  if (best_us) *best_us = best;
+  set_error("");
+  return 0;
+}
+
+// conv + GroupNorm partials of its output (the tower convs of gfl_head.py:128-152: conv -> GN -> ReLU): the statistics
+// pass of glsdet_groupnorm reads the tensor once more only to sum it; here the conv's store phase sums what it stores.
+extern "C" int64_t glsdet_conv2d_gnstats_bytes(int32_t n, int32_t ho, int32_t wo, int32_t groups) {
+  if (n < 1 || ho < 1 || wo < 1 || groups < 1) return 0;
+  return (int64_t)n * ((ho + 7) / 8) * ((wo + 15) / 16) * groups * 2 * (int64_t)sizeof(double);
+}
+extern "C" int glsdet_conv2d_gnstats(const glsdet_conv_desc* d, int32_t groups, void* stats, void* stream) {
+  if (!d || !stats) GLS_FAIL(GLSDET_E_ARG, "conv2d_gnstats: null argument");
+  OpRecord op;
+  int rc = build_conv_op(d, d->tile_hint ? d->tile_hint : 8, op, nullptr, groups, stats);
+  if (rc) return rc;
+  return submit(std::move(op), stream);
+}
+extern "C" int glsdet_conv2d_gnstats_tune(const glsdet_conv_desc* d, int32_t groups, void* stats, void* stream, int32_t* best_hint,
+                                          float* best_us) {
+  if (!d || !stats || !best_hint) GLS_FAIL(GLSDET_E_ARG, "conv2d_gnstats_tune: null argument");
+  std::vector<OpRecord> ops;
+  std::vector<int> ids;
+  for (int h : {8, 9, 10, 11}) {
+    OpRecord op;
+    if (build_conv_op(d, h, op, nullptr, groups, stats)) continue;
+    ops.push_back(std::move(op));
+    ids.push_back(h);
+  }
+  float best = 1e30f;
+  int bh = 0, any = 0;
+  int rc = time_variants(ops, ids, (hipStream_t)stream, &bh, &best, &any);
+  if (rc) return rc;
+  if (!any) GLS_FAIL(GLSDET_E_ARG, "conv2d_gnstats_tune: no halo ring kernel applies");
   *best_hint = bh;
   if (best_us) *best_us = best;
   set_error("");

@@ -50,6 +50,10 @@ struct ConvArgs {
   long y2_sn, y2_sh, y2_sw;
   int c2_0, cin2, cout2, cout2_pad, kpad2, act2, y2_lin;
   unsigned w2_bytes;
+  // GroupNorm statistics of the output (glsdet_conv2d_gnstats): per (image, pixel tile, group) the sum and the sum of
+  // squares of the STORED values, fp64, at gn_part[((img * tiles + tile) * gn_groups + group) * 2]; nullptr: none
+  double* gn_part;
+  int gn_cpg, gn_groups;
 };
 
 // Bottleneck front (glsdet_bottleneck, conv_bneck.hip): `c` describes the 3x3 (weights, epilogue, output, residual,
@@ -225,13 +229,59 @@ __device__ __forceinline__ void pix_to_xy16(int pix, int& oy, int& ox) {
 // optional residual.  A thread's chunks are 256 / OCPR pixels apart -- one or two tile rows -- so its addresses advance
 // by a constant: the 64-bit offsets are built once and stepped with one add per chunk (the per-chunk multiplies were
 // ~10 vector instructions each in kernels that PMC shows issue bound), and the loop is fully unrolled.
-template <typename TO, int CO_T, int PW>
+// sum and sum of squares of one stored 16-byte chunk
+__device__ __forceinline__ void gn_chunk_sums(u32x4 v, f16*, float& s1, float& s2) {
+  const f16x8 h = __builtin_bit_cast(f16x8, v);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const float f = (float)h[e];
+    s1 += f;
+    s2 += f * f;
+  }
+}
+__device__ __forceinline__ void gn_chunk_sums(u32x4 v, float*, float& s1, float& s2) {
+  const f32x4 h = __builtin_bit_cast(f32x4, v);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    s1 += h[e];
+    s2 += h[e] * h[e];
+  }
+}
+// GroupNorm partials of a tile (GN instantiations only): every thread owns ONE channel chunk (cq = tid % OCPR) of several
+// pixels; its fp32 sums go through LDS, the first CO_T / cpg threads fold the (256 / OCPR) x (cpg / VO) contributions of
+// their group in a fixed order into fp64 and write the tile's partial.  All 256 threads call it.
+template <typename TO, int CO_T>
+__device__ __forceinline__ void gn_tile_partials(unsigned char* scratch, const ConvArgs& a, int img, int ty0, int tx0, int co0,
+                                                 int tid, float s1, float s2) {
+  constexpr int VO = 16 / (int)sizeof(TO), OCPR = CO_T / VO;
+  __syncthreads();                                // every thread has read its chunks of the staged tile
+  reinterpret_cast<float2*>(scratch)[tid] = float2{s1, s2};
+  __syncthreads();
+  const int cpv = a.gn_cpg / VO;                  // chunks per group
+  if (tid < CO_T / a.gn_cpg && co0 + tid * a.gn_cpg < a.Cout) {
+    double t = 0.0, q = 0.0;
+    for (int r = 0; r < 256 / OCPR; ++r)
+      for (int c = tid * cpv; c < (tid + 1) * cpv; ++c) {
+        const float2 v = reinterpret_cast<const float2*>(scratch)[r * OCPR + c];
+        t += (double)v.x;
+        q += (double)v.y;
+      }
+    const int tiles_x = (a.Wo + 15) / 16, tiles = tiles_x * ((a.Ho + 7) / 8);
+    const int tile = (ty0 >> 3) * tiles_x + (tx0 >> 4);
+    double* o = a.gn_part + (((long)img * tiles + tile) * a.gn_groups + (co0 / a.gn_cpg + tid)) * 2;
+    o[0] = t;
+    o[1] = q;
+  }
+}
+
+template <typename TO, int CO_T, int PW, bool GN = false>
 __device__ __forceinline__ void halo_store_tile(const unsigned char* stile, const ConvArgs& a, int img, int ty0, int tx0, int co0,
                                                 int tid) {
   constexpr int PX_T = 128, ORS = CO_T * (int)sizeof(TO) + 16;
   constexpr int VO = 16 / (int)sizeof(TO);
   constexpr int OCPR = CO_T / VO;                 // chunks per pixel
   constexpr int PXS = 256 / OCPR;                 // pixels between two chunks of one thread (a multiple of 16)
+  float gs1 = 0.f, gs2 = 0.f;                     // (GN) sums over this thread's stored chunks
   if (sizeof(TO) == 2 && a.res) {                 // wide staging (fp32 rows): add in fp32, round once
     constexpr int ORSW = CO_T * 4 + 16;
     for (int q = tid; q < PX_T * OCPR; q += 256) {
@@ -246,8 +296,10 @@ __device__ __forceinline__ void halo_store_tile(const unsigned char* stile, cons
         const u32x4 v = add_chunk_wide(lo, hi, *reinterpret_cast<const u32x4*>(a.res + ro * 2), a.act_post);
         const long yo = (long)img * a.y_sn + (long)ho * a.y_sh + (long)wo * a.y_sw + co;
         *reinterpret_cast<u32x4*>(a.y + yo * 2) = v;
+        if constexpr (GN) gn_chunk_sums(v, (TO*)nullptr, gs1, gs2);
       }
     }
+    if constexpr (GN) gn_tile_partials<TO, CO_T>(const_cast<unsigned char*>(stile), a, img, ty0, tx0, co0, tid, gs1, gs2);
     return;
   }
   if constexpr (PXS % 16 != 0) {                  // fp32 output with 128-row tiles: 8 pixels apart, plain form
@@ -264,8 +316,10 @@ __device__ __forceinline__ void halo_store_tile(const unsigned char* stile, cons
         }
         const long yo = (long)img * a.y_sn + (long)ho * a.y_sh + (long)wo * a.y_sw + co;
         *reinterpret_cast<u32x4*>(a.y + yo * (long)sizeof(TO)) = v;
+        if constexpr (GN) gn_chunk_sums(v, (TO*)nullptr, gs1, gs2);
       }
     }
+    if constexpr (GN) gn_tile_partials<TO, CO_T>(const_cast<unsigned char*>(stile), a, img, ty0, tx0, co0, tid, gs1, gs2);
     return;
   }
   constexpr int NCH = PX_T / (PXS > 0 ? PXS : 1); // chunks per thread
@@ -294,8 +348,10 @@ __device__ __forceinline__ void halo_store_tile(const unsigned char* stile, cons
       }
       const long yo = (odd ? y_o : y_e) + k * ystep;
       *reinterpret_cast<u32x4*>(a.y + yo * (long)sizeof(TO)) = v;
+      if constexpr (GN) gn_chunk_sums(v, (TO*)nullptr, gs1, gs2);
     }
   }
+  if constexpr (GN) gn_tile_partials<TO, CO_T>(const_cast<unsigned char*>(stile), a, img, ty0, tx0, co0, tid, gs1, gs2);
 }
 
 // ---- chained 1x1 conv on the tile a workgroup has just produced (CSPLayer: conv1|conv2 -> m.0.conv1, Bottleneck i ->
@@ -416,9 +472,13 @@ __device__ __forceinline__ void halo_store_tile_keep(unsigned char* stile, const
 
 // epilogue tail shared by the pixel-tile kernels: store the staged tile, then the chained 1x1 if this workgroup's cout tile
 // holds its input channels
-template <typename T, typename TO, int CO_T, int PW, bool CH>
+template <typename T, typename TO, int CO_T, int PW, bool CH, bool GN = false>
 __device__ __forceinline__ void halo_store_and_chain(unsigned char* smem, const ConvArgs& a, int img, int ty0, int tx0, int co0,
                                                      int tid) {
+  if constexpr (GN) {
+    halo_store_tile<TO, CO_T, PW, true>(smem, a, img, ty0, tx0, co0, tid);
+    return;
+  }
   if constexpr (CH && sizeof(T) == sizeof(TO)) {
     const bool chain = a.w2 != nullptr && co0 <= a.c2_0 && a.c2_0 + a.cin2 <= co0 + CO_T;
     if (chain) {

@@ -244,7 +244,7 @@ __device__ __forceinline__ void halo_lds_barrier() {
 // stored DE-INTERLEAVED (even columns first, then the odd ones), so that the 16 pixels of a fragment read, which are two
 // input columns apart, are consecutive LDS rows again: tap (r, s) of output pixel (oy, ox) is slot
 // (2*oy + r) * PW + ox + (s & 1 ? HALF : s >> 1) -- a per-lane base plus a per-tap constant, exactly as for stride 1.
-template <typename T, typename TO, int CO_T, int KS, int RING, int KB = 128, int STR = 1, bool CH = false>
+template <typename T, typename TO, int CO_T, int KS, int RING, int KB = 128, int STR = 1, bool CH = false, bool GN = false>
 __global__ __launch_bounds__(256) void conv_halo_ring_kernel(const ConvArgs a, const int tiles_x, const int tiles_y) {
   constexpr int TH = 8, TW = 16, WCO = 2;
   constexpr int RS = KB + 16;
@@ -444,23 +444,28 @@ __global__ __launch_bounds__(256) void conv_halo_ring_kernel(const ConvArgs a, c
     }
   }
   __syncthreads();
-  halo_store_and_chain<T, TO, CO_T, PITCH, CH>(smem, a, img, ty0, tx0, co0, tid);
+  halo_store_and_chain<T, TO, CO_T, PITCH, CH, GN>(smem, a, img, ty0, tx0, co0, tid);
 }
 
 // (the chained 1x1 exists for 3x3 stride 1 only: a CSP Bottleneck's conv2 -> the next Bottleneck's conv1)
-template <typename T, typename TO, int CO_T, int KS, int RING, int KB = 128, int STR = 1, bool CH = false>
+// and so do the GroupNorm partials (glsdet_conv2d_gnstats: the 3x3 tower convs of GFLHead / MPHead)
+template <typename T, typename TO, int CO_T, int KS, int RING, int KB = 128, int STR = 1, bool CH = false, bool GN = false>
 static int launch_halo_ring(const ConvArgs& a, hipStream_t st) {
-  if constexpr (!CH && KS == 3 && STR == 1) {
-    if (a.w2) return launch_halo_ring<T, TO, CO_T, KS, RING, KB, STR, true>(a, st);
+  if constexpr (!CH && !GN && KS == 3 && STR == 1) {
+    if (a.w2) return launch_halo_ring<T, TO, CO_T, KS, RING, KB, STR, true, false>(a, st);
+    if constexpr (sizeof(T) == sizeof(TO)) {
+      if (a.gn_part) return launch_halo_ring<T, TO, CO_T, KS, RING, KB, STR, false, true>(a, st);
+    }
   }
   if (a.w2 && !CH) GLS_FAIL(GLSDET_E_ARG, "conv2d_chain: this halo kernel has no chained form");
+  if (a.gn_part && !GN) GLS_FAIL(GLSDET_E_ARG, "conv2d_gnstats: this halo kernel has no statistics form");
   constexpr int PH = 7 * STR + KS, PW = 15 * STR + KS;
   constexpr int stage = RING * CO_T * KB + PH * PW * (KB + 16);
   constexpr int epiw = epi_bytes<TO>(CO_T, 128, true), ldsw = stage > epiw ? stage : epiw;
   const int epi = epi_bytes<TO>(CO_T, 128, a.res != nullptr);
   int lds = stage > epi ? stage : epi;
   if (a.w2 && chain_lds_bytes<T>(CO_T, 128, a) > lds) lds = chain_lds_bytes<T>(CO_T, 128, a);
-  auto kern = conv_halo_ring_kernel<T, TO, CO_T, KS, RING, KB, STR, CH>;
+  auto kern = conv_halo_ring_kernel<T, TO, CO_T, KS, RING, KB, STR, CH, GN>;
   static int attr_lds = 64 * 1024;
   const int want_attr = lds > ldsw ? lds : ldsw;
   if (want_attr > attr_lds) {
@@ -548,6 +553,7 @@ int conv_halo_try(const ConvArgs& a, int xdt, int ydt, int hint, OpRecord* op) {
   if (hint == 1 || hint == 3 || (hint > 5 && hint != 8 && hint != 9 && hint != 10 && hint != 11)) return 1;          // hint 1 / explicit tile = the generic kernel
   const int es = dtype_size(xdt);
   if (a.w2 && (a.R != 3 || a.stride != 1)) return 1;      // chained 1x1: compiled into the 3x3 stride-1 forms only
+  if (a.gn_part && (a.R != 3 || a.stride != 1 || hint < 8 || hint > 11 || a.w2 || a.res)) return 1;   // GN partials: ring forms only
   if (a.stride == 2) {            // 3x3 stride 2: the de-interleaved-patch form of the ring kernel, 64-byte channel chunks
     if (a.R != 3 || a.S != 3 || a.pad != 1 || xdt != ydt || (a.Cin * es) % 64 || (hint != 0 && hint != 10 && hint != 11)) return 1;
     if (hint == 11 && a.cout_pad <= 64) return 1;

@@ -119,6 +119,7 @@ struct GnSet {
   const float *gamma, *beta;
   double* partial;
   int H, W, nsplit, chunk, gb;
+  int pstride, pre;             // partial slices per image in `partial`; pre: they were written by the producing conv
 };
 struct GnArgs {
   GnSet s[GLS_GN_SETS];
@@ -133,7 +134,7 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const GnArgs a) {
   __shared__ double s_sum[256], s_sq[256];
   const GnSet& S = a.s[blockIdx.z];
   const int b = blockIdx.y, z = blockIdx.x;
-  if (z >= S.nsplit) return;
+  if (z >= S.nsplit || S.pre) return;
   const int C = a.C, groups = a.groups, W = S.W;
   const int vcols = C / VN, rows = 256 / vcols;
   const int cc = threadIdx.x % vcols, r0 = threadIdx.x / vcols;
@@ -163,7 +164,7 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const GnArgs a) {
         t += s_sum[r * vcols + c];
         q += s_sq[r * vcols + c];
       }
-    double* o = S.partial + (((long)b * GLS_GN_SPLIT + z) * groups + g) * 2;
+    double* o = S.partial + (((long)b * S.pstride + z) * groups + g) * 2;
     o[0] = t;
     o[1] = q;
   }
@@ -183,7 +184,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GnArgs a) {
   if ((int)threadIdx.x < groups) {
     double t = 0.0, q = 0.0;
     for (int z = 0; z < S.nsplit; ++z) {
-      const double* o = S.partial + (((long)b * GLS_GN_SPLIT + z) * groups + threadIdx.x) * 2;
+      const double* o = S.partial + (((long)b * S.pstride + z) * groups + threadIdx.x) * 2;
       t += o[0];
       q += o[1];
     }
@@ -369,9 +370,9 @@ extern "C" int64_t glsdet_groupnorm_workspace_bytes(int32_t n, int32_t groups) {
   return (int64_t)n * GLS_GN_SPLIT * groups * 2 * (int64_t)sizeof(double);
 }
 
-extern "C" int glsdet_groupnorm_multi(const glsdet_view* x, const glsdet_view* y, int32_t n_sets, int32_t groups,
-                                      const float* const* gamma, const float* const* beta, float eps, int32_t act,
-                                      void* stats, void* stream) {
+static int groupnorm_sets(const glsdet_view* x, const glsdet_view* y, int32_t n_sets, int32_t groups,
+                          const float* const* gamma, const float* const* beta, float eps, int32_t act,
+                          void* stats, void* const* pre_stats, void* stream) {
   if (!x || !y || !gamma || !beta || !stats) GLS_FAIL(GLSDET_E_ARG, "groupnorm: null argument");
   if (n_sets < 1 || n_sets > GLS_GN_SETS) GLS_FAIL(GLSDET_E_ARG, "groupnorm: 1..%d sets", GLS_GN_SETS);
   if (act != GLSDET_ACT_NONE && act != GLSDET_ACT_RELU) GLS_FAIL(GLSDET_E_ARG, "groupnorm: act must be none or relu");
@@ -385,6 +386,7 @@ extern "C" int glsdet_groupnorm_multi(const glsdet_view* x, const glsdet_view* y
   a.n = n_sets; a.C = C; a.groups = groups; a.act = act; a.eps = eps;
   const int rows = 256 / (C / vn);
   int max_split = 1, max_gb = 1;
+  bool any_stats = false;
   OpRecord op;
   op.kind = 7;
   op.flops = op.bytes = 0;
@@ -404,28 +406,48 @@ extern "C" int glsdet_groupnorm_multi(const glsdet_view* x, const glsdet_view* y
     S.gamma = gamma[q]; S.beta = beta[q];
     S.partial = (double*)stats + q * per_set;
     S.H = x[q].h; S.W = x[q].w;
+    S.pstride = GLS_GN_SPLIT;
+    S.pre = 0;
     S.nsplit = (N + 255) / 256;
     if (S.nsplit > GLS_GN_SPLIT) S.nsplit = GLS_GN_SPLIT;
+    if (pre_stats && pre_stats[q]) {          // partials per 8 x 16 pixel tile, written by glsdet_conv2d_gnstats
+      if ((uintptr_t)pre_stats[q] & 7) GLS_FAIL(GLSDET_E_ALIGN, "groupnorm: stats must be 8-byte aligned");
+      S.partial = (double*)pre_stats[q];
+      S.pre = 1;
+      S.nsplit = S.pstride = ((x[q].h + 7) / 8) * ((x[q].w + 15) / 16);
+    }
     S.chunk = (N + S.nsplit - 1) / S.nsplit;
     S.gb = (N + rows * 8 - 1) / (rows * 8);
     if (S.gb > 1024) S.gb = 1024;
-    if (S.nsplit > max_split) max_split = S.nsplit;
+    if (!S.pre && S.nsplit > max_split) max_split = S.nsplit;
     if (S.gb > max_gb) max_gb = S.gb;
-    op.bytes += 3.0 * nimg * N * C * dtype_size(dt);
+    if (!S.pre) any_stats = true;
+    op.bytes += (S.pre ? 2.0 : 3.0) * nimg * N * C * dtype_size(dt);
   }
-  op.name = n_sets > 1 ? "groupnorm_multi(stats+apply)" : "groupnorm(stats+apply)";
+  op.name = !any_stats ? "groupnorm_multi(apply; stats by the convs)" : (n_sets > 1 ? "groupnorm_multi(stats+apply)" : "groupnorm(stats+apply)");
   op.launch = [=](hipStream_t st) -> int {
     if (dt == GLSDET_F16) {
-      hipLaunchKernelGGL(gn_stats_kernel<f16>, dim3(max_split, nimg, a.n), dim3(256), 0, st, a);
+      if (any_stats) hipLaunchKernelGGL(gn_stats_kernel<f16>, dim3(max_split, nimg, a.n), dim3(256), 0, st, a);
       hipLaunchKernelGGL(gn_apply_kernel<f16>, dim3(max_gb, nimg, a.n), dim3(256), 0, st, a);
     } else {
-      hipLaunchKernelGGL(gn_stats_kernel<float>, dim3(max_split, nimg, a.n), dim3(256), 0, st, a);
+      if (any_stats) hipLaunchKernelGGL(gn_stats_kernel<float>, dim3(max_split, nimg, a.n), dim3(256), 0, st, a);
       hipLaunchKernelGGL(gn_apply_kernel<float>, dim3(max_gb, nimg, a.n), dim3(256), 0, st, a);
     }
     GLS_HIP(hipGetLastError());
     return 0;
   };
   return submit(std::move(op), stream);
+}
+
+extern "C" int glsdet_groupnorm_multi(const glsdet_view* x, const glsdet_view* y, int32_t n_sets, int32_t groups,
+                                      const float* const* gamma, const float* const* beta, float eps, int32_t act,
+                                      void* stats, void* stream) {
+  return groupnorm_sets(x, y, n_sets, groups, gamma, beta, eps, act, stats, nullptr, stream);
+}
+extern "C" int glsdet_groupnorm_multi_pre(const glsdet_view* x, const glsdet_view* y, int32_t n_sets, int32_t groups,
+                                          const float* const* gamma, const float* const* beta, float eps, int32_t act,
+                                          void* stats, void* const* pre_stats, void* stream) {
+  return groupnorm_sets(x, y, n_sets, groups, gamma, beta, eps, act, stats, pre_stats, stream);
 }
 
 extern "C" int glsdet_groupnorm(const glsdet_view* x, const glsdet_view* y, int32_t groups, const float* gamma,

@@ -696,8 +696,10 @@ class Engine:
                                         eps, ACT[act], ws.data_ptr(), _stream_ptr(self.stream)), "groupnorm")
         return out
 
-    def groupnorm_multi(self, xs: Sequence[TView], groups: int, gammas, betas, eps: float, act: str = "relu") -> List[TView]:
-        """In place on each x: up to 16 tensors of the same n / C per launch pair."""
+    def groupnorm_multi(self, xs: Sequence[TView], groups: int, gammas, betas, eps: float, act: str = "relu",
+                        pre=None) -> List[TView]:
+        """In place on each x: up to 16 tensors of the same n / C per launch pair.  pre[i]: the partial sums the conv
+        that produced xs[i] already wrote (Engine.conv_gnstats), or None."""
         done = 0
         while done < len(xs):
             part = list(range(done, min(done + 16, len(xs))))
@@ -706,10 +708,52 @@ class Engine:
             xa = (View * n)(*[xs[i].as_c() for i in part])
             ga = (C.c_void_p * n)(*[gammas[i].data_ptr() for i in part])
             ba = (C.c_void_p * n)(*[betas[i].data_ptr() for i in part])
-            check(self.lib.glsdet_groupnorm_multi(xa, xa, n, groups, ga, ba, eps, ACT[act], ws.data_ptr(),
-                                                  _stream_ptr(self.stream)), "groupnorm_multi")
+            if pre is not None and any(pre[i] is not None for i in part):
+                pa = (C.c_void_p * n)(*[(pre[i].data_ptr() if pre[i] is not None else None) for i in part])
+                check(self.lib.glsdet_groupnorm_multi_pre(xa, xa, n, groups, ga, ba, eps, ACT[act], ws.data_ptr(), pa,
+                                                          _stream_ptr(self.stream)), "groupnorm_multi_pre")
+            else:
+                check(self.lib.glsdet_groupnorm_multi(xa, xa, n, groups, ga, ba, eps, ACT[act], ws.data_ptr(),
+                                                      _stream_ptr(self.stream)), "groupnorm_multi")
             done += n
         return list(xs)
+
+    def conv_gnstats(self, x: TView, packed, pad: int, groups: int, out: Optional[TView] = None):
+        """3x3 stride-1 conv (no activation: GroupNorm follows) that also writes the GroupNorm partial sums of its output
+        (glsdet_conv2d_gnstats).  -> (y, stats) or (y, None) when no statistics form applies or (autotune) the plain conv
+        is faster by more than the statistics pass costs -- y is then produced by Engine.conv."""
+        wdev, sdev, bdev, cout, R, S = packed
+        if out is None:
+            out = self.tensor(x.n, x.h + 2 * pad - R + 1, x.w + 2 * pad - S + 1, cout)
+        if (R, S, pad) != (3, 3, 1) or x.dtype != out.dtype or os.environ.get("GLSDET_NO_GN_FUSION"):
+            return self.conv(x, packed, 1, pad, "none", out=out), None
+        stats = self.raw(self.lib.glsdet_conv2d_gnstats_bytes(out.n, out.h, out.w, groups))
+        d = ConvDesc()
+        d.x, d.y, d.res = x.as_c(), out.as_c(), View()
+        d.w, d.scale, d.bias = wdev.data_ptr(), sdev.data_ptr(), bdev.data_ptr()
+        d.R, d.S, d.stride, d.pad, d.act, d.tile_hint = 3, 3, 1, 1, ACT["none"], 8
+        st = _stream_ptr(self.stream)
+        if self.autotune:
+            key = ("gnstats", x.n, x.h, x.w, x.c, x.sn, x.sh, x.sw, out.c, out.sn, out.sh, out.sw, groups, out.dtype)
+            if key not in self._tuned:
+                best, us = C.c_int32(0), C.c_float(0)
+                hint = -1
+                if self.lib.glsdet_conv2d_gnstats_tune(C.byref(d), groups, stats.data_ptr(), st, C.byref(best), C.byref(us)) == 0:
+                    hint = best.value
+                    # against the plain conv's best variant + the statistics pass it saves (one read of the output at ~4 TB/s)
+                    b1, u1 = C.c_int32(0), C.c_float(0)
+                    d.tile_hint = 0
+                    saved = out.n * out.h * out.w * out.c * _ESIZE[out.dtype] / 4e6
+                    if self.lib.glsdet_conv2d_tune(C.byref(d), st, C.byref(b1), C.byref(u1)) == 0 and us.value > u1.value + saved:
+                        hint = -1
+                self._tuned[key] = hint
+                self._tune_dirty = True
+            if self._tuned[key] < 0:
+                return self.conv(x, packed, 1, pad, "none", out=out), None
+            d.tile_hint = self._tuned[key]
+        if self.lib.glsdet_conv2d_gnstats(C.byref(d), groups, stats.data_ptr(), st) != 0:
+            return self.conv(x, packed, 1, pad, "none", out=out), None
+        return out, stats
 
     def proxy_scores(self, feat: TView, dots: TView, counts: Sequence[int], gamma: float,
                      out: Optional[TView] = None) -> TView:

@@ -248,17 +248,24 @@ class ResDetBuilder:
         groups += [small[i:i + step] for i in range(0, len(small), step)]
         return groups
 
-    def _conv_levels(self, xs: Sequence[TView], packs, pad: int, out_dtype=None, per_level: int = 1) -> List[TView]:
+    def _conv_levels(self, xs: Sequence[TView], packs, pad: int, out_dtype=None, per_level: int = 1, gn_groups: int = 0):
         """One conv per entry (entries ordered level-major, `per_level` consecutive entries per level),
-        grouped over the small levels."""
+        grouped over the small levels.  gn_groups > 0: a GroupNorm of that many groups follows; the convs of the big
+        levels then also write its partial sums (Engine.conv_gnstats) and (outs, stats) is returned, stats[i] None where
+        the GroupNorm still has to sum the tensor itself."""
         L = len(xs) // per_level
         outs: List[Optional[TView]] = [None] * len(xs)
+        stats: List[Optional[torch.Tensor]] = [None] * len(xs)
         for g in self._level_groups(xs[::per_level], per_level):
             idx = [l * per_level + j for l in g for j in range(per_level)]
+            if gn_groups and len(g) == 1 and out_dtype is None:        # a big level: its convs run alone anyway
+                for i in idx:
+                    outs[i], stats[i] = self.e.conv_gnstats(xs[i], packs[i], pad, gn_groups)
+                continue
             res = self.e.conv_group([xs[i] for i in idx], [packs[i] for i in idx], 1, pad, "none", out_dtype=out_dtype)
             for i, r in zip(idx, res):
                 outs[i] = r
-        return outs
+        return (outs, stats) if gn_groups else outs
 
     def _gn_params(self, key: str, names: Sequence[str]):
         ga = self._dev(key + ".gamma", torch.cat([self.sd[n + ".gn.weight"] for n in names]))
@@ -276,17 +283,17 @@ class ResDetBuilder:
         names0 = ["%s.cls_convs.0" % p, "%s.reg_convs.0" % p]
         f = self.sd[names0[0] + ".conv.weight"].shape[0]
         pk0 = self._pack(p + ".tower0", [raw(n) for n in names0], feats[0].c)
-        both = self._conv_levels(feats, [pk0] * L, 1)
+        both, pre = self._conv_levels(feats, [pk0] * L, 1, gn_groups=64)
         ga, be = self._gn_params(p + ".tower0", names0)
-        e.groupnorm_multi(both, 64, [ga] * L, [be] * L, GN_EPS, "relu")
+        e.groupnorm_multi(both, 64, [ga] * L, [be] * L, GN_EPS, "relu", pre=pre)
         cur = [t.channels(j * f, (j + 1) * f) for t in both for j in (0, 1)]      # level-major: cls_l, reg_l
         for i in range(1, stacked):
             names = ["%s.%s_convs.%d" % (p, which, i) for which in ("cls", "reg")]
             pks = [self._pack(n, [raw(n)], f) for n in names]
             gb = [self._gn_params(n, [n]) for n in names]
-            cur = self._conv_levels(cur, pks * L, 1, per_level=2)
+            cur, pre = self._conv_levels(cur, pks * L, 1, per_level=2, gn_groups=32)
             e.groupnorm_multi(cur, 32, [gb[j][0] for _ in range(L) for j in (0, 1)],
-                              [gb[j][1] for _ in range(L) for j in (0, 1)], GN_EPS, "relu")
+                              [gb[j][1] for _ in range(L) for j in (0, 1)], GN_EPS, "relu", pre=pre)
         return cur[0::2], cur[1::2]
 
     def _reg_preds(self, p: str, regs: Sequence[TView]) -> List[TView]:

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GLSDET_ABI_VERSION 7
+#define GLSDET_ABI_VERSION 8
 
 enum { GLSDET_F16 = 0, GLSDET_F32 = 1 };
 enum { GLSDET_ACT_NONE = 0, GLSDET_ACT_SILU = 1, GLSDET_ACT_RELU = 2, GLSDET_ACT_LRELU = 3,
@@ -295,6 +295,22 @@ int glsdet_groupnorm(const glsdet_view* x, const glsdet_view* y, int32_t groups,
 int glsdet_groupnorm_multi(const glsdet_view* x, const glsdet_view* y, int32_t n_sets, int32_t groups,
                            const float* const* gamma, const float* const* beta, float eps, int32_t act,
                            void* stats, void* stream);
+
+/* The same, with the statistics of some sets already produced by the conv that wrote them: pre_stats[q] != NULL names
+ * the partials glsdet_conv2d_gnstats wrote for x[q] (one slice per 8 x 16 pixel tile); those sets skip the statistics
+ * pass (one read of the tensor less).  pre_stats == NULL or all NULL: glsdet_groupnorm_multi.                          */
+int glsdet_groupnorm_multi_pre(const glsdet_view* x, const glsdet_view* y, int32_t n_sets, int32_t groups,
+                               const float* const* gamma, const float* const* beta, float eps, int32_t act,
+                               void* stats, void* const* pre_stats, void* stream);
+/* glsdet_conv2d that ALSO writes the GroupNorm partial sums of the tensor it stores (gfl_head.py:128-152: every tower
+ * conv is followed by GN(32) + ReLU): per (image, 8 x 16 pixel tile, group) the fp64 sum and sum of squares of the
+ * stored values, summed in a fixed order.  3x3 stride 1, no residual, x.dtype == y.dtype, halo ring kernels only
+ * (tile_hint 8..11, 0 = 8); anything else is GLSDET_E_ARG and the caller runs glsdet_conv2d + the two-pass GN.
+ * stats: glsdet_conv2d_gnstats_bytes(n, ho, wo, groups) bytes, 8-byte aligned.                                         */
+int64_t glsdet_conv2d_gnstats_bytes(int32_t n, int32_t ho, int32_t wo, int32_t groups);
+int     glsdet_conv2d_gnstats(const glsdet_conv_desc* d, int32_t groups, void* stats, void* stream);
+int     glsdet_conv2d_gnstats_tune(const glsdet_conv_desc* d, int32_t groups, void* stats, void* stream, int32_t* best_hint,
+                                   float* best_us);
 
 /* MPHead.forward_proxy (ufp/mmdet/models/dense_heads/mp_head.py:105-121).
  *   feat : view [n,h,w,C] (the gfl_cls_conv output), engine dtype

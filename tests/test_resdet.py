@@ -209,6 +209,38 @@ def test_groupnorm(engines, mode, c, g, hw):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("mode", ["f32", "f16"])
+@pytest.mark.parametrize("cin,cout,g,hw", [(256, 256, 32, (20, 24)), (256, 512, 64, (17, 33)), (64, 64, 8, (8, 16)), (128, 256, 32, (41, 70))])
+def test_conv_with_groupnorm_partials_equals_conv_then_two_pass_groupnorm(engines, mode, cin, cout, g, hw):
+    """glsdet_conv2d_gnstats + glsdet_groupnorm_multi_pre (the conv's store phase sums what it stores, the GroupNorm
+    only folds and applies) against glsdet_conv2d + the two-pass GroupNorm on the same operands, and against torch:
+    the conv outputs are bit-identical; the normalised tensors agree to the fp32 noise of two summation orders
+    (fp64 folds of fp32 partial sums either way).  Ragged maps, one tile, cout tiles of 64 and 128 rows."""
+    from tests.test_hip_ops import _to_view
+    eng = engines[mode]
+    gen = torch.Generator().manual_seed(cin + cout + hw[0])
+    x = torch.randn(2, cin, hw[0], hw[1], generator=gen)
+    w = torch.randn(cout, cin, 3, 3, generator=gen) / np.sqrt(9 * cin)
+    ga, be = (torch.rand(cout, generator=gen) + 0.5), torch.randn(cout, generator=gen) * 0.2
+    pk = eng.pack_conv([(w, torch.ones(cout), torch.zeros(cout))], cin)
+    xv = _to_view(eng, x)
+    ref = eng.conv(xv, pk, 1, 1, "none", tile_hint=8)
+    raw_ref = ref.to_nchw().cpu()
+    eng.groupnorm_multi([ref], g, [ga.cuda()], [be.cuda()], 1e-5, "relu")
+    y, st = eng.conv_gnstats(xv, pk, 1, g)
+    assert st is not None, "the statistics form must apply to a 3x3 stride-1 conv"
+    torch.cuda.synchronize()
+    assert torch.equal(y.to_nchw().cpu(), raw_ref)
+    eng.groupnorm_multi([y], g, [ga.cuda()], [be.cuda()], 1e-5, "relu", pre=[st])
+    torch.cuda.synchronize()
+    a, b = y.to_nchw().cpu(), ref.to_nchw().cpu()
+    want = torch.relu(F.group_norm(F.conv2d(_r(x, mode), _r(w, mode), None, 1, 1) if mode == "f32" else raw_ref, g, ga, be, 1e-5))
+    assert _err(a, b) <= (2e-6 if mode == "f32" else 1.1e-3)            # f16: one ulp where a rounding flips
+    assert float((a != b).float().mean()) <= (1.0 if mode == "f32" else 0.01)
+    assert _err(a, want) <= (3e-5 if mode == "f32" else 4e-3)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["f32", "f16"])
 @pytest.mark.parametrize("k,cin,cout", [(1, 64, 256), (3, 32, 32)])
 def test_conv_residual_before_activation(engines, mode, k, cin, cout):
     from tests.test_hip_ops import _to_view
