@@ -940,7 +940,7 @@ extern "C" int glsdet_bottleneck_tune(const glsdet_conv_desc* c1, const glsdet_c
 // pass of glsdet_groupnorm reads the tensor once more only to sum it; here the conv's store phase sums what it stores.
 extern "C" int64_t glsdet_conv2d_gnstats_bytes(int32_t n, int32_t ho, int32_t wo, int32_t groups) {
   if (n < 1 || ho < 1 || wo < 1 || groups < 1) return 0;
-  return (int64_t)n * ((ho + 7) / 8) * ((wo + 15) / 16) * groups * 2 * (int64_t)sizeof(double);
+  return (int64_t)n * ((ho + 7) / 8) * ((wo + 15) / 16) * 4 * groups * 2 * (int64_t)sizeof(double);
 }
 extern "C" int glsdet_conv2d_gnstats(const glsdet_conv_desc* d, int32_t groups, void* stats, void* stream) {
   if (!d || !stats) GLS_FAIL(GLSDET_E_ARG, "conv2d_gnstats: null argument");

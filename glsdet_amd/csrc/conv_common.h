@@ -50,8 +50,8 @@ struct ConvArgs {
   long y2_sn, y2_sh, y2_sw;
   int c2_0, cin2, cout2, cout2_pad, kpad2, act2, y2_lin;
   unsigned w2_bytes;
-  // GroupNorm statistics of the output (glsdet_conv2d_gnstats): per (image, pixel tile, group) the sum and the sum of
-  // squares of the STORED values, fp64, at gn_part[((img * tiles + tile) * gn_groups + group) * 2]; nullptr: none
+  // GroupNorm statistics of the output (glsdet_conv2d_gnstats): per (image, pixel tile, wave, group) the sum and the sum
+  // of squares of the STORED values, fp64, at gn_part[(((img * tiles + tile) * 4 + wave) * gn_groups + group) * 2]; nullptr: none
   double* gn_part;
   int gn_cpg, gn_groups;
 };
@@ -248,29 +248,28 @@ __device__ __forceinline__ void gn_chunk_sums(u32x4 v, float*, float& s1, float&
   }
 }
 // GroupNorm partials of a tile (GN instantiations only): every thread owns ONE channel chunk (cq = tid % OCPR) of several
-// pixels; its fp32 sums go through LDS, the first CO_T / cpg threads fold the (256 / OCPR) x (cpg / VO) contributions of
-// their group in a fixed order into fp64 and write the tile's partial.  All 256 threads call it.
+// pixels.  The lanes of a wave that hold chunks of the same group are folded by xor shuffles (fixed order, no LDS, no
+// barrier) and one lane per (wave, group) writes the fp64 partial: four slices per tile, one per wave.
 template <typename TO, int CO_T>
-__device__ __forceinline__ void gn_tile_partials(unsigned char* scratch, const ConvArgs& a, int img, int ty0, int tx0, int co0,
-                                                 int tid, float s1, float s2) {
+__device__ __forceinline__ void gn_tile_partials(const ConvArgs& a, int img, int ty0, int tx0, int co0, int tid, float s1, float s2) {
   constexpr int VO = 16 / (int)sizeof(TO), OCPR = CO_T / VO;
-  __syncthreads();                                // every thread has read its chunks of the staged tile
-  reinterpret_cast<float2*>(scratch)[tid] = float2{s1, s2};
-  __syncthreads();
-  const int cpv = a.gn_cpg / VO;                  // chunks per group
-  if (tid < CO_T / a.gn_cpg && co0 + tid * a.gn_cpg < a.Cout) {
-    double t = 0.0, q = 0.0;
-    for (int r = 0; r < 256 / OCPR; ++r)
-      for (int c = tid * cpv; c < (tid + 1) * cpv; ++c) {
-        const float2 v = reinterpret_cast<const float2*>(scratch)[r * OCPR + c];
-        t += (double)v.x;
-        q += (double)v.y;
-      }
+  const int cpv = a.gn_cpg / VO;                  // chunks per group: 1 (f16, 8 channels per group), 2, 4, ...
+  for (int m = 1; m < cpv; m <<= 1) {
+    s1 += __shfl_xor(s1, m);
+    s2 += __shfl_xor(s2, m);
+  }
+#pragma unroll
+  for (int m = OCPR; m < 64; m <<= 1) {
+    s1 += __shfl_xor(s1, m);
+    s2 += __shfl_xor(s2, m);
+  }
+  const int lane = tid & 63, wave = tid >> 6;
+  if (lane < OCPR && lane % cpv == 0 && co0 + lane * VO < a.Cout) {
     const int tiles_x = (a.Wo + 15) / 16, tiles = tiles_x * ((a.Ho + 7) / 8);
     const int tile = (ty0 >> 3) * tiles_x + (tx0 >> 4);
-    double* o = a.gn_part + (((long)img * tiles + tile) * a.gn_groups + (co0 / a.gn_cpg + tid)) * 2;
-    o[0] = t;
-    o[1] = q;
+    double* o = a.gn_part + ((((long)img * tiles + tile) * 4 + wave) * a.gn_groups + (co0 + lane * VO) / a.gn_cpg) * 2;
+    o[0] = (double)s1;
+    o[1] = (double)s2;
   }
 }
 
@@ -299,7 +298,7 @@ __device__ __forceinline__ void halo_store_tile(const unsigned char* stile, cons
         if constexpr (GN) gn_chunk_sums(v, (TO*)nullptr, gs1, gs2);
       }
     }
-    if constexpr (GN) gn_tile_partials<TO, CO_T>(const_cast<unsigned char*>(stile), a, img, ty0, tx0, co0, tid, gs1, gs2);
+    if constexpr (GN) gn_tile_partials<TO, CO_T>(a, img, ty0, tx0, co0, tid, gs1, gs2);
     return;
   }
   if constexpr (PXS % 16 != 0) {                  // fp32 output with 128-row tiles: 8 pixels apart, plain form
@@ -319,7 +318,7 @@ __device__ __forceinline__ void halo_store_tile(const unsigned char* stile, cons
         if constexpr (GN) gn_chunk_sums(v, (TO*)nullptr, gs1, gs2);
       }
     }
-    if constexpr (GN) gn_tile_partials<TO, CO_T>(const_cast<unsigned char*>(stile), a, img, ty0, tx0, co0, tid, gs1, gs2);
+    if constexpr (GN) gn_tile_partials<TO, CO_T>(a, img, ty0, tx0, co0, tid, gs1, gs2);
     return;
   }
   constexpr int NCH = PX_T / (PXS > 0 ? PXS : 1); // chunks per thread
@@ -351,7 +350,7 @@ __device__ __forceinline__ void halo_store_tile(const unsigned char* stile, cons
       if constexpr (GN) gn_chunk_sums(v, (TO*)nullptr, gs1, gs2);
     }
   }
-  if constexpr (GN) gn_tile_partials<TO, CO_T>(const_cast<unsigned char*>(stile), a, img, ty0, tx0, co0, tid, gs1, gs2);
+  if constexpr (GN) gn_tile_partials<TO, CO_T>(a, img, ty0, tx0, co0, tid, gs1, gs2);
 }
 
 // ---- chained 1x1 conv on the tile a workgroup has just produced (CSPLayer: conv1|conv2 -> m.0.conv1, Bottleneck i ->

@@ -118,6 +118,7 @@ struct GnSet {
   long xsn, xsh, xsw, ysn, ysh, ysw;
   const float *gamma, *beta;
   double* partial;
+  float* mr;                    // [image][group] mean, rstd (gn_fold_kernel -> gn_apply_kernel)
   int H, W, nsplit, chunk, gb;
   int pstride, pre;             // partial slices per image in `partial`; pre: they were written by the producing conv
 };
@@ -170,7 +171,39 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const GnArgs a) {
   }
 }
 
-// Pass 2: fold the partials of this image (fixed order), then y = act((x - mean) * rstd * gamma + beta).
+// Pass 2: fold the partial slices of one (set, image): thread t sums the slices z = t / groups, t / groups + R, ... of group
+// t % groups (R = 256 / groups rows of threads), the rows are folded through LDS in a fixed order -> mean, rstd.
+__global__ __launch_bounds__(256) void gn_fold_kernel(const GnArgs a) {
+  __shared__ double s_t[256], s_q[256];
+  const GnSet& S = a.s[blockIdx.y];
+  const int b = blockIdx.x, groups = a.groups;
+  const int R = 256 / groups;
+  const int g = threadIdx.x % groups, r = threadIdx.x / groups;
+  double t = 0.0, q = 0.0;
+  if (r < R)
+    for (int z = r; z < S.nsplit; z += R) {
+      const double* o = S.partial + (((long)b * S.pstride + z) * groups + g) * 2;
+      t += o[0];
+      q += o[1];
+    }
+  s_t[threadIdx.x] = t;
+  s_q[threadIdx.x] = q;
+  __syncthreads();
+  if ((int)threadIdx.x < groups) {
+    for (int k = 1; k < R; ++k) {
+      t += s_t[k * groups + g];
+      q += s_q[k * groups + g];
+    }
+    const double cnt = (double)S.H * S.W * (a.C / groups);
+    const double mean = t / cnt;
+    double var = q / cnt - mean * mean;
+    if (var < 0.0) var = 0.0;
+    S.mr[((long)b * groups + g) * 2] = (float)mean;
+    S.mr[((long)b * groups + g) * 2 + 1] = (float)(1.0 / sqrt(var + (double)a.eps));
+  }
+}
+
+// Pass 3: y = act((x - mean) * rstd * gamma + beta).
 template <typename T>
 __global__ __launch_bounds__(256) void gn_apply_kernel(const GnArgs a) {
   typedef typename V16<T>::type V;
@@ -182,18 +215,8 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GnArgs a) {
   const int C = a.C, groups = a.groups, W = S.W;
   const int N = S.H * W, cpg = C / groups;
   if ((int)threadIdx.x < groups) {
-    double t = 0.0, q = 0.0;
-    for (int z = 0; z < S.nsplit; ++z) {
-      const double* o = S.partial + (((long)b * S.pstride + z) * groups + threadIdx.x) * 2;
-      t += o[0];
-      q += o[1];
-    }
-    const double cnt = (double)N * cpg;
-    const double mean = t / cnt;
-    double var = q / cnt - mean * mean;
-    if (var < 0.0) var = 0.0;
-    s_mean[threadIdx.x] = (float)mean;
-    s_rstd[threadIdx.x] = (float)(1.0 / sqrt(var + (double)a.eps));
+    s_mean[threadIdx.x] = S.mr[((long)b * groups + threadIdx.x) * 2];
+    s_rstd[threadIdx.x] = S.mr[((long)b * groups + threadIdx.x) * 2 + 1];
   }
   __syncthreads();
   const int vcols = C / VN, rows = 256 / vcols;
@@ -366,8 +389,8 @@ extern "C" int glsdet_upsample_add(const glsdet_view* coarse, const glsdet_view*
 }
 
 extern "C" int64_t glsdet_groupnorm_workspace_bytes(int32_t n, int32_t groups) {
-  if (n < 1 || groups < 1) return 0;
-  return (int64_t)n * GLS_GN_SPLIT * groups * 2 * (int64_t)sizeof(double);
+  if (n < 1 || groups < 1) return 0;      // partial sums + (mean, rstd) per (image, group)
+  return (int64_t)n * GLS_GN_SPLIT * groups * 2 * (int64_t)sizeof(double) + (int64_t)n * groups * 2 * (int64_t)sizeof(double);
 }
 
 static int groupnorm_sets(const glsdet_view* x, const glsdet_view* y, int32_t n_sets, int32_t groups,
@@ -390,7 +413,7 @@ static int groupnorm_sets(const glsdet_view* x, const glsdet_view* y, int32_t n_
   OpRecord op;
   op.kind = 7;
   op.flops = op.bytes = 0;
-  const long per_set = (long)nimg * GLS_GN_SPLIT * groups * 2;      // doubles
+  const long per_set = (long)nimg * GLS_GN_SPLIT * groups * 2 + (long)nimg * groups * 2;      // doubles (the tail holds mean, rstd as floats)
   for (int q = 0; q < n_sets; ++q) {
     int rc;
     if ((rc = check_view(x[q], "groupnorm.x"))) return rc;
@@ -405,6 +428,7 @@ static int groupnorm_sets(const glsdet_view* x, const glsdet_view* y, int32_t n_
     S.ysn = y[q].sn; S.ysh = y[q].sh; S.ysw = y[q].sw;
     S.gamma = gamma[q]; S.beta = beta[q];
     S.partial = (double*)stats + q * per_set;
+    S.mr = (float*)((double*)stats + q * per_set + (long)nimg * GLS_GN_SPLIT * groups * 2);
     S.H = x[q].h; S.W = x[q].w;
     S.pstride = GLS_GN_SPLIT;
     S.pre = 0;
@@ -414,7 +438,7 @@ static int groupnorm_sets(const glsdet_view* x, const glsdet_view* y, int32_t n_
       if ((uintptr_t)pre_stats[q] & 7) GLS_FAIL(GLSDET_E_ALIGN, "groupnorm: stats must be 8-byte aligned");
       S.partial = (double*)pre_stats[q];
       S.pre = 1;
-      S.nsplit = S.pstride = ((x[q].h + 7) / 8) * ((x[q].w + 15) / 16);
+      S.nsplit = S.pstride = ((x[q].h + 7) / 8) * ((x[q].w + 15) / 16) * 4;      // one slice per (tile, wave)
     }
     S.chunk = (N + S.nsplit - 1) / S.nsplit;
     S.gb = (N + rows * 8 - 1) / (rows * 8);
@@ -428,9 +452,11 @@ static int groupnorm_sets(const glsdet_view* x, const glsdet_view* y, int32_t n_
   op.launch = [=](hipStream_t st) -> int {
     if (dt == GLSDET_F16) {
       if (any_stats) hipLaunchKernelGGL(gn_stats_kernel<f16>, dim3(max_split, nimg, a.n), dim3(256), 0, st, a);
+      hipLaunchKernelGGL(gn_fold_kernel, dim3(nimg, a.n), dim3(256), 0, st, a);
       hipLaunchKernelGGL(gn_apply_kernel<f16>, dim3(max_gb, nimg, a.n), dim3(256), 0, st, a);
     } else {
       if (any_stats) hipLaunchKernelGGL(gn_stats_kernel<float>, dim3(max_split, nimg, a.n), dim3(256), 0, st, a);
+      hipLaunchKernelGGL(gn_fold_kernel, dim3(nimg, a.n), dim3(256), 0, st, a);
       hipLaunchKernelGGL(gn_apply_kernel<float>, dim3(max_gb, nimg, a.n), dim3(256), 0, st, a);
     }
     GLS_HIP(hipGetLastError());

@@ -725,7 +725,10 @@ class Engine:
         wdev, sdev, bdev, cout, R, S = packed
         if out is None:
             out = self.tensor(x.n, x.h + 2 * pad - R + 1, x.w + 2 * pad - S + 1, cout)
-        if (R, S, pad) != (3, 3, 1) or x.dtype != out.dtype or os.environ.get("GLSDET_NO_GN_FUSION"):
+        # Off unless GLSDET_GN_FUSION=1: measured (MPDet, 8 x 800 x 1344, A/B on one box) the statistics pass it saves costs
+        # 30 us per GroupNorm launch but the tower convs, MFMA bound at ~1000 TFLOP/s, pay 8 % for the sums in their store
+        # phase (148 -> 162 us each): 1214 vs 1230 img/s.  The HBM-bound pass overlaps the other batches' convs; the convs do not.
+        if (R, S, pad) != (3, 3, 1) or x.dtype != out.dtype or not os.environ.get("GLSDET_GN_FUSION"):
             return self.conv(x, packed, 1, pad, "none", out=out), None
         stats = self.raw(self.lib.glsdet_conv2d_gnstats_bytes(out.n, out.h, out.w, groups))
         d = ConvDesc()

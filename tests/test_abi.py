@@ -84,7 +84,7 @@ def test_new_entry_points_validate_their_operands_on_the_host():
     assert lib.glsdet_groupnorm(P(x), P(x), 3, g, g, 1e-5, 2, 0x4000, None) < 0 and "groupnorm" in _err(lib)
     assert lib.glsdet_groupnorm(P(x), P(x), 2, g, g, 1e-5, 1, 0x4000, None) < 0 and "act" in _err(lib)
     assert lib.glsdet_groupnorm(P(x), P(x), 2, g, g, 1e-5, 2, 0x4001, None) < 0 and "aligned" in _err(lib)
-    assert lib.glsdet_groupnorm_workspace_bytes(8, 32) == 8 * 64 * 32 * 2 * 8
+    assert lib.glsdet_groupnorm_workspace_bytes(8, 32) == 8 * 64 * 32 * 2 * 8 + 8 * 32 * 2 * 8
     # proxy_scores: class with no proxies, dots not fp32
     counts = (C.c_int32 * 2)(3, 0)
     d32, o32 = _view(2, 8, 10, 8, dtype=1, base=0x90000), _view(2, 8, 10, 8, dtype=1, base=0xA0000)

@@ -210,12 +210,13 @@ def test_groupnorm(engines, mode, c, g, hw):
 @pytest.mark.gpu
 @pytest.mark.parametrize("mode", ["f32", "f16"])
 @pytest.mark.parametrize("cin,cout,g,hw", [(256, 256, 32, (20, 24)), (256, 512, 64, (17, 33)), (64, 64, 8, (8, 16)), (128, 256, 32, (41, 70))])
-def test_conv_with_groupnorm_partials_equals_conv_then_two_pass_groupnorm(engines, mode, cin, cout, g, hw):
+def test_conv_with_groupnorm_partials_equals_conv_then_two_pass_groupnorm(engines, monkeypatch, mode, cin, cout, g, hw):
     """glsdet_conv2d_gnstats + glsdet_groupnorm_multi_pre (the conv's store phase sums what it stores, the GroupNorm
     only folds and applies) against glsdet_conv2d + the two-pass GroupNorm on the same operands, and against torch:
     the conv outputs are bit-identical; the normalised tensors agree to the fp32 noise of two summation orders
     (fp64 folds of fp32 partial sums either way).  Ragged maps, one tile, cout tiles of 64 and 128 rows."""
     from tests.test_hip_ops import _to_view
+    monkeypatch.setenv("GLSDET_GN_FUSION", "1")         # (off by default: DESIGN.md, it does not pay on the tower convs)
     eng = engines[mode]
     gen = torch.Generator().manual_seed(cin + cout + hw[0])
     x = torch.randn(2, cin, hw[0], hw[1], generator=gen)
