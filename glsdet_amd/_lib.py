@@ -68,6 +68,9 @@ _SIGS = {
                                     C.POINTER(View), C.c_void_p]),
     "glsdet_focus_conv": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                                     C.c_int32, C.POINTER(View), C.c_void_p]),
+    "glsdet_focus_conv_down": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                         C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(View),
+                                         C.c_void_p]),
     "glsdet_channel_maxmean": (C.c_int, [C.POINTER(View), C.POINTER(View), C.c_void_p]),
     "glsdet_spp_pools": (C.c_int, [C.POINTER(View), C.POINTER(View), C.POINTER(View), C.POINTER(View), C.c_void_p]),
     "glsdet_maxpool2d": (C.c_int, [C.POINTER(View), C.POINTER(View), C.c_int32, C.c_void_p]),

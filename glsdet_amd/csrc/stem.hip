@@ -172,9 +172,295 @@ static int launch_stem(const StemArgs& a, hipStream_t st) {
   return 0;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Focus + stem conv + the FIRST downsampling conv (dark2.0: 3x3 stride 2, darknet.py:117-121) in one kernel.
+// The stem output is the largest tensor of the network (8 x 400 x 672 x 32 fp16 = 138 MB), written once and read once by
+// a layer that does 18 MACs per byte of it: as two launches (focus_stem 74 us + 3x3 s2 81 us) it costs 2 x 138 MB of the
+// 447 MB both move.  Here the workgroup of an 8 x 16 OUTPUT tile of dark2.0
+//   phase A  reads the fp32 image region of the tile's 17 x 33 stem-output halo (38 x 70 pixels, float2 loads), builds
+//            the packed 19 x 35 x 16 patch, multiplies the nine stem taps for all 561 halo pixels (18 blocks of 32, five
+//            per wave: the accumulators live in registers until ALL are done, because the result patch overwrites the
+//            packed one), applies scale / bias / act, ZERO outside the stem's map, rounds to the storage type and writes
+//            the patch with its columns DE-INTERLEAVED (conv_halo.hip, STR = 2);
+//   phase B  runs the stride-2 ring loop over that resident patch (its weight DMAs were issued at kernel start);
+//   epilogue as the halo kernels.
+// Rounding points and k order are those of the two stand-alone kernels: bit-identical result (tests/test_hip_model.py).
+struct Stem2Args {
+  ConvArgs c;                  // the stride-2 conv: w, scale, bias, y, strides, H / W = the stem's map, Ho / Wo, Cout, act
+  const float* img;            // [n][3][IH][IW] fp32
+  const unsigned char* w1;     // stem weights [32][kpad(3,3,16)]
+  const float* scale1;
+  const float* bias1;
+  int IH, IW, kpad1, act1;
+};
+
+template <typename T>
+struct Stem2Geom {
+  static constexpr int ES = (int)sizeof(T), C1 = 32, CO_T = 64;
+  static constexpr int KB = C1 * ES;                           // one channel chunk: 64 B (f16) / 128 B (f32)
+  static constexpr int RING = KB == 64 ? 4 : 3;
+  static constexpr int SH = 17, SW = 33, NS = SH * SW;         // stem-output halo of an 8 x 16 stride-2 tile
+  static constexpr int FH = SH + 2, FW = SW + 2, NF = FH * FW; // packed patch
+  static constexpr int FRS = 16 * ES + 16, WRS = 144 * ES + 16, RS1 = KB + 16;
+  static constexpr int RING_BYTES = RING * CO_T * KB, W1_BYTES = C1 * WRS;
+  static constexpr int W1_OFF = RING_BYTES, B_OFF = RING_BYTES + W1_BYTES;
+  static constexpr int F_BYTES = (NF + 40) * FRS, P1_BYTES = NS * RS1;        // (+40: the junk pixels 561..575 read past the patch)
+  static constexpr int STAGE = B_OFF + (F_BYTES > P1_BYTES ? F_BYTES : P1_BYTES);
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void focus_stem_down_kernel(const Stem2Args b, const int tiles_x, const int tiles_y) {
+  using G = Stem2Geom<T>;
+  const ConvArgs& a = b.c;
+  constexpr int ES = G::ES, VEC = 16 / ES, KB = G::KB, RING = G::RING, CO_T = G::CO_T;
+  constexpr int SW = G::SW, NS = G::NS, FH = G::FH, FW = G::FW, NF = G::NF, FRS = G::FRS, WRS = G::WRS, RS1 = G::RS1;
+  constexpr int HALF = (SW + 1) / 2, PITCH = 2 * SW;
+  constexpr int CPRW = KB / 16, RPL = 256 / KB, RPI = 64 / CPRW, NI = CO_T / RPI / 4;
+  constexpr int A_BYTES = CO_T * KB;
+  constexpr int TM = 1, TN = 2;                        // waves: 2 (cout) x 2 (pixels)
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+  unsigned char* sW = smem + G::W1_OFF;
+  unsigned char* sF = smem + G::B_OFF;                 // packed patch, then the stem-output patch P1
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, lh = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int t = blockIdx.x;
+  const int tx = t % tiles_x;
+  t /= tiles_x;
+  const int ty = t % tiles_y, img = t / tiles_y;
+  const int ty0 = ty * 8, tx0 = tx * 16;               // output tile origin
+  const int Y0 = 2 * ty0 - 2, X0 = 2 * tx0 - 2;        // packed (= stem map) coordinates of the packed patch's origin
+
+  // ---- weight ring of the second conv: the first RING - 1 taps are requested now and land during phase A
+  const auto wrs = gls_make_rsrc(a.w, a.w_bytes);
+  unsigned wd[NI];
+#pragma unroll
+  for (int q = 0; q < NI; ++q) {
+    const int row = RPI * (wave + 4 * q) + lane / CPRW;
+    const int ch = (lane % CPRW) ^ ((row / RPL) & (CPRW - 1));
+    wd[q] = row < a.cout_pad ? (unsigned)((row * a.kpad + ch * VEC) * ES) : GLS_OOB;
+  }
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  int dg = 0, dslot = 0;
+  unsigned dadd = 0;
+  auto dma_next = [&]() __attribute__((always_inline)) {
+    unsigned char* dst = smem + dslot * A_BYTES + wave * 1024;
+#pragma unroll
+    for (int q = 0; q < NI; ++q)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lds_ptr)(dst + q * 4096), 16, (int)(wd[q] + dadd), 0, 0, 0);
+    dslot = dslot + 1 == RING ? 0 : dslot + 1;
+    dadd += (unsigned)KB;
+    if (++dg >= 9) dadd = GLS_OOB;
+  };
+#pragma unroll
+  for (int g = 0; g < RING - 1; ++g) dma_next();
+
+  // ---- phase A: image -> packed patch -> stem conv on the 17 x 33 halo
+  {
+    const long plane = (long)b.IH * b.IW;
+    const float* ibase = b.img + (long)img * 3 * plane;
+    constexpr int NQ = 3 * (2 * FH) * FW, NL = (NQ + 255) / 256;
+    float2 pre[NL];
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      const int q = tid + i * 256;
+      const int px = q % FW, r = q / FW;
+      const int iy_l = r % (2 * FH), c = r / (2 * FH);
+      const int Y = Y0 + (iy_l >> 1), X = X0 + px;
+      pre[i] = float2{0.f, 0.f};
+      if (q < NQ && (unsigned)Y < (unsigned)a.H && (unsigned)X < (unsigned)a.W)
+        pre[i] = *reinterpret_cast<const float2*>(ibase + c * plane + (long)(2 * Y + (iy_l & 1)) * b.IW + 2 * X);
+    }
+    for (int q = tid; q < G::C1 * (144 * ES / 16); q += 256) {
+      const int row = q / (144 * ES / 16), c = q - row * (144 * ES / 16);
+      *reinterpret_cast<u32x4*>(sW + row * WRS + c * 16) = *reinterpret_cast<const u32x4*>(b.w1 + ((long)row * b.kpad1) * ES + c * 16);
+    }
+    for (int q = tid; q < NF; q += 256) {              // channels 12..15
+      T* dst = reinterpret_cast<T*>(sF + q * FRS) + 12;
+      dst[0] = dst[1] = dst[2] = dst[3] = (T)0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      const int q = tid + i * 256;
+      if (q < NQ) {
+        const int px = q % FW, r = q / FW;
+        const int iy_l = r % (2 * FH), c = r / (2 * FH);
+        const int py = iy_l >> 1, dy = iy_l & 1;
+        T* dst = reinterpret_cast<T*>(sF + (py * FW + px) * FRS);
+        dst[dy * 3 + c] = (T)pre[i].x;                // TL (dy 0) / BL (dy 1)
+        dst[6 + dy * 3 + c] = (T)pre[i].y;            // TR / BR
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // (never __syncthreads(): it would drain the ring's DMAs)
+    constexpr int NT = 5;                              // 18 pixel blocks of 32 over four waves
+    f32x16 acc[NT];
+    int boff[NT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][e] = 0.0f;
+      const int p = (wave + 4 * i) * 32 + l31;
+      const int sy = p / SW, sx = p - sy * SW;
+      boff[i] = (sy * FW + sx) * FRS + lh * 16;
+    }
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int r = tap / 3, c = tap - 3 * r;
+#pragma unroll
+      for (int kk = 0; kk < 16 * ES / 32; ++kk) {
+        const u32x4 af = *reinterpret_cast<const u32x4*>(sW + l31 * WRS + tap * 16 * ES + kk * 32 + lh * 16);
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+          if (wave + 4 * i < 18) {
+            const u32x4 bf = *reinterpret_cast<const u32x4*>(sF + boff[i] + (r * FW + c) * FRS + kk * 32);
+            MMA<T>::run(af, bf, acc[i]);
+          }
+        }
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // every wave is done with the packed patch: its bytes become P1
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+      const int p = (wave + 4 * i) * 32 + l31;
+      const int sy = p / SW, sx = p - sy * SW;
+      const int Ys = 2 * ty0 - 1 + sy, Xs = 2 * tx0 - 1 + sx;
+      const bool inside = (unsigned)Ys < (unsigned)a.H && (unsigned)Xs < (unsigned)a.W;
+      if (wave + 4 * i < 18 && p < NS) {
+        const int slot = sy * SW + ((sx & 1) ? HALF + (sx >> 1) : (sx >> 1));
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int co = 8 * g + 4 * lh;
+          const f32x4 sc = *reinterpret_cast<const f32x4*>(b.scale1 + co), bi = *reinterpret_cast<const f32x4*>(b.bias1 + co);
+          const f32x4 xv = {acc[i][4 * g], acc[i][4 * g + 1], acc[i][4 * g + 2], acc[i][4 * g + 3]};
+          f32x4 yv = scale_bias_act4<T>(xv, sc, bi, b.act1);
+          if (!inside) yv = f32x4{0.f, 0.f, 0.f, 0.f};
+          const float v[4] = {yv[0], yv[1], yv[2], yv[3]};
+          store4(sF + slot * RS1 + co * ES, v, (T*)nullptr);
+        }
+      }
+    }
+  }
+
+  // ---- phase B: 3x3 stride 2 over the resident patch
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+  const int wco = wave % 2, wpx = wave / 2;
+  const int a_row = (wco * 32 + l31) * KB;
+  int a_sw[KB / 32];
+#pragma unroll
+  for (int kk = 0; kk < KB / 32; ++kk) a_sw[kk] = ((2 * kk + lh) ^ ((l31 / RPL) & (CPRW - 1))) << 4;
+  int b_off[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int pix = wpx * 64 + j * 32 + l31;
+    int oy, ox;
+    pix_to_xy16<PITCH>(pix, oy, ox);
+    b_off[j] = G::B_OFF + (oy * PITCH + ox) * RS1 + lh * 16;
+  }
+  int g = 0, tap_off = 0, ts = 0;
+  for (int tap = 0; tap < 9; ++tap) {
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NI * (RING - 2)) : "memory");   // at tap 0 also: P1 is visible
+    dma_next();
+    const unsigned char* sA = smem + g * A_BYTES + a_row;
+#pragma unroll
+    for (int kk = 0; kk < KB / 32; ++kk) {
+      const u32x4 af = *reinterpret_cast<const u32x4*>(sA + a_sw[kk]);
+      u32x4 bf[TN];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const u32x4*>(smem + b_off[j] + tap_off + kk * 32);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) MMA<T>::run(af, bf[j], acc[0][j]);
+    }
+    g = g + 1 == RING ? 0 : g + 1;
+    ++ts;
+    tap_off += (ts == 1) ? HALF * RS1 : (ts == 2 ? -(HALF - 1) * RS1 : (SW - 1) * RS1);
+    ts = (ts == 3) ? 0 : ts;
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+
+#pragma unroll
+  for (int gq = 0; gq < 4; ++gq) {
+    const int co_l = wco * 32 + 8 * gq + 4 * lh;
+    f32x4 sc = {0.f, 0.f, 0.f, 0.f}, bi = {0.f, 0.f, 0.f, 0.f};
+    if (co_l < a.cout_pad) {
+      sc = *reinterpret_cast<const f32x4*>(a.scale + co_l);
+      bi = *reinterpret_cast<const f32x4*>(a.bias + co_l);
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int px_l = wpx * 64 + j * 32 + l31;
+      const f32x4 xv = {acc[0][j][4 * gq], acc[0][j][4 * gq + 1], acc[0][j][4 * gq + 2], acc[0][j][4 * gq + 3]};
+      const f32x4 yv = scale_bias_act4<T>(xv, sc, bi, a.act);
+      const float v[4] = {yv[0], yv[1], yv[2], yv[3]};
+      stage4<T, CO_T>(smem, px_l, co_l, v, false);
+    }
+  }
+  __syncthreads();
+  halo_store_tile<T, CO_T, PITCH>(smem, a, img, ty0, tx0, 0, tid);
+}
+
+template <typename T>
+static int launch_stem_down(const Stem2Args& b, hipStream_t st) {
+  using G = Stem2Geom<T>;
+  constexpr int epi = epi_bytes<T>(64, 128, false);
+  constexpr int lds = G::STAGE > epi ? G::STAGE : epi;
+  static bool attr_set = false;
+  if (!attr_set && lds > 64 * 1024) {
+    GLS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(focus_stem_down_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    attr_set = true;
+  }
+  const int tiles_x = (b.c.Wo + 15) / 16, tiles_y = (b.c.Ho + 7) / 8;
+  const long grid = (long)b.c.N * tiles_x * tiles_y;
+  if (grid <= 0 || grid > 0x7fffffffL) GLS_FAIL(GLSDET_E_ARG, "focus_conv_down: grid %ld out of range", grid);
+  hipLaunchKernelGGL((focus_stem_down_kernel<T>), dim3((unsigned)grid), dim3(256), lds, st, b, tiles_x, tiles_y);
+  GLS_HIP(hipGetLastError());
+  return 0;
+}
+
 }  // namespace glsdet
 
 using namespace glsdet;
+
+extern "C" int glsdet_focus_conv_down(const float* img, int32_t n, int32_t cin, int32_t H, int32_t W, const void* w1, const float* scale1,
+                                      const float* bias1, int32_t act1, int32_t c1, const void* w2, const float* scale2,
+                                      const float* bias2, int32_t act2, const glsdet_view* y, void* stream) {
+  if (!img || !w1 || !scale1 || !bias1 || !w2 || !scale2 || !bias2 || !y) GLS_FAIL(GLSDET_E_ARG, "focus_conv_down: null argument");
+  if (cin != 3 || n < 1 || H < 4 || W < 4 || (H & 1) || (W & 1)) GLS_FAIL(GLSDET_E_ARG, "focus_conv_down: needs a 3-channel image with even H and W");
+  if (((uintptr_t)img & 7) || ((uintptr_t)w1 | (uintptr_t)scale1 | (uintptr_t)bias1 | (uintptr_t)w2 | (uintptr_t)scale2 | (uintptr_t)bias2) & 15)
+    GLS_FAIL(GLSDET_E_ALIGN, "focus_conv_down: operand alignment");
+  int rc;
+  if ((rc = check_view(*y, "focus_conv_down.y"))) return rc;
+  const int Hs = H / 2, Ws = W / 2, Ho = (Hs + 2 - 3) / 2 + 1, Wo = (Ws + 2 - 3) / 2 + 1;
+  if (c1 != 32 || y->n != n || y->h != Ho || y->w != Wo || y->c % 8 || y->c > 64)
+    GLS_FAIL(GLSDET_E_ARG, "focus_conv_down: stem of 32 channels, output [n, %d, %d, <= 64 channels]", Ho, Wo);
+  if (act1 < 0 || act1 > 5 || act2 < 0 || act2 > 5) GLS_FAIL(GLSDET_E_ARG, "focus_conv_down: bad act");
+  Stem2Args b = {};
+  ConvArgs& a = b.c;
+  const int dt = y->dtype, es = dtype_size(dt);
+  a.w = (const unsigned char*)w2; a.scale = scale2; a.bias = bias2;
+  a.y = (unsigned char*)y->base; a.y_sn = y->sn; a.y_sh = y->sh; a.y_sw = y->sw;
+  a.res = nullptr;
+  a.N = n; a.H = Hs; a.W = Ws; a.Cin = 32; a.Ho = Ho; a.Wo = Wo; a.Cout = y->c; a.cout_pad = glsdet_conv_cout_pad(y->c);
+  a.R = a.S = 3; a.stride = 2; a.pad = 1; a.act = act2; a.act_post = 0;
+  a.kreal = 9 * 32; a.kpad = glsdet_conv_kpad(3, 3, 32, dt);
+  a.w_bytes = (unsigned)((int64_t)a.cout_pad * a.kpad * es);
+  a.M = n * Ho * Wo;
+  b.img = img; b.w1 = (const unsigned char*)w1; b.scale1 = scale1; b.bias1 = bias1;
+  b.IH = H; b.IW = W; b.kpad1 = glsdet_conv_kpad(3, 3, 16, dt); b.act1 = act1;
+  OpRecord op;
+  op.kind = 0;
+  op.flops = 2.0 * (double)n * Hs * Ws * 32 * 108.0 + 2.0 * (double)n * Ho * Wo * y->c * 288.0;
+  op.bytes = (double)n * 3 * H * W * 4.0 + (double)n * Ho * Wo * y->c * es;
+  char nm[112];
+  snprintf(nm, sizeof nm, "focus_stem_down<%s> 3x3 cin12 cout32 -> 3x3 s2 cout%d (fp32 NCHW image in)", dt ? "f32" : "f16", y->c);
+  op.name = nm;
+  op.launch = [b, dt](hipStream_t st) -> int { return dt == GLSDET_F16 ? launch_stem_down<f16>(b, st) : launch_stem_down<float>(b, st); };
+  return submit(std::move(op), stream);
+}
 
 extern "C" int glsdet_focus_conv(const float* img, int32_t n, int32_t cin, int32_t H, int32_t W, const void* w, const float* scale,
                                  const float* bias, int32_t act, const glsdet_view* y, void* stream) {

@@ -542,6 +542,20 @@ class Engine:
                                          ACT[act], C.byref(out.as_c()), _stream_ptr(self.stream)), "focus_conv")
         return out
 
+    def focus_conv_down(self, img: torch.Tensor, packed1, act1: str, packed2, act2: str, out: Optional[TView] = None) -> TView:
+        """Focus + stem conv + the 3x3 stride-2 conv that follows, in one launch (glsdet_focus_conv_down)."""
+        assert img.dtype == torch.float32 and img.is_contiguous() and img.device.type == "cuda"
+        n, cin, H, W = img.shape
+        w1, s1, b1, c1, R1, S1 = packed1
+        w2, s2, b2, cout, R2, S2 = packed2
+        assert (R1, S1, R2, S2) == (3, 3, 3, 3)
+        if out is None:
+            out = self.tensor(n, (H // 2 + 1) // 2, (W // 2 + 1) // 2, cout)
+        check(self.lib.glsdet_focus_conv_down(img.data_ptr(), n, cin, H, W, w1.data_ptr(), s1.data_ptr(), b1.data_ptr(), ACT[act1], c1,
+                                              w2.data_ptr(), s2.data_ptr(), b2.data_ptr(), ACT[act2], C.byref(out.as_c()),
+                                              _stream_ptr(self.stream)), "focus_conv_down")
+        return out
+
     def channel_maxmean(self, x: TView, out: Optional[TView] = None) -> TView:
         if out is None:
             out = self.tensor(x.n, x.h, x.w, 8, x.dtype)

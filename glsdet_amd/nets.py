@@ -235,16 +235,27 @@ class NetBuilder:
         f = {}
         q = p + ".stem.conv"
         w0 = self.sd.get(q + ".conv.weight")
+        d2 = p + ".dark2.0"
+        wd = self.sd.get(d2 + ".conv.weight")
+        fused_down = False
         if w0 is not None and img.shape[1] == 3 and tuple(w0.shape[1:]) == (12, 3, 3) and w0.shape[0] <= 64 and \
                 not os.environ.get("GLSDET_NO_STEM_FUSION"):
-            # Focus + stem conv in one launch: the packed tensor is never written (glsdet_focus_conv)
-            x = self.e.focus_conv(img, self._pack(q, [self._bn_part(q)], 16), "silu")
-            self._rec(q, x, 0, w0.shape[0])
+            if w0.shape[0] == 32 and wd is not None and tuple(wd.shape[1:]) == (32, 3, 3) and wd.shape[0] <= 64 and self.trace is None \
+                    and img.shape[2] % 4 == 0 and img.shape[3] % 4 == 0 and not os.environ.get("GLSDET_NO_STEM2_FUSION"):
+                # ... and dark2.0 (3x3 stride 2) too: the stem's output, the largest tensor of the net, never exists either
+                # (glsdet_focus_conv_down; a trace keeps the two-launch form, which it equals bit for bit)
+                x = self.e.focus_conv_down(img, self._pack(q, [self._bn_part(q)], 16), "silu", self._pack(d2, [self._bn_part(d2)], 32), "silu")
+                fused_down = True
+            else:
+                # Focus + stem conv in one launch: the packed tensor is never written (glsdet_focus_conv)
+                x = self.e.focus_conv(img, self._pack(q, [self._bn_part(q)], 16), "silu")
+                self._rec(q, x, 0, w0.shape[0])
         else:
             x = self.cba(q, self.e.focus_pack(img))
         att = lambda i: self.has("%s.lsk%d.proj_1.weight" % (p, i))     # new/darknet_att.py:161-201
         for i, name in enumerate(("dark2", "dark3", "dark4")):
-            x = self.cba("%s.%s.0" % (p, name), x, 2)
+            if not (fused_down and name == "dark2"):
+                x = self.cba("%s.%s.0" % (p, name), x, 2)
             if att(i + 2):
                 x = self.csp("%s.%s.1" % (p, name), x, True)
                 x = self.attention("%s.lsk%d" % (p, i + 2), x, out=homes.get(name))

@@ -155,6 +155,14 @@ int glsdet_focus_pack(const float* img, int32_t n, int32_t cin, int32_t H, int32
  * over 16 input channels (12 real), packed for y's dtype.  y: NHWC view [n, H/2, W/2, <= 64 channels].                */
 int glsdet_focus_conv(const float* img, int32_t n, int32_t cin, int32_t H, int32_t W, const void* w, const float* scale,
                       const float* bias, int32_t act, const glsdet_view* y, void* stream);
+/* Focus, its 3x3 BaseConv AND the first downsampling conv (CSPDarknet.stem -> dark2[0], drone/models/base/darknet.py:117-121,
+ * 3x3 stride 2) in one launch: the stem's output tensor -- the largest of the network -- is neither written nor read; the
+ * workgroup of an output tile computes the stem on the tile's halo into LDS.  w1 / scale1 / bias1: the stem (c1 = 32
+ * output channels, packed as for glsdet_focus_conv); w2 / scale2 / bias2: a 3x3 conv over 32 channels; y: NHWC view
+ * [n, (H/2 + 1) / 2, (W/2 + 1) / 2, <= 64 channels].  Equals glsdet_focus_conv + glsdet_conv2d(stride 2) bit for bit.     */
+int glsdet_focus_conv_down(const float* img, int32_t n, int32_t cin, int32_t H, int32_t W, const void* w1, const float* scale1,
+                           const float* bias1, int32_t act1, int32_t c1, const void* w2, const float* scale2,
+                           const float* bias2, int32_t act2, const glsdet_view* y, void* stream);
 
 /* max pool k x k, stride 1, pad k/2 (-inf padding)   drone/models/base/darknet.py:29,35 */
 int glsdet_maxpool2d(const glsdet_view* x, const glsdet_view* y, int32_t k, void* stream);

@@ -107,6 +107,35 @@ def test_fused_focus_stem_vs_reference_golden_and_oracle(engines, golden, mode, 
     assert torch.equal(got, two.to_nchw(want.shape[1]).cpu())
 
 
+@pytest.mark.parametrize("mode", ["f32", "f16"])
+@pytest.mark.parametrize("cout,hw", [(64, (64, 96)), (64, (72, 136)), (40, (32, 40)), (64, (70, 130)), (64, (132, 260))])
+def test_fused_focus_stem_and_first_downsampling_conv_equal_two_launches_bit_for_bit(engines, mode, cout, hw):
+    """glsdet_focus_conv_down (Focus + stem 3x3 + dark2.0's 3x3 stride 2 in one launch; the stem is recomputed on the
+    halo of every output tile into LDS, rounded to the storage type, zero outside the stem's map) against
+    glsdet_focus_conv followed by the stride-2 conv (generic kernel): identical bits in both precisions, also where the
+    stem's map has odd extents, one tile, ragged tile borders; and against the oracle."""
+    from glsdet_amd.arch import _Table
+    from glsdet_amd.nets import NetBuilder
+    from glsdet_amd.synth import synth_input, synth_state_dict
+    eng = engines[mode]
+    t = _Table()
+    t.conv_bn("m.conv", 12, 32, 3)
+    t.conv_bn("d", 32, cout, 3)
+    sd = synth_state_dict(t, 6)
+    x = synth_input((2, 3, hw[0], hw[1]), 23)
+    b = NetBuilder(eng, sd)
+    p1, p2 = b._pack("m.conv", [b._bn_part("m.conv")], 16), b._pack("d", [b._bn_part("d")], 32)
+    fused = eng.focus_conv_down(x.cuda(), p1, "silu", p2, "silu")
+    two = eng.conv(eng.focus_conv(x.cuda(), p1, "silu"), p2, 2, 1, "silu", tile_hint=1)
+    torch.cuda.synchronize()
+    r = (lambda v: v.half().float()) if mode == "f16" else (lambda v: v)
+    want = O.base_conv(sd, "d", r(O.focus(sd, "m", r(x))), 2) if mode == "f32" else None
+    got = fused.to_nchw(cout).cpu()
+    assert torch.equal(got, two.to_nchw(cout).cpu())
+    if want is not None:
+        assert float((got - want).abs().max()) <= 5e-5 * max(1.0, float(want.abs().max()))
+
+
 MODELS = ["base_tiny_seed0", "base_tiny_seed1", "base_s_seed0", "gl_tiny_seed0", "gl_tiny_seed1", "gl_s_seed0",
           "base_nano_seed0", "base_nano_seed1", "gl_nano_seed0", "gl_nano_seed1"]     # nano = depthwise towers
 
