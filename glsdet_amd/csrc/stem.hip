@@ -8,6 +8,8 @@
 // on MFMA (K = 9 x 16, channels 12..15 zero) and writes NHWC: 103 + 137 MB, one launch.  A workgroup walks a strip of
 // STRIP tiles along x with the weight tile resident in LDS.
 // GEMM orientation, fragment layout and epilogue as in conv.hip; weights packed as for a 3x3 conv over 16 channels.
+#include <stdlib.h>
+
 #include "conv_common.h"
 
 namespace glsdet {
@@ -267,7 +269,7 @@ __global__ __launch_bounds__(256) void focus_stem_down_kernel(const Stem2Args b,
       const int iy_l = r % (2 * FH), c = r / (2 * FH);
       const int Y = Y0 + (iy_l >> 1), X = X0 + px;
       pre[i] = float2{0.f, 0.f};
-      if (q < NQ && (unsigned)Y < (unsigned)a.H && (unsigned)X < (unsigned)a.W)
+      if (q < NQ && (unsigned)Y < (unsigned)a.H && (unsigned)X < (unsigned)a.W && !(a.dbg & 1))
         pre[i] = *reinterpret_cast<const float2*>(ibase + c * plane + (long)(2 * Y + (iy_l & 1)) * b.IW + 2 * X);
     }
     for (int q = tid; q < G::C1 * (144 * ES / 16); q += 256) {
@@ -281,7 +283,7 @@ __global__ __launch_bounds__(256) void focus_stem_down_kernel(const Stem2Args b,
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
       const int q = tid + i * 256;
-      if (q < NQ) {
+      if (q < NQ && !(a.dbg & 2)) {
         const int px = q % FW, r = q / FW;
         const int iy_l = r % (2 * FH), c = r / (2 * FH);
         const int py = iy_l >> 1, dy = iy_l & 1;
@@ -302,6 +304,7 @@ __global__ __launch_bounds__(256) void focus_stem_down_kernel(const Stem2Args b,
       const int sy = p / SW, sx = p - sy * SW;
       boff[i] = (sy * FW + sx) * FRS + lh * 16;
     }
+    if (!(a.dbg & 4))
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
       const int r = tap / 3, c = tap - 3 * r;
@@ -324,7 +327,7 @@ __global__ __launch_bounds__(256) void focus_stem_down_kernel(const Stem2Args b,
       const int sy = p / SW, sx = p - sy * SW;
       const int Ys = 2 * ty0 - 1 + sy, Xs = 2 * tx0 - 1 + sx;
       const bool inside = (unsigned)Ys < (unsigned)a.H && (unsigned)Xs < (unsigned)a.W;
-      if (wave + 4 * i < 18 && p < NS) {
+      if (wave + 4 * i < 18 && p < NS && !(a.dbg & 8)) {
         const int slot = sy * SW + ((sx & 1) ? HALF + (sx >> 1) : (sx >> 1));
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -366,6 +369,7 @@ __global__ __launch_bounds__(256) void focus_stem_down_kernel(const Stem2Args b,
     asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NI * (RING - 2)) : "memory");   // at tap 0 also: P1 is visible
     dma_next();
     const unsigned char* sA = smem + g * A_BYTES + a_row;
+    if (!(a.dbg & 16))
 #pragma unroll
     for (int kk = 0; kk < KB / 32; ++kk) {
       const u32x4 af = *reinterpret_cast<const u32x4*>(sA + a_sw[kk]);
@@ -400,7 +404,7 @@ __global__ __launch_bounds__(256) void focus_stem_down_kernel(const Stem2Args b,
     }
   }
   __syncthreads();
-  halo_store_tile<T, CO_T, PITCH>(smem, a, img, ty0, tx0, 0, tid);
+  if (!(a.dbg & 32)) halo_store_tile<T, CO_T, PITCH>(smem, a, img, ty0, tx0, 0, tid);
 }
 
 template <typename T>
@@ -451,6 +455,7 @@ extern "C" int glsdet_focus_conv_down(const float* img, int32_t n, int32_t cin, 
   a.M = n * Ho * Wo;
   b.img = img; b.w1 = (const unsigned char*)w1; b.scale1 = scale1; b.bias1 = bias1;
   b.IH = H; b.IW = W; b.kpad1 = glsdet_conv_kpad(3, 3, 16, dt); b.act1 = act1;
+  a.dbg = getenv("GLSDET_STEM2_DBG") ? atoi(getenv("GLSDET_STEM2_DBG")) : 0;      // knock-out timing experiments (results invalid)
   OpRecord op;
   op.kind = 0;
   op.flops = 2.0 * (double)n * Hs * Ws * 32 * 108.0 + 2.0 * (double)n * Ho * Wo * y->c * 288.0;

@@ -241,9 +241,10 @@ class NetBuilder:
         if w0 is not None and img.shape[1] == 3 and tuple(w0.shape[1:]) == (12, 3, 3) and w0.shape[0] <= 64 and \
                 not os.environ.get("GLSDET_NO_STEM_FUSION"):
             if w0.shape[0] == 32 and wd is not None and tuple(wd.shape[1:]) == (32, 3, 3) and wd.shape[0] <= 64 and self.trace is None \
-                    and img.shape[2] % 4 == 0 and img.shape[3] % 4 == 0 and not os.environ.get("GLSDET_NO_STEM2_FUSION"):
+                    and img.shape[2] % 4 == 0 and img.shape[3] % 4 == 0 and os.environ.get("GLSDET_STEM2_FUSION"):
                 # ... and dark2.0 (3x3 stride 2) too: the stem's output, the largest tensor of the net, never exists either
-                # (glsdet_focus_conv_down; a trace keeps the two-launch form, which it equals bit for bit)
+                # (glsdet_focus_conv_down; equals the two-launch form bit for bit).  OFF unless GLSDET_STEM2_FUSION=1: measured
+                # 198 us against 60 + 67 for the two launches (tools/probe/stem2_knock.py)
                 x = self.e.focus_conv_down(img, self._pack(q, [self._bn_part(q)], 16), "silu", self._pack(d2, [self._bn_part(d2)], 32), "silu")
                 fused_down = True
             else:

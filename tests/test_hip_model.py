@@ -110,7 +110,8 @@ def test_fused_focus_stem_vs_reference_golden_and_oracle(engines, golden, mode, 
 @pytest.mark.parametrize("mode", ["f32", "f16"])
 @pytest.mark.parametrize("cout,hw", [(64, (64, 96)), (64, (72, 136)), (40, (32, 40)), (64, (70, 130)), (64, (132, 260))])
 def test_fused_focus_stem_and_first_downsampling_conv_equal_two_launches_bit_for_bit(engines, mode, cout, hw):
-    """glsdet_focus_conv_down (Focus + stem 3x3 + dark2.0's 3x3 stride 2 in one launch; the stem is recomputed on the
+    """(the detectors use it only under GLSDET_STEM2_FUSION=1: DESIGN.md section 3, it is slower than the two launches)
+    glsdet_focus_conv_down (Focus + stem 3x3 + dark2.0's 3x3 stride 2 in one launch; the stem is recomputed on the
     halo of every output tile into LDS, rounded to the storage type, zero outside the stem's map) against
     glsdet_focus_conv followed by the stride-2 conv (generic kernel): identical bits in both precisions, also where the
     stem's map has odd extents, one tile, ragged tile borders; and against the oracle."""
