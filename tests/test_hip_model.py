@@ -184,11 +184,12 @@ def test_model_f32_meets_north_star_tolerance(golden, shapes, tag):
 
 @pytest.mark.parametrize("tag", ["base_s_seed0", "gl_tiny_seed0", "gl_s_seed0"])
 def test_model_f16_close_to_reference(golden, shapes, tag):
-    """fp16 storage / fp32 accumulate (the benchmarked mode): each of ~80 layers rounds its
-    output to 11 bits, and the nets amplify that ~100x, so the bar is stated relative to
-    the logit range: max error <= 0.15 * max|logit|, rms error <= 0.03 * max|logit|
-    (measured round 1: 0.05-0.07 and 0.003-0.011).  The fp16 kernels themselves are pinned
-    per op (4e-3, tests/test_hip_ops.py) and per block (2e-2, above)."""
+    """fp16 storage / fp32 accumulate (the benchmarked mode), absolute backstop: max error <= 0.10 * max|logit|, rms error
+    <= 0.015 * max|logit| (measured: 0.058-0.072 and 0.008-0.011).  The 5e-2 / 1e-2 of round 1's first draft cannot be met by
+    ANY fp16-storage implementation of these random-weight nets: the oracle's own fp16-storage emulation (no HIP code)
+    sits at 0.043 / 0.0076 (gl_s) and 0.076 / 0.0097 (base_s) -- tools/f16_attribution.py, DESIGN.md section 4a.  The bars
+    that bind are in tests/test_f16_emulation.py: every stored tensor within one fp16 ulp of the teacher-forced emulation, and
+    the free-running error within 1.5x (rms) / 2x (max) of the emulation's.  Per op 4e-3, per block 2e-2."""
     from glsdet_amd.detector import HipDetector
     meta, sd, x, outs, decoded = model_case(golden, shapes, tag)
     det = HipDetector(meta["model"], sd, dtype="f16")
@@ -197,8 +198,8 @@ def test_model_f16_close_to_reference(golden, shapes, tag):
     err = max(float((g.cpu() - w).abs().max()) for g, w in zip(got, outs))
     rms = float(torch.cat([(g.cpu() - w).flatten() for g, w in zip(got, outs)]).pow(2).mean().sqrt())
     print("f16 %s: max|err| %.3e rms %.3e max|logit| %.2f" % (tag, err, rms, scale))
-    assert err <= 0.15 * max(1.0, scale)
-    assert rms <= 0.03 * max(1.0, scale)
+    assert err <= 0.10 * max(1.0, scale)
+    assert rms <= 0.015 * max(1.0, scale)
 
 
 def _nms_ref(decoded, nc, conf, thr):
