@@ -27,7 +27,7 @@ template <int CO_T, int PX_T, int KB, typename TO>
 constexpr int conv_lds_bytes(bool wide) {        // wide: fp32 staging of an fp16 output tile (residual layers)
   constexpr int stage = 2 * (CO_T + PX_T) * (KB + 16);
   const int epi = epi_bytes<TO>(CO_T, PX_T, wide);
-  return stage > epi ? stage : epi;
+  return (stage > epi ? stage : epi) + CO_T * 8;   // + scale | bias of the cout tile (fp32), parked in LDS for the epilogue
 }
 
 // UT ("uniform tap"): Cin * sizeof(T) is a multiple of KB, so all chunks of a K step belong to ONE
@@ -216,8 +216,22 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
   const int a_off = (wco * WT_CO + l31) * RS + lh * 16;
   const int b_off = CO_T * RS + (wpx * WT_PX + l31) * RS + lh * 16;
 
+  // folded-BN scale / bias of the cout tile: requested FIRST (so that waiting for them waits for nothing else), parked in
+  // LDS behind the staging area once step 0's operands have landed anyway -- the epilogue then starts without a dependent
+  // global round trip (these launches are one round of workgroups whose life IS such a chain) and no register lives
+  // through the K loop for it (holding them in registers cost the 64x64 tile two of its six waves per SIMD)
+  unsigned char* sSB = smem + conv_lds_bytes<CO_T, PX_T, KB, TO>(sizeof(TO) == 2 && a.res != nullptr) - CO_T * 8;
+  f32x4 sb_s = {0.f, 0.f, 0.f, 0.f}, sb_b = {0.f, 0.f, 0.f, 0.f};
+  if (tid < CO_T / 4 && co0 + tid * 4 < a.cout_pad) {
+    sb_s = *reinterpret_cast<const f32x4*>(a.scale + co0 + tid * 4);
+    sb_b = *reinterpret_cast<const f32x4*>(a.bias + co0 + tid * 4);
+  }
   gload(0, ra0, rb0);
   lstore(0, ra0, rb0);
+  if (tid < CO_T / 4) {
+    *reinterpret_cast<f32x4*>(sSB + tid * 16) = sb_s;
+    *reinterpret_cast<f32x4*>(sSB + CO_T * 4 + tid * 16) = sb_b;
+  }
   if (nsteps > 1) gload(1, ra1, rb1);
   if (nsteps > 2) gload(2, ra2, rb2);
   __syncthreads();
@@ -262,11 +276,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const int co_l = wco * WT_CO + i * 32 + 8 * g + 4 * lh;
-      f32x4 sc = {0.f, 0.f, 0.f, 0.f}, bi = {0.f, 0.f, 0.f, 0.f};
-      if (co0 + co_l < a.cout_pad) {
-        sc = *reinterpret_cast<const f32x4*>(a.scale + co0 + co_l);
-        bi = *reinterpret_cast<const f32x4*>(a.bias + co0 + co_l);
-      }
+      const f32x4 sc = *reinterpret_cast<const f32x4*>(sSB + co_l * 4), bi = *reinterpret_cast<const f32x4*>(sSB + CO_T * 4 + co_l * 4);
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         const int px_l = wpx * WT_PX + j * 32 + l31;
