@@ -35,6 +35,10 @@ struct BneckGeom {
   static constexpr int XC_BYTES = 192 * XS, P1_BYTES = NSLOT * RS1;
   static constexpr int REG_B = XC_BYTES > P1_BYTES ? XC_BYTES : P1_BYTES;
   static constexpr int STAGE = REG_A + REG_B;
+  // parked scale | bias of the 1x1 (CM * 8 bytes) and of the 3x3's cout tile (CO_T * 8 bytes): behind everything else
+  static constexpr int epi_w = 128 * (CO_T * 4 + 16);
+  static constexpr int SB_OFF = ((STAGE > epi_w ? STAGE : epi_w) + 15) / 16 * 16;
+  static constexpr int LDS = SB_OFF + (CM + CO_T) * 8;
 };
 
 template <typename T, int CM, int CO_T, int KB, int RING>
@@ -74,6 +78,17 @@ __global__ __launch_bounds__(256) void conv_bneck_kernel(const BneckArgs b, cons
   const auto xrs = gls_make_rsrc(a.x_lo, a.x_bytes);
   const auto wrs = gls_make_rsrc(a.w, a.w_bytes);
   const auto w0rs = gls_make_rsrc(b.w0, b.w0_bytes);
+  // both convs' folded-BN scale / bias: requested first, parked in LDS once the first x chunk has landed anyway
+  unsigned char* sSB0 = smem + G::SB_OFF;                  // [scale0 | bias0] (CM floats each)
+  unsigned char* sSB = sSB0 + CM * 8;                      // [scale | bias] of this cout tile (CO_T floats each)
+  f32x4 sbv = {0.f, 0.f, 0.f, 0.f};
+  {
+    constexpr int N0 = CM / 4, N1 = CO_T / 4;              // f32x4 pieces: scale0, bias0, scale, bias
+    if (tid < N0) sbv = *reinterpret_cast<const f32x4*>(b.scale0 + tid * 4);
+    else if (tid < 2 * N0) sbv = *reinterpret_cast<const f32x4*>(b.bias0 + (tid - N0) * 4);
+    else if (tid < 2 * N0 + N1) { if (co0 + (tid - 2 * N0) * 4 < a.cout_pad) sbv = *reinterpret_cast<const f32x4*>(a.scale + co0 + (tid - 2 * N0) * 4); }
+    else if (tid < 2 * N0 + 2 * N1) { if (co0 + (tid - 2 * N0 - N1) * 4 < a.cout_pad) sbv = *reinterpret_cast<const f32x4*>(a.bias + co0 + (tid - 2 * N0 - N1) * 4); }
+  }
 
   // ------------------------------------------------------------------ phase A: the 1x1 on the halo
   {
@@ -126,6 +141,7 @@ __global__ __launch_bounds__(256) void conv_bneck_kernel(const BneckArgs b, cons
         const int q = tid + i * 256;
         if (q < CM * CPRW) *reinterpret_cast<u32x4*>(smem + W1_OFF + (q / CPRW) * XS + kc * 16) = rw[i];
       }
+      if (cc == 0 && tid < (CM + CO_T) / 2) *reinterpret_cast<f32x4*>(sSB0 + tid * 16) = sbv;
       if (cc + 1 < nch0) load_chunk(cc + 1);
       __syncthreads();
       const unsigned char* sA = smem + W1_OFF + (cb * 32 + l31) * XS + lh * 16;
@@ -155,7 +171,7 @@ __global__ __launch_bounds__(256) void conv_bneck_kernel(const BneckArgs b, cons
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const int co = cb * 32 + 8 * g + 4 * lh;
-          const f32x4 sc = *reinterpret_cast<const f32x4*>(b.scale0 + co), bi = *reinterpret_cast<const f32x4*>(b.bias0 + co);
+          const f32x4 sc = *reinterpret_cast<const f32x4*>(sSB0 + co * 4), bi = *reinterpret_cast<const f32x4*>(sSB0 + CM * 4 + co * 4);
           const f32x4 xv = {acc[i][4 * g], acc[i][4 * g + 1], acc[i][4 * g + 2], acc[i][4 * g + 3]};
           f32x4 yv = scale_bias_act4<T>(xv, sc, bi, b.act0);
           if (!inside) yv = f32x4{0.f, 0.f, 0.f, 0.f};   // the 3x3's zero padding
@@ -250,11 +266,7 @@ __global__ __launch_bounds__(256) void conv_bneck_kernel(const BneckArgs b, cons
 #pragma unroll
     for (int gq = 0; gq < 4; ++gq) {
       const int co_l = wco * WT_CO + i * 32 + 8 * gq + 4 * lh;
-      f32x4 sc = {0.f, 0.f, 0.f, 0.f}, bi = {0.f, 0.f, 0.f, 0.f};
-      if (co0 + co_l < a.cout_pad) {
-        sc = *reinterpret_cast<const f32x4*>(a.scale + co0 + co_l);
-        bi = *reinterpret_cast<const f32x4*>(a.bias + co0 + co_l);
-      }
+      const f32x4 sc = *reinterpret_cast<const f32x4*>(sSB + co_l * 4), bi = *reinterpret_cast<const f32x4*>(sSB + CO_T * 4 + co_l * 4);
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         const int px_l = wpx * WT_PX + j * 32 + l31;
@@ -272,10 +284,8 @@ __global__ __launch_bounds__(256) void conv_bneck_kernel(const BneckArgs b, cons
 template <typename T, int CM, int CO_T, int KB, int RING>
 static int launch_bneck(const BneckArgs& b0, hipStream_t st) {
   using G = BneckGeom<T, CM, CO_T, KB, RING>;
-  constexpr int epiw = epi_bytes<T>(CO_T, 128, true);
-  constexpr int ldsw = G::STAGE > epiw ? G::STAGE : epiw;
-  const int epi = epi_bytes<T>(CO_T, 128, b0.c.res != nullptr);
-  const int lds = G::STAGE > epi ? G::STAGE : epi;
+  constexpr int ldsw = G::LDS;
+  const int lds = G::LDS;
   auto kern = conv_bneck_kernel<T, CM, CO_T, KB, RING>;
   static int attr_lds = 64 * 1024;
   if (ldsw > attr_lds) {

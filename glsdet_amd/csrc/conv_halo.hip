@@ -244,6 +244,16 @@ __device__ __forceinline__ void halo_lds_barrier() {
 // stored DE-INTERLEAVED (even columns first, then the odd ones), so that the 16 pixels of a fragment read, which are two
 // input columns apart, are consecutive LDS rows again: tap (r, s) of output pixel (oy, ox) is slot
 // (2*oy + r) * PW + ox + (s & 1 ? HALF : s >> 1) -- a per-lane base plus a per-tap constant, exactly as for stride 1.
+// byte offset of the parked scale | bias (CO_T * 8 bytes): behind the staging area AND this launch's epilogue tile
+// (wide = fp32 staging of a residual layer)
+template <typename T, typename TO, int CO_T, int KS, int RING, int KB, int STR>
+__host__ __device__ constexpr int halo_ring_sb_off(bool wide) {
+  constexpr int PH = 7 * STR + KS, PW = 15 * STR + KS;
+  constexpr int stage = RING * CO_T * KB + PH * PW * (KB + 16);
+  const int epi = epi_bytes<TO>(CO_T, 128, wide);
+  return ((stage > epi ? stage : epi) + 15) / 16 * 16;
+}
+
 template <typename T, typename TO, int CO_T, int KS, int RING, int KB = 128, int STR = 1, bool CH = false, bool GN = false>
 __global__ __launch_bounds__(256) void conv_halo_ring_kernel(const ConvArgs a, const int tiles_x, const int tiles_y) {
   constexpr int TH = 8, TW = 16, WCO = 2;
@@ -283,6 +293,15 @@ __global__ __launch_bounds__(256) void conv_halo_ring_kernel(const ConvArgs a, c
   const int tx0 = (rest - r1 * tiles_x) * TW;
   const int img = gls_div(r1, a.ty_mul, a.ty_sh);
   const int ty0 = (r1 - img * tiles_y) * TH;
+
+  // folded-BN scale / bias of the cout tile: requested first, parked in LDS behind the staging / epilogue areas when the
+  // first patch has landed anyway (conv.hip: the epilogue then starts without a dependent global round trip)
+  unsigned char* sSB = smem + halo_ring_sb_off<T, TO, CO_T, KS, RING, KB, STR>(sizeof(TO) == 2 && a.res != nullptr);
+  f32x4 sb_s = {0.f, 0.f, 0.f, 0.f}, sb_b = {0.f, 0.f, 0.f, 0.f};
+  if (tid < CO_T / 4 && co0 + tid * 4 < a.cout_pad) {
+    sb_s = *reinterpret_cast<const f32x4*>(a.scale + co0 + tid * 4);
+    sb_b = *reinterpret_cast<const f32x4*>(a.bias + co0 + tid * 4);
+  }
 
   const int kc = tid % CPRW;
   const auto xrs = gls_make_rsrc(a.x_lo, a.x_bytes);
@@ -376,6 +395,10 @@ __global__ __launch_bounds__(256) void conv_halo_ring_kernel(const ConvArgs a, c
 #pragma unroll
   for (int g = 0; g < RING - 1; ++g) dma_next();
   store_patch();                                   // (the compiler waits for the patch registers here)
+  if (tid < CO_T / 4) {
+    *reinterpret_cast<f32x4*>(sSB + tid * 16) = sb_s;
+    *reinterpret_cast<f32x4*>(sSB + CO_T * 4 + tid * 16) = sb_b;
+  }
 
   int g = 0;                                       // ring slot of the tap being multiplied
   auto mma_tap = [&](int tap_off) __attribute__((always_inline)) {
@@ -428,11 +451,7 @@ __global__ __launch_bounds__(256) void conv_halo_ring_kernel(const ConvArgs a, c
 #pragma unroll
     for (int gq = 0; gq < 4; ++gq) {
       const int co_l = wco * WT_CO + i * 32 + 8 * gq + 4 * lh;
-      f32x4 sc = {0.f, 0.f, 0.f, 0.f}, bi = {0.f, 0.f, 0.f, 0.f};
-      if (co0 + co_l < a.cout_pad) {
-        sc = *reinterpret_cast<const f32x4*>(a.scale + co0 + co_l);
-        bi = *reinterpret_cast<const f32x4*>(a.bias + co0 + co_l);
-      }
+      const f32x4 sc = *reinterpret_cast<const f32x4*>(sSB + co_l * 4), bi = *reinterpret_cast<const f32x4*>(sSB + CO_T * 4 + co_l * 4);
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         const int px_l = wpx * WT_PX + j * 32 + l31;
@@ -459,11 +478,8 @@ static int launch_halo_ring(const ConvArgs& a, hipStream_t st) {
   }
   if (a.w2 && !CH) GLS_FAIL(GLSDET_E_ARG, "conv2d_chain: this halo kernel has no chained form");
   if (a.gn_part && !GN) GLS_FAIL(GLSDET_E_ARG, "conv2d_gnstats: this halo kernel has no statistics form");
-  constexpr int PH = 7 * STR + KS, PW = 15 * STR + KS;
-  constexpr int stage = RING * CO_T * KB + PH * PW * (KB + 16);
-  constexpr int epiw = epi_bytes<TO>(CO_T, 128, true), ldsw = stage > epiw ? stage : epiw;
-  const int epi = epi_bytes<TO>(CO_T, 128, a.res != nullptr);
-  int lds = stage > epi ? stage : epi;
+  constexpr int ldsw = halo_ring_sb_off<T, TO, CO_T, KS, RING, KB, STR>(true) + CO_T * 8;
+  int lds = halo_ring_sb_off<T, TO, CO_T, KS, RING, KB, STR>(sizeof(TO) == 2 && a.res != nullptr) + CO_T * 8;
   if (a.w2 && chain_lds_bytes<T>(CO_T, 128, a) > lds) lds = chain_lds_bytes<T>(CO_T, 128, a);
   auto kern = conv_halo_ring_kernel<T, TO, CO_T, KS, RING, KB, STR, CH, GN>;
   static int attr_lds = 64 * 1024;
