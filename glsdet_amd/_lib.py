@@ -10,7 +10,7 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "lib", "libglsdet_hip.so")
-ABI_VERSION = 8
+ABI_VERSION = 9
 CAPTURE_LOCK = threading.RLock()        # hipGraph captures are serialised across host threads
 
 F16, F32 = 0, 1
@@ -61,6 +61,8 @@ _SIGS = {
                                            C.POINTER(C.c_float)]),
     "glsdet_conv2d_tune": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_float)]),
     "glsdet_dwconv2d": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
+    "glsdet_dwconv2d_dilated": (C.c_int, [C.POINTER(ConvDesc), C.c_int32, C.c_void_p]),
+    "glsdet_gate": (C.c_int, [C.POINTER(View), C.POINTER(View), C.POINTER(View), C.POINTER(View), C.c_int32, C.c_void_p]),
     "glsdet_conv_weight_elems": (C.c_int64, [C.c_int32] * 5),
     "glsdet_conv_kpad": (C.c_int32, [C.c_int32] * 4),
     "glsdet_conv_cout_pad": (C.c_int32, [C.c_int32]),

@@ -154,6 +154,36 @@ __global__ __launch_bounds__(256) void scale_by_map_kernel(const unsigned char* 
   }
 }
 
+// mode 0: y[.., c] = a[.., c] * m[.., 0] + b[.., c] * m[.., 1]   (LSKblock: attn1 * sig[:, 0] + attn2 * sig[:, 1], LSK.py:46)
+// mode 1: y = a * b elementwise                                   (LSKblock: x * attn, LSK.py:48)
+template <typename T>
+__global__ __launch_bounds__(256) void gate_kernel(const unsigned char* a, long asn, long ash, long asw, const unsigned char* b, long bsn,
+                                                   long bsh, long bsw, const unsigned char* m, long msn, long msh, long msw,
+                                                   unsigned char* y, long ysn, long ysh, long ysw, int n, int H, int W, int cch, int mode) {
+  constexpr int VN = 16 / (int)sizeof(T);
+  const long total = (long)n * H * W * cch;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int cc = (int)(i % cch);
+    long p = i / cch;
+    const int w = (int)(p % W);
+    p /= W;
+    const int h = (int)(p % H), img = (int)(p / H);
+    T va[VN], vb[VN];
+    *reinterpret_cast<uint4*>(va) = *reinterpret_cast<const uint4*>(a + (img * asn + h * ash + w * asw + cc * VN) * (long)sizeof(T));
+    *reinterpret_cast<uint4*>(vb) = *reinterpret_cast<const uint4*>(b + (img * bsn + h * bsh + w * bsw + cc * VN) * (long)sizeof(T));
+    if (mode == 0) {
+      const T* mp = reinterpret_cast<const T*>(m) + img * msn + h * msh + w * msw;
+      const float g0 = (float)mp[0], g1 = (float)mp[1];
+#pragma unroll
+      for (int e = 0; e < VN; ++e) va[e] = (T)((float)va[e] * g0 + (float)vb[e] * g1);
+    } else {
+#pragma unroll
+      for (int e = 0; e < VN; ++e) va[e] = (T)((float)va[e] * (float)vb[e]);
+    }
+    *reinterpret_cast<uint4*>(y + (img * ysn + h * ysh + w * ysw + cc * VN) * (long)sizeof(T)) = *reinterpret_cast<uint4*>(va);
+  }
+}
+
 static inline unsigned grid_of(long items) {
   long g = (items + 255) / 256;
   return (unsigned)(g < 1 ? 1 : (g > 8192 ? 8192 : g));
@@ -242,6 +272,39 @@ extern "C" int glsdet_scale_by_map(const glsdet_view* x, const glsdet_view* map,
       hipLaunchKernelGGL(scale_by_map_kernel<f16>, dim3(g), dim3(256), 0, st, (const unsigned char*)vx.base, vx.sn, vx.sh, vx.sw, (const unsigned char*)vm.base, vm.sn, vm.sh, vm.sw, (unsigned char*)vy.base, vy.sn, vy.sh, vy.sw, vx.n, vx.h, vx.w, vx.c / vn);
     else
       hipLaunchKernelGGL(scale_by_map_kernel<float>, dim3(g), dim3(256), 0, st, (const unsigned char*)vx.base, vx.sn, vx.sh, vx.sw, (const unsigned char*)vm.base, vm.sn, vm.sh, vm.sw, (unsigned char*)vy.base, vy.sn, vy.sh, vy.sw, vx.n, vx.h, vx.w, vx.c / vn);
+    GLS_HIP(hipGetLastError());
+    return 0;
+  };
+  return submit(std::move(op), stream);
+}
+
+extern "C" int glsdet_gate(const glsdet_view* a, const glsdet_view* b, const glsdet_view* map, const glsdet_view* y, int32_t mode,
+                           void* stream) {
+  if (!a || !b || !y || mode < 0 || mode > 1 || (mode == 0 && !map)) GLS_FAIL(GLSDET_E_ARG, "gate: bad argument");
+  int rc;
+  if ((rc = check_view(*a, "gate.a"))) return rc;
+  if ((rc = check_view(*b, "gate.b"))) return rc;
+  if ((rc = check_view(*y, "gate.y"))) return rc;
+  if (!same_extent(*a, *y) || !same_extent(*b, *y) || a->dtype != y->dtype || b->dtype != y->dtype) GLS_FAIL(GLSDET_E_ARG, "gate: a / b / y mismatch");
+  glsdet_view vm = *a;
+  if (mode == 0) {
+    if ((rc = check_view(*map, "gate.map", false))) return rc;
+    if (map->n != y->n || map->h != y->h || map->w != y->w || map->c < 2 || map->dtype != y->dtype) GLS_FAIL(GLSDET_E_ARG, "gate: map must be [n,h,w,>=2] of y's dtype");
+    vm = *map;
+  }
+  const glsdet_view va = *a, vb = *b, vy = *y;
+  OpRecord op;
+  op.kind = 3;
+  op.flops = 0;
+  op.bytes = 3.0 * va.n * va.h * va.w * va.c * dtype_size(va.dtype);
+  op.name = mode == 0 ? "gate(a * m0 + b * m1)" : "gate(a * b)";
+  op.launch = [=](hipStream_t st) -> int {
+    const int vn = 16 / dtype_size(va.dtype);
+    const unsigned g = grid_of((long)va.n * va.h * va.w * (va.c / vn));
+    if (va.dtype == GLSDET_F16)
+      hipLaunchKernelGGL(gate_kernel<f16>, dim3(g), dim3(256), 0, st, (const unsigned char*)va.base, va.sn, va.sh, va.sw, (const unsigned char*)vb.base, vb.sn, vb.sh, vb.sw, (const unsigned char*)vm.base, vm.sn, vm.sh, vm.sw, (unsigned char*)vy.base, vy.sn, vy.sh, vy.sw, va.n, va.h, va.w, va.c / vn, mode);
+    else
+      hipLaunchKernelGGL(gate_kernel<float>, dim3(g), dim3(256), 0, st, (const unsigned char*)va.base, va.sn, va.sh, va.sw, (const unsigned char*)vb.base, vb.sn, vb.sh, vb.sw, (const unsigned char*)vm.base, vm.sn, vm.sh, vm.sw, (unsigned char*)vy.base, vy.sn, vy.sh, vy.sw, va.n, va.h, va.w, va.c / vn, mode);
     GLS_HIP(hipGetLastError());
     return 0;
   };

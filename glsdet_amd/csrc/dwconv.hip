@@ -13,7 +13,7 @@ template <> struct DwVec<float> { typedef f32x4 type; static constexpr int N = 4
 struct DwArgs {
   const unsigned char* x; const unsigned char* w; const float* scale; const float* bias; unsigned char* y;
   long x_sn, x_sh, x_sw, y_sn, y_sh, y_sw;
-  int N, H, W, C, Ho, Wo, R, S, stride, pad, act;
+  int N, H, W, C, Ho, Wo, R, S, stride, pad, act, dil;
 };
 
 template <typename T>
@@ -33,10 +33,10 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const DwArgs a) {
 #pragma unroll
     for (int e = 0; e < VN; ++e) acc[e] = 0.f;
     for (int r = 0; r < a.R; ++r) {
-      const int hi = ho * a.stride - a.pad + r;
+      const int hi = ho * a.stride - a.pad + r * a.dil;
       if (hi < 0 || hi >= a.H) continue;
       for (int s = 0; s < a.S; ++s) {
-        const int wi = wo * a.stride - a.pad + s;
+        const int wi = wo * a.stride - a.pad + s * a.dil;
         if (wi < 0 || wi >= a.W) continue;
         const V xv = *reinterpret_cast<const V*>(a.x + (n * a.x_sn + hi * a.x_sh + wi * a.x_sw + cc * VN) * (long)sizeof(T));
         const V wv = *reinterpret_cast<const V*>(a.w + ((long)(r * a.S + s) * a.C + cc * VN) * (long)sizeof(T));
@@ -61,8 +61,11 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const DwArgs a) {
 
 using namespace glsdet;
 
-extern "C" int glsdet_dwconv2d(const glsdet_conv_desc* d, void* stream) {
+extern "C" int glsdet_dwconv2d(const glsdet_conv_desc* d, void* stream) { return glsdet_dwconv2d_dilated(d, 1, stream); }
+
+extern "C" int glsdet_dwconv2d_dilated(const glsdet_conv_desc* d, int32_t dilation, void* stream) {
   if (!d) GLS_FAIL(GLSDET_E_ARG, "dwconv2d: null descriptor");
+  if (dilation < 1 || dilation > 8) GLS_FAIL(GLSDET_E_ARG, "dwconv2d: dilation 1..8");
   const glsdet_view &x = d->x, &y = d->y;
   int rc;
   if ((rc = check_view(x, "dwconv2d.x"))) return rc;
@@ -71,7 +74,7 @@ extern "C" int glsdet_dwconv2d(const glsdet_conv_desc* d, void* stream) {
   if (d->R < 1 || d->S < 1 || d->R > 15 || d->S > 15 || d->stride < 1 || d->stride > 4 || d->pad < 0)
     GLS_FAIL(GLSDET_E_ARG, "dwconv2d: bad R/S/stride/pad");
   if (d->res.base) GLS_FAIL(GLSDET_E_ARG, "dwconv2d: residual not supported (it belongs to the pointwise conv)");
-  const int Ho = (x.h + 2 * d->pad - d->R) / d->stride + 1, Wo = (x.w + 2 * d->pad - d->S) / d->stride + 1;
+  const int Ho = (x.h + 2 * d->pad - dilation * (d->R - 1) - 1) / d->stride + 1, Wo = (x.w + 2 * d->pad - dilation * (d->S - 1) - 1) / d->stride + 1;
   if (y.n != x.n || y.h != Ho || y.w != Wo) GLS_FAIL(GLSDET_E_ARG, "dwconv2d: output extent mismatch");
   if (!d->w || !d->scale || !d->bias || (((uintptr_t)d->w) & 15)) GLS_FAIL(GLSDET_E_ARG, "dwconv2d: bad weight/scale/bias");
   if (d->act < 0 || d->act > 3) GLS_FAIL(GLSDET_E_ARG, "dwconv2d: bad act");
@@ -80,14 +83,14 @@ extern "C" int glsdet_dwconv2d(const glsdet_conv_desc* d, void* stream) {
   a.y = (unsigned char*)y.base;
   a.x_sn = x.sn; a.x_sh = x.sh; a.x_sw = x.sw; a.y_sn = y.sn; a.y_sh = y.sh; a.y_sw = y.sw;
   a.N = x.n; a.H = x.h; a.W = x.w; a.C = x.c; a.Ho = Ho; a.Wo = Wo;
-  a.R = d->R; a.S = d->S; a.stride = d->stride; a.pad = d->pad; a.act = d->act;
+  a.R = d->R; a.S = d->S; a.stride = d->stride; a.pad = d->pad; a.act = d->act; a.dil = dilation;
   const int dt = x.dtype;
   OpRecord op;
   op.kind = 0;
   op.flops = 2.0 * (double)x.n * Ho * Wo * x.c * d->R * d->S;
   op.bytes = ((double)x.n * x.h * x.w + (double)x.n * Ho * Wo) * x.c * dtype_size(dt);
   char nm[96];
-  snprintf(nm, sizeof nm, "dwconv<%s> %dx%d s%d c%d", dt ? "f32" : "f16", d->R, d->S, d->stride, x.c);
+  snprintf(nm, sizeof nm, "dwconv<%s> %dx%d s%d d%d c%d", dt ? "f32" : "f16", d->R, d->S, d->stride, dilation, x.c);
   op.name = nm;
   op.launch = [a, dt](hipStream_t st) -> int {
     const long items = (long)a.N * a.Ho * a.Wo * (a.C / (dt == GLSDET_F16 ? 8 : 4));

@@ -508,17 +508,25 @@ class Engine:
         sc[:C_], bi[:C_] = scale.float(), bias.float()
         return (self.upload(wp.to(_TORCH_DT[self.dt])), self.upload(sc), self.upload(bi), C_, R, S)
 
-    def dwconv(self, x: TView, packed, stride: int, pad: int, act: str, out: Optional[TView] = None) -> TView:
+    def gate(self, a: TView, b: TView, gmap: Optional[TView], out: Optional[TView] = None) -> TView:
+        """glsdet_gate: a * map[0] + b * map[1] with a map, a * b without"""
+        if out is None:
+            out = self.tensor(a.n, a.h, a.w, a.c, a.dtype)
+        check(self.lib.glsdet_gate(C.byref(a.as_c()), C.byref(b.as_c()), C.byref(gmap.as_c()) if gmap is not None else None,
+                                   C.byref(out.as_c()), 0 if gmap is not None else 1, _stream_ptr(self.stream)), "gate")
+        return out
+
+    def dwconv(self, x: TView, packed, stride: int, pad: int, act: str, out: Optional[TView] = None, dilation: int = 1) -> TView:
         wdev, sdev, bdev, C_, R, S = packed
-        ho = (x.h + 2 * pad - R) // stride + 1
-        wo = (x.w + 2 * pad - S) // stride + 1
+        ho = (x.h + 2 * pad - dilation * (R - 1) - 1) // stride + 1
+        wo = (x.w + 2 * pad - dilation * (S - 1) - 1) // stride + 1
         if out is None:
             out = self.tensor(x.n, ho, wo, x.c, x.dtype)
         d = ConvDesc()
         d.x, d.y, d.res = x.as_c(), out.as_c(), View()
         d.w, d.scale, d.bias = wdev.data_ptr(), sdev.data_ptr(), bdev.data_ptr()
         d.R, d.S, d.stride, d.pad, d.act, d.tile_hint = R, S, stride, pad, ACT[act], 0
-        check(self.lib.glsdet_dwconv2d(C.byref(d), _stream_ptr(self.stream)), "dwconv2d")
+        check(self.lib.glsdet_dwconv2d_dilated(C.byref(d), dilation, _stream_ptr(self.stream)), "dwconv2d")
         return out
 
     def focus_pack(self, img: torch.Tensor, out: Optional[TView] = None) -> TView:

@@ -460,9 +460,51 @@ class NetBuilder:
             return self.plain(p + ".channel_conv", Fm, out=out)
         return self.cba(p + ".channel_conv", Fm, out=out)
 
+    def lsk_block(self, p: str, x: TView, out: Optional[TView] = None) -> TView:
+        """LSKblock (drone/models/lsk/LSK.py:27-51): depthwise 5x5, depthwise 7x7 with dilation 3 (glsdet_dwconv2d_dilated),
+        conv1 / conv2 (1x1 to dim / 2, one grouped launch) into the two halves of ONE buffer = the reference's torch.cat,
+        channel mean / max of it, 7x7 conv 2 -> 2 + sigmoid (its input channels swapped at pack time: the reference
+        concatenates [mean, max], glsdet_channel_maxmean writes [max, mean]), glsdet_gate for
+        attn1 * sig0 + attn2 * sig1, 1x1 to dim, glsdet_gate for x * attn."""
+        e = self.e
+        dim = self.sd[p + ".conv0.weight"].shape[0]
+        half = self.sd[p + ".conv1.weight"].shape[0]
+
+        def dw(q):
+            key = (q, "dw")
+            if key not in self._packed:
+                w = self.sd[q + ".weight"]
+                self._packed[key] = e.pack_dw(w, torch.ones(w.shape[0]), self.sd[q + ".bias"], x.c)
+            return self._packed[key]
+        a1 = e.dwconv(x, dw(p + ".conv0"), 1, 2, "none")
+        self._rec(p + ".conv0", a1, 0, dim)
+        a2 = e.dwconv(a1, dw(p + ".conv_spatial"), 1, 9, "none", dilation=3)
+        self._rec(p + ".conv_spatial", a2, 0, dim)
+        cat = e.tensor(x.n, x.h, x.w, 2 * half)
+        h1, h2 = cat.channels(0, half), cat.channels(half, 2 * half)
+        e.conv_group([a1, a2], [self._pack(p + ".conv1", [self._plain_part(p + ".conv1")], a1.c),
+                                self._pack(p + ".conv2", [self._plain_part(p + ".conv2")], a2.c)], 1, 0, "none", outs=[h1, h2])
+        self._rec(p + ".conv1", cat, 0, half)
+        self._rec(p + ".conv2", cat, half, 2 * half)
+        mm = e.channel_maxmean(cat)                        # [max, mean]
+        key = (p + ".conv_squeeze", "swapped")
+        if key not in self._packed:
+            w = self.sd[p + ".conv_squeeze.weight"]
+            self._packed[key] = e.pack_conv([(w[:, [1, 0]].contiguous(), torch.ones(w.shape[0]), self.sd[p + ".conv_squeeze.bias"])], mm.c)
+        sig = e.conv(mm, self._packed[key], 1, 3, "sigmoid")
+        self._rec(p + ".conv_squeeze", sig, 0, 2)
+        mix = e.gate(h1, h2, sig)
+        self._rec(p + ".mix", mix, 0, half)
+        attn = self.plain(p + ".conv", mix)
+        y = e.gate(x, attn, None, out=out)
+        self._rec(p + ".out", y, 0, dim)
+        return y
+
     def gating_variant(self, p: str) -> str:
         """Which member of the Patch_Conv_NonLocal family (new/Non_local_family.py:112-421) a checkpoint holds under p,
         told from its parameter names: the reference swaps them by editing Attention.__init__ (:258), never by a config key."""
+        if self.has(p + ".conv_spatial.weight"):
+            return "lsk"                                   # drone/models/lsk/LSK.py (darknet_lsk.py)
         if self.has(p + ".patchconv_lt_nonlocal.feat_patchconv_lt.conv.weight"):
             return "44"
         if self.has(p + ".attention_map.conv.weight"):
@@ -479,6 +521,8 @@ class NetBuilder:
             t = self.patch_conv_nonlocal_adapt_new(p + ".spatial_gating_unit", t)
         elif kind == "new":
             t = self.patch_conv_nonlocal_new(p + ".spatial_gating_unit", t)
+        elif kind == "lsk":
+            t = self.lsk_block(p + ".spatial_gating_unit", t)
         else:
             raise ValueError("Attention cannot gate with Patch_Conv_NonLocal_%s: it halves the map (use it as a neck block)" % kind)
         return self.plain(p + ".proj_2", t, out=out, res=x)

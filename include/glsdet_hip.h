@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GLSDET_ABI_VERSION 8
+#define GLSDET_ABI_VERSION 9
 
 enum { GLSDET_F16 = 0, GLSDET_F32 = 1 };
 enum { GLSDET_ACT_NONE = 0, GLSDET_ACT_SILU = 1, GLSDET_ACT_RELU = 2, GLSDET_ACT_LRELU = 3,
@@ -137,6 +137,9 @@ int     glsdet_bottleneck_tune(const glsdet_conv_desc* c1, const glsdet_conv_des
  * mmcv DepthwiseSeparableConvModule).  Same descriptor; x.c == y.c; w = [R*S][x.c] elements of
  * x.dtype (tap-major), scale/bias fp32 [x.c]; res must be empty. */
 int     glsdet_dwconv2d(const glsdet_conv_desc* d, void* stream);
+/* the same with a dilation (LSKblock.conv_spatial: 7x7, dilation 3, padding 9, groups = dim; drone/models/lsk/LSK.py:31);
+ * y extent = floor((x + 2 pad - dilation (k - 1) - 1) / stride) + 1.                                                  */
+int     glsdet_dwconv2d_dilated(const glsdet_conv_desc* d, int32_t dilation, void* stream);
 /* number of ELEMENTS of the packed weight buffer for (cout, R, S, cin, dtype)           */
 int64_t glsdet_conv_weight_elems(int32_t cout, int32_t R, int32_t S, int32_t cin, int32_t dtype);
 int32_t glsdet_conv_kpad(int32_t R, int32_t S, int32_t cin, int32_t dtype);
@@ -319,6 +322,13 @@ int64_t glsdet_conv2d_gnstats_bytes(int32_t n, int32_t ho, int32_t wo, int32_t g
 int     glsdet_conv2d_gnstats(const glsdet_conv_desc* d, int32_t groups, void* stats, void* stream);
 int     glsdet_conv2d_gnstats_tune(const glsdet_conv_desc* d, int32_t groups, void* stats, void* stream, int32_t* best_hint,
                                    float* best_us);
+
+/* The two elementwise steps of LSKblock.forward (drone/models/lsk/LSK.py:46-48) on NHWC views of one dtype:
+ *   mode 0: y[.., c] = a[.., c] * map[.., 0] + b[.., c] * map[.., 1]     (`attn1 * sig[:, 0] + attn2 * sig[:, 1]`)
+ *   mode 1: y = a * b                                                     (`x * attn`; map may be NULL)
+ * fp32 arithmetic, one rounding.  y may alias a or b.                                                                 */
+int glsdet_gate(const glsdet_view* a, const glsdet_view* b, const glsdet_view* map, const glsdet_view* y, int32_t mode,
+                void* stream);
 
 /* MPHead.forward_proxy (ufp/mmdet/models/dense_heads/mp_head.py:105-121).
  *   feat : view [n,h,w,C] (the gfl_cls_conv output), engine dtype

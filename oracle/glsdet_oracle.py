@@ -362,11 +362,36 @@ def patch_conv_nonlocal_adapt(sd: SD, p: str, x: Tensor) -> Tensor:
     return base_conv(sd, p + ".channel_conv", both)
 
 
+def lsk_block(sd: SD, p: str, x: Tensor) -> Tensor:
+    """LSKblock (drone/models/lsk/LSK.py:27-51): depthwise 5x5 -> depthwise 7x7 dilation 3 -> a 1x1 each to dim/2 ->
+    [mean_c, max_c] of their concat -> 7x7 conv 2->2 -> sigmoid -> attn1 * sig0 + attn2 * sig1 -> 1x1 to dim -> x * attn.
+    (The HIP path stores every intermediate; the fp16-storage emulation rounds at the same points.)"""
+    dim = x.shape[1]
+    a1 = _q(F.conv2d(x, _qw(sd[p + ".conv0.weight"], p + ".conv0"), sd[p + ".conv0.bias"], 1, 2, 1, dim), p + ".conv0")
+    a2 = _q(F.conv2d(a1, _qw(sd[p + ".conv_spatial.weight"], p + ".conv_spatial"), sd[p + ".conv_spatial.bias"], 1, 9, 3, dim),
+            p + ".conv_spatial")
+    a1 = plain_conv(sd, p + ".conv1", a1)
+    a2 = plain_conv(sd, p + ".conv2", a2)
+    attn = torch.cat((a1, a2), 1)
+    agg = _q(torch.cat((attn.mean(1, keepdim=True), attn.max(1, keepdim=True)[0]), 1), p + ".agg")
+    sig = plain_conv(sd, p + ".conv_squeeze", agg, 1, 3, post=torch.sigmoid)
+    mix = _q(a1 * sig[:, 0:1] + a2 * sig[:, 1:2], p + ".mix")
+    attn = plain_conv(sd, p + ".conv", mix)
+    return _q(x * attn, p + ".out")
+
+
 def attention(sd: SD, p: str, x: Tensor) -> Tensor:
-    """Attention (Non_local_family.py:254-272): proj_1 1x1 -> exact GELU -> quadrant non-local
-    gating unit -> proj_2 1x1 -> + shortcut."""
+    """Attention (Non_local_family.py:254-272; lsk/LSK.py:54-71 with an LSKblock): proj_1 1x1 -> exact GELU -> gating unit
+    (told from the parameter names: the quadrant non-local unit, its attention-split form, or the LSK block) -> proj_2
+    1x1 -> + shortcut."""
     y = plain_conv(sd, p + ".proj_1", x, post=F.gelu)
-    y = patch_conv_nonlocal_new(sd, p + ".spatial_gating_unit", y)
+    g = p + ".spatial_gating_unit"
+    if g + ".conv_spatial.weight" in sd:
+        y = lsk_block(sd, g, y)
+    elif g + ".attention_map.conv.weight" in sd:
+        y = patch_conv_nonlocal_adapt_new(sd, g, y)
+    else:
+        y = patch_conv_nonlocal_new(sd, g, y)
     return plain_conv(sd, p + ".proj_2", y, post=lambda t: t + x)
 
 

@@ -106,15 +106,24 @@ def attention_cases(block):
     block("att_pcnl_adapt_new_linear", lambda: Patch_Conv_NonLocal_adapt_new(16, 16, channel_scale=0.5, channel_cat="linear"),
           (3, 16, 30, 22), seed=1)
 
-    class Outs(torch.nn.Module):            # dict -> tuple so that block() can store it
-        def __init__(self):
-            super().__init__()
-            self.backbone = AttDarknet(0.33, 0.375, out_features=("dark2", "dark3", "dark4", "dark5"))
+    # the LSK gating unit (drone/models/lsk/LSK.py; darknet_lsk.py = darknet_att.py with this Attention)
+    from models.lsk.LSK import Attention as LskAttention, LSKblock
+    from models.lsk.darknet_lsk import CSPDarknet as LskDarknet
+    block("att_lskblock_c32", lambda: LSKblock(32), (2, 32, 20, 24))
+    block("att_lsk_attention_c48_odd", lambda: LskAttention(48), (1, 48, 17, 23), seed=1)
 
-        def forward(self, x):
-            f = self.backbone(x)
-            return torch.cat([f[k].flatten(1) for k in ("dark2", "dark3", "dark4", "dark5")], 1)
-    block("att_darknet_tiny", Outs, (1, 3, 128, 160), calibrate=True)
+    def outs_of(ctor):
+        class Outs(torch.nn.Module):            # dict -> tuple so that block() can store it
+            def __init__(self):
+                super().__init__()
+                self.backbone = ctor(0.33, 0.375, out_features=("dark2", "dark3", "dark4", "dark5"))
+
+            def forward(self, x):
+                f = self.backbone(x)
+                return torch.cat([f[k].flatten(1) for k in ("dark2", "dark3", "dark4", "dark5")], 1)
+        return Outs
+    block("att_darknet_tiny", outs_of(AttDarknet), (1, 3, 128, 160), calibrate=True)
+    block("att_lsk_darknet_tiny", outs_of(LskDarknet), (1, 3, 128, 160), calibrate=True)
 
 
 PRE_CASES = [  # (in_h, in_w), input_shape (H, W), letterbox   -- synth_image(seed = index)

@@ -32,6 +32,9 @@ ORACLE = {
     "att_pcnl_adapt_new": lambda sd, x: O.patch_conv_nonlocal_adapt_new(sd, "m", x),
     "att_pcnl_adapt_new_linear": lambda sd, x: O.patch_conv_nonlocal_adapt_new(sd, "m", x),
     "att_darknet_tiny": _dark,
+    "att_lskblock_c32": lambda sd, x: O.lsk_block(sd, "m", x),
+    "att_lsk_attention_c48_odd": lambda sd, x: O.attention(sd, "m", x),
+    "att_lsk_darknet_tiny": _dark,
 }
 
 
@@ -75,6 +78,8 @@ HIP = {
     "att_pcnl_adapt_new_linear": lambda b, x: b.patch_conv_nonlocal_adapt_new("m", x),
     "att_pcnl_adapt": lambda b, x: b.patch_conv_nonlocal_adapt("m", x),
     "att_pcnl_adapt_nonlinear": lambda b, x: b.patch_conv_nonlocal_adapt("m", x),
+    "att_lskblock_c32": lambda b, x: b.lsk_block("m", x),
+    "att_lsk_attention_c48_odd": lambda b, x: b.attention("m", x),
 }
 
 
@@ -95,11 +100,13 @@ def test_hip_block_vs_reference_golden(engines, att_golden, mode, tag):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("mode", ["f32", "f16"])
-def test_hip_attention_backbone_vs_reference_golden(engines, att_golden, mode):
-    """new/darknet_att.py CSPDarknet (Attention after every stage), all four stage outputs."""
+@pytest.mark.parametrize("tag", ["att_darknet_tiny", "att_lsk_darknet_tiny"])
+def test_hip_attention_backbone_vs_reference_golden(engines, att_golden, mode, tag):
+    """new/darknet_att.py and lsk/darknet_lsk.py CSPDarknet (an Attention block after every stage: the quadrant
+    non-local gating unit resp. the LSK block), all four stage outputs."""
     from glsdet_amd.nets import NetBuilder
     eng = engines[mode]
-    sd, x, want = block_case(att_golden, "att_darknet_tiny")
+    sd, x, want = block_case(att_golden, tag)
     got = _hip_dark(NetBuilder(eng, sd), eng, x).cpu()
     torch.cuda.synchronize()
     assert got.shape == want.shape
@@ -195,7 +202,8 @@ def test_adaptive_split_is_found_on_the_device_and_survives_graph_capture(engine
 def test_gating_variant_is_told_from_the_checkpoint_keys(att_golden):
     """the reference swaps family members by editing Attention.__init__; a checkpoint says which by its names"""
     from glsdet_amd.nets import NetBuilder
-    want = {"att_pcnl_44": "44", "att_pcnl_adapt": "adapt", "att_pcnl_adapt_new": "adapt_new", "att_pcnl_new_linear": "new"}
+    want = {"att_pcnl_44": "44", "att_pcnl_adapt": "adapt", "att_pcnl_adapt_new": "adapt_new", "att_pcnl_new_linear": "new",
+            "att_lskblock_c32": "lsk"}
     for name, kind in want.items():
         sd, _, _ = block_case(att_golden, name)
         b = NetBuilder.__new__(NetBuilder)
