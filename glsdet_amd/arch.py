@@ -55,7 +55,20 @@ class _Table(OrderedDict):
         self.conv_bn(g + ".channel_conv", d, d, 3)
         self.plain(p + ".proj_2", d, d, 1)
 
-    def darknet(self, p: str, dep: float, wid: float, depthwise: bool, attention: bool = False):
+    def lsk_attention(self, p: str, d: int):
+        """Attention with an LSKblock (drone/models/lsk/LSK.py:27-71), registration order of the two __init__s."""
+        self.plain(p + ".proj_1", d, d, 1)
+        g = p + ".spatial_gating_unit"
+        for q, k in ((".conv0", 5), (".conv_spatial", 7)):          # depthwise: groups = dim
+            self[g + q + ".weight"] = (d, 1, k, k)
+            self[g + q + ".bias"] = (d,)
+        self.plain(g + ".conv1", d, d // 2, 1)
+        self.plain(g + ".conv2", d, d // 2, 1)
+        self.plain(g + ".conv_squeeze", 2, 2, 7)
+        self.plain(g + ".conv", d // 2, d, 1)
+        self.plain(p + ".proj_2", d, d, 1)
+
+    def darknet(self, p: str, dep: float, wid: float, depthwise: bool, attention=False):
         base, depth = int(wid * 64), max(round(dep * 3), 1)
         self.conv_bn(p + ".stem.conv", 12, base, 3)
         for i, (name, mult, n) in enumerate((("dark2", 2, depth), ("dark3", 4, depth * 3), ("dark4", 8, depth * 3))):
@@ -66,9 +79,9 @@ class _Table(OrderedDict):
         self.conv_bn(p + ".dark5.1.conv1", base * 16, base * 8, 1)
         self.conv_bn(p + ".dark5.1.conv2", base * 8 * 4, base * 16, 1)
         self.csp(p + ".dark5.2", base * 16, base * 16, depth, depthwise)
-        if attention:                       # drone/models/new/darknet_att.py:161-164
+        if attention:                       # drone/models/new/darknet_att.py:161-164; "lsk": drone/models/lsk/darknet_lsk.py
             for i, mult in enumerate((2, 4, 8, 16)):
-                self.attention("%s.lsk%d" % (p, i + 2), base * mult)
+                (self.lsk_attention if attention == "lsk" else self.attention)("%s.lsk%d" % (p, i + 2), base * mult)
 
     def nonlocal_block(self, p: str, cin: int, ci: int):
         self.plain(p + ".g", cin, ci, 1)
@@ -114,9 +127,9 @@ def cross_head_table(t: "_Table", h: str, num_classes: int, wid: float, dw: bool
 
 
 def state_dict_shapes(kind: str, phi: str, num_classes: int,
-                      attention_backbone: bool = False) -> "OrderedDict[str, Tuple[int, ...]]":
+                      attention_backbone=False) -> "OrderedDict[str, Tuple[int, ...]]":
     """attention_backbone=True: the backbone is new/darknet_att.py's CSPDarknet (an Attention
-    block after each stage) instead of base/darknet.py's."""
+    block after each stage) instead of base/darknet.py's; "lsk": lsk/darknet_lsk.py's (the same with LSK.Attention)."""
     if kind not in KINDS:
         raise ValueError("kind must be one of %r" % (KINDS,))
     if phi not in DEPTH:

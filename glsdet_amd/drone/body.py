@@ -96,12 +96,13 @@ class TableModule(nn.Module):
 
 class HipYoloBody(TableModule):
     kind = "base"
+    attention_backbone = False          # True: new/darknet_att.py, "lsk": lsk/darknet_lsk.py
 
     def __init__(self, num_classes: int, phi: str, dtype: str = "f16"):
         super().__init__()
         self.num_classes, self.phi, self.hip_dtype = num_classes, phi, dtype
         self._det = None
-        self._init_table(state_dict_shapes(self.kind, phi, num_classes))
+        self._init_table(state_dict_shapes(self.kind, phi, num_classes, self.attention_backbone))
 
     def _on_weights_changed(self):
         self._det = None
@@ -135,3 +136,9 @@ class CrossYoloBody(HipYoloBody):
     `models.decouple` is missing from the reference checkout; head text-identical to
     drone/models/lsk/yolox6.py) on the plain CSPDarknet backbone."""
     kind = "cross"
+
+
+class LskCrossYoloBody(CrossYoloBody):
+    """drone/models/lsk/yolox6.py = lsk/yolox6_lsk.py: the cross-scale head on lsk/darknet_lsk.py's backbone (an
+    LSK.Attention block -- 1x1, GELU, LSKblock, 1x1 + shortcut -- after every stage)."""
+    attention_backbone = "lsk"

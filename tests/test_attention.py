@@ -7,6 +7,8 @@ CPU part: the oracle restatement against those goldens.  GPU part: the HIP lower
 (NetBuilder.attention / patch_conv_nonlocal_new / spatial_attention / darknet with lsk*)
 against the same goldens, through the C ABI.  Tolerances as in test_hip_model.py:
 f32 5e-5 * max(1,|ref|) per block, f16 2e-2 * max(1,|ref|)."""
+import os
+
 import pytest
 import torch
 
@@ -144,16 +146,48 @@ def test_arch_table_equals_the_reference_attention_backbone(att_golden):
     assert ours == [(k, list(v)) for k, v in ref.items()]
 
 
+def test_arch_table_equals_the_reference_lsk_backbone(att_golden):
+    """... and with attention_backbone="lsk" lsk/darknet_lsk.py's (LSK.Attention: depthwise 5x5 / dilated 7x7 with bias)."""
+    from glsdet_amd.arch import state_dict_shapes
+    from tests.helpers import meta_of
+    ref = meta_of(att_golden, "block/att_lsk_darknet_tiny/meta")["shapes"]
+    ours = [(k[len("backbone."):], list(v)) for k, v in state_dict_shapes("cross", "tiny", 10, "lsk").items()
+            if k.startswith("backbone.backbone.")]
+    assert ours == [(k, list(v)) for k, v in ref.items()]
+
+
+def test_drone_surface_has_the_lsk_detector_twins():
+    import importlib
+    import sys
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "glsdet_amd", "drone")
+    sys.path.insert(0, root)
+    try:
+        for name in ("models.lsk.yolox6", "models.lsk.yolox6_lsk"):
+            for k in [m for m in sys.modules if m == "models" or m.startswith("models.")]:
+                del sys.modules[k]
+            net = importlib.import_module(name).YoloBody(10, "tiny")
+            keys = list(net.state_dict())
+            assert "backbone.backbone.lsk2.spatial_gating_unit.conv_spatial.weight" in keys
+            assert net.state_dict()["backbone.backbone.lsk3.spatial_gating_unit.conv0.weight"].shape[1:] == (1, 5, 5)
+            assert any(k.startswith("head.csp_feat0.") for k in keys)          # the cross-scale head
+    finally:
+        sys.path.remove(root)
+        for k in [m for m in sys.modules if m == "models" or m.startswith("models.")]:
+            del sys.modules[k]
+
+
 @pytest.mark.gpu
-def test_detector_with_attention_backbone_vs_oracle():
-    """A whole detector whose backbone is the attention CSPDarknet (the lsk* keys switch it on)."""
+@pytest.mark.parametrize("kind,att", [("base", True), ("cross", "lsk")])
+def test_detector_with_attention_backbone_vs_oracle(kind, att):
+    """A whole detector whose backbone is the attention CSPDarknet (the lsk* keys switch it on): the quadrant non-local
+    gating unit on the plain head, the LSK block under the cross-scale head (= drone/models/lsk/yolox6.py)."""
     from glsdet_amd.arch import state_dict_shapes
     from glsdet_amd.detector import HipDetector
-    sd = O.synth_state_dict(state_dict_shapes("base", "tiny", 10, True), 2)
+    sd = O.synth_state_dict(state_dict_shapes(kind, "tiny", 10, att), 2)
     x = O.synth_input((1, 3, 96, 128), 5)
-    want = O.FORWARDS["base"](sd, x)
-    got = [g.cpu() for g in HipDetector("base", sd, dtype="f32").forward_raw(x.cuda())]
-    truth = [o.float() for o in O.FORWARDS["base"](
+    want = O.FORWARDS[kind](sd, x)
+    got = [g.cpu() for g in HipDetector(kind, sd, dtype="f32").forward_raw(x.cuda())]
+    truth = [o.float() for o in O.FORWARDS[kind](
         {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}, x.double())]
     noise = max(_err(w, t) for w, t in zip(want, truth))
     for g, w in zip(got, want):
