@@ -425,9 +425,196 @@ static int launch_stem_down(const Stem2Args& b, hipStream_t st) {
   return 0;
 }
 
+// ------------------------------------------------------------------------------------------------
+// ResNet stem: y = relu(bn(conv7x7 stride 2 pad 3 (img)))  straight from the fp32 NCHW image
+// (ufp/mmdet/models/backbones/resnet.py:634-636).  As two launches (NCHW -> NHWC8 pack, then the generic kernel with 3
+// channels padded to 8: K = 392, 1.7 TB/s) it cost 60 + 246 us of the MPDet step and moved 137 MB of packed image twice.
+// Here K is laid out [7 rows][8 taps][4 channels] (tap 7 and channel 3 are zero weights): a 16-element K step is HALF A
+// FILTER ROW -- four taps x four channels -- which in a patch stored [row][column][4 channels] is 32 CONTIGUOUS bytes
+// starting at an even column, so every B fragment is one aligned ds_read_b128 and the im2col costs nothing.  The patch row
+// pitch is 48 pixels so that the two pixel rows of a 32-lane MFMA block hit the same bank sets (conflict free).  Weights
+// (64 x 224) resident in LDS, a strip of tiles per workgroup with the next tile's image loads in flight (focus_stem recipe).
+struct RStemArgs {
+  const float* img;            // [n][3][H][W] fp32
+  const unsigned char* w;      // [64][7][8][4] elements of y's dtype
+  const float* scale;
+  const float* bias;
+  unsigned char* y;
+  long y_sn, y_sh, y_sw;
+  int n, H, W, Ho, Wo, cout, act;
+  int tiles_x, tiles_y, strips_x;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void resnet_stem_kernel(const RStemArgs a) {
+  constexpr int ES = (int)sizeof(T);
+  constexpr int TH = 8, TW = 16, PH = 2 * TH + 5, PW = 2 * TW + 5, PWP = 48, STRIP = 6, CO_T = 64;
+  constexpr int PXB = 4 * ES;                         // bytes of a patch pixel: 4 channels
+  constexpr int KROW = 224 * ES, WRS = KROW + 16;     // weight row: 7 x 8 x 4 elements
+  constexpr int RB = 16 * ES;                         // bytes of one K step (4 taps x 4 channels)
+  constexpr int ORS = CO_T * ES + 16;
+  constexpr int W_BYTES = CO_T * WRS, P_BYTES = PH * PWP * PXB, E_BYTES = 128 * ORS;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* sW = smem;
+  unsigned char* sP = smem + W_BYTES;                 // patch, later the staged output tile
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
+  int t = blockIdx.x;
+  const int sx = t % a.strips_x;
+  t /= a.strips_x;
+  const int ty = t % a.tiles_y, img = t / a.tiles_y;
+  const int ty0 = ty * TH;
+
+  for (int q = tid; q < CO_T * (KROW / 16); q += 256) {
+    const int row = q / (KROW / 16), c = q - row * (KROW / 16);
+    *reinterpret_cast<u32x4*>(sW + row * WRS + c * 16) = *reinterpret_cast<const u32x4*>(a.w + (long)row * KROW + c * 16);
+  }
+  f32x4 scv[2][4], biv[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int co = i * 32 + 8 * g + 4 * lh;
+      scv[i][g] = *reinterpret_cast<const f32x4*>(a.scale + co);
+      biv[i][g] = *reinterpret_cast<const f32x4*>(a.bias + co);
+    }
+  const long plane = (long)a.H * a.W;
+  const float* ibase = a.img + (long)img * 3 * plane;
+  constexpr int NQ = 3 * PH * PW, NL = (NQ + 255) / 256;
+  float pre[NL];
+  auto issue_loads = [&](int tx0) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      const int q = tid + i * 256;
+      const int px = q % PW, r = q / PW;
+      const int py = r % PH, c = r / PH;
+      const int Y = 2 * ty0 - 3 + py, X = 2 * tx0 - 3 + px;
+      pre[i] = 0.f;
+      if (q < NQ && (unsigned)Y < (unsigned)a.H && (unsigned)X < (unsigned)a.W) pre[i] = ibase[c * plane + (long)Y * a.W + X];
+    }
+  };
+  issue_loads(sx * STRIP * TW);
+  for (int s = 0; s < STRIP; ++s) {
+    const int tx = sx * STRIP + s;
+    if (tx >= a.tiles_x) break;                       // uniform
+    const int tx0 = tx * TW;
+    __syncthreads();                                  // the previous tile's store phase is done with sP
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      const int q = tid + i * 256;
+      if (q < NQ) {
+        const int px = q % PW, r = q / PW;
+        const int py = r % PH, c = r / PH;
+        reinterpret_cast<T*>(sP + (py * PWP + px) * PXB)[c] = (T)pre[i];
+      }
+    }
+    for (int q = tid; q < PH * PWP; q += 256) {       // channel 3 of every pixel, and the pad columns (tap 7 reads column PW)
+      T* dst = reinterpret_cast<T*>(sP + q * PXB);
+      dst[3] = (T)0.f;
+      if (q % PWP >= PW) dst[0] = dst[1] = dst[2] = (T)0.f;
+    }
+    if (s + 1 < STRIP && tx + 1 < a.tiles_x) issue_loads(tx0 + TW);
+    __syncthreads();
+    f32x16 acc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][e] = 0.0f;
+    const int pix = wave * 32 + l31;
+    const int oy = pix >> 4, ox = pix & 15;
+    const unsigned char* bbase = sP + ((2 * oy) * PWP + 2 * ox + 2 * lh) * PXB;     // lane half: taps s0 + 2 lh, + 1
+    const unsigned char* abase = sW + l31 * WRS + lh * 16;
+#pragma unroll
+    for (int r = 0; r < 7; ++r) {
+#pragma unroll
+      for (int hs = 0; hs < 2; ++hs) {                // taps 0..3 / 4..7 of filter row r
+#pragma unroll
+        for (int kk = 0; kk < RB / 32; ++kk) {        // f16: one 32-byte step, f32: two
+          // f16: 16 B = taps (s0 + 2 lh, + 1) x 4 channels; f32: the K step's 64 bytes are taken 32 at a time, 16 per lane half
+          const unsigned char* bp = ES == 2 ? bbase + (r * PWP + 4 * hs) * PXB
+                                            : sP + ((2 * oy + r) * PWP + 2 * ox + 4 * hs) * PXB + kk * 32 + lh * 16;
+          const u32x4 bf = *reinterpret_cast<const u32x4*>(bp);
+          const int aoff = (r * 2 + hs) * RB + (ES == 2 ? 0 : kk * 32);
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            const u32x4 af = *reinterpret_cast<const u32x4*>(abase + i * 32 * WRS + aoff);
+            MMA<T>::run(af, bf, acc[i]);
+          }
+        }
+      }
+    }
+    __syncthreads();                                  // all waves are done reading the patch: it becomes the output stage
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int co_l = i * 32 + 8 * g + 4 * lh;
+        const f32x4 xv = {acc[i][4 * g], acc[i][4 * g + 1], acc[i][4 * g + 2], acc[i][4 * g + 3]};
+        const f32x4 yv = scale_bias_act4<T>(xv, scv[i][g], biv[i][g], a.act);
+        const float v[4] = {yv[0], yv[1], yv[2], yv[3]};
+        store4(sP + pix * ORS + co_l * ES, v, (T*)nullptr);
+      }
+    __syncthreads();
+    constexpr int VO = 16 / ES, OCPR = CO_T / VO;
+    for (int q = tid; q < 128 * OCPR; q += 256) {
+      const int px_l = q / OCPR, cq = q - px_l * OCPR;
+      const int ho = ty0 + (px_l >> 4), wo = tx0 + (px_l & 15), co = cq * VO;
+      if (ho < a.Ho && wo < a.Wo && co < a.cout) {
+        const long yo = (long)img * a.y_sn + (long)ho * a.y_sh + (long)wo * a.y_sw + co;
+        *reinterpret_cast<u32x4*>(a.y + yo * (long)ES) = *reinterpret_cast<const u32x4*>(sP + px_l * ORS + cq * 16);
+      }
+    }
+  }
+  (void)P_BYTES; (void)E_BYTES;
+}
+
+template <typename T>
+static int launch_rstem(const RStemArgs& a, hipStream_t st) {
+  constexpr int ES = (int)sizeof(T);
+  constexpr int patch = 21 * 48 * 4 * ES, epi = 128 * (64 * ES + 16);
+  constexpr int lds = 64 * (224 * ES + 16) + (patch > epi ? patch : epi);
+  static bool attr_set = false;
+  if (!attr_set && lds > 64 * 1024) {
+    GLS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(resnet_stem_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    attr_set = true;
+  }
+  const long grid = (long)a.n * a.tiles_y * a.strips_x;
+  hipLaunchKernelGGL((resnet_stem_kernel<T>), dim3((unsigned)grid), dim3(256), lds, st, a);
+  GLS_HIP(hipGetLastError());
+  return 0;
+}
+
 }  // namespace glsdet
 
 using namespace glsdet;
+
+extern "C" int64_t glsdet_resnet_stem_weight_elems(void) { return 64 * 224; }
+
+extern "C" int glsdet_resnet_stem(const float* img, int32_t n, int32_t cin, int32_t H, int32_t W, const void* w, const float* scale,
+                                  const float* bias, int32_t act, const glsdet_view* y, void* stream) {
+  if (!img || !w || !scale || !bias || !y) GLS_FAIL(GLSDET_E_ARG, "resnet_stem: null argument");
+  if (cin != 3 || n < 1 || H < 7 || W < 7) GLS_FAIL(GLSDET_E_ARG, "resnet_stem: needs a 3-channel image of at least 7 x 7");
+  if (((uintptr_t)img & 3) || ((uintptr_t)w | (uintptr_t)scale | (uintptr_t)bias) & 15) GLS_FAIL(GLSDET_E_ALIGN, "resnet_stem: operand alignment");
+  int rc;
+  if ((rc = check_view(*y, "resnet_stem.y"))) return rc;
+  const int Ho = (H + 6 - 7) / 2 + 1, Wo = (W + 6 - 7) / 2 + 1;
+  if (y->n != n || y->h != Ho || y->w != Wo || y->c != 64) GLS_FAIL(GLSDET_E_ARG, "resnet_stem: output must be [n, %d, %d, 64]", Ho, Wo);
+  if (act < 0 || act > 5) GLS_FAIL(GLSDET_E_ARG, "resnet_stem: bad act %d", act);
+  RStemArgs a;
+  a.img = img; a.w = (const unsigned char*)w; a.scale = scale; a.bias = bias;
+  a.y = (unsigned char*)y->base; a.y_sn = y->sn; a.y_sh = y->sh; a.y_sw = y->sw;
+  a.n = n; a.H = H; a.W = W; a.Ho = Ho; a.Wo = Wo; a.cout = 64; a.act = act;
+  a.tiles_x = (Wo + 15) / 16; a.tiles_y = (Ho + 7) / 8; a.strips_x = (a.tiles_x + 5) / 6;
+  const int dt = y->dtype;
+  OpRecord op;
+  op.kind = 0;
+  op.flops = 2.0 * (double)n * Ho * Wo * 64 * 147.0;
+  op.bytes = (double)n * 3 * H * W * 4.0 + (double)n * Ho * Wo * 64 * dtype_size(dt);
+  char nm[96];
+  snprintf(nm, sizeof nm, "resnet_stem<%s,64x8x16> 7x7 s2 cin3 cout64 (fp32 NCHW image in)", dt ? "f32" : "f16");
+  op.name = nm;
+  op.launch = [a, dt](hipStream_t st) -> int { return dt == GLSDET_F16 ? launch_rstem<f16>(a, st) : launch_rstem<float>(a, st); };
+  return submit(std::move(op), stream);
+}
 
 extern "C" int glsdet_focus_conv_down(const float* img, int32_t n, int32_t cin, int32_t H, int32_t W, const void* w1, const float* scale1,
                                       const float* bias1, int32_t act1, int32_t c1, const void* w2, const float* scale2,

@@ -688,6 +688,24 @@ class Engine:
         return nb["packed"]
 
     # ------------------------------------------------------------------ ResNet / FPN / GFL / MPHead ops
+    def pack_resnet_stem(self, w: torch.Tensor, scale: torch.Tensor, bias: torch.Tensor):
+        """conv1.weight [64,3,7,7] -> [64][7][8][4] (tap 7 and channel 3 zero) in the engine dtype, + folded BN"""
+        assert tuple(w.shape) == (64, 3, 7, 7)
+        wp = torch.zeros(64, 7, 8, 4, dtype=torch.float32)
+        wp[:, :, :7, :3] = w.float().permute(0, 2, 3, 1)
+        assert wp.numel() == self.lib.glsdet_resnet_stem_weight_elems()
+        return (self.upload(wp.to(_TORCH_DT[self.dt])), self.upload(scale.float()), self.upload(bias.float()))
+
+    def resnet_stem(self, img: torch.Tensor, packed, act: str = "relu", out: Optional[TView] = None) -> TView:
+        """7x7 stride-2 stem conv + BN + act straight from the fp32 NCHW image (glsdet_resnet_stem)"""
+        assert img.dtype == torch.float32 and img.is_contiguous() and img.device.type == "cuda"
+        n, cin, H, W = img.shape
+        if out is None:
+            out = self.tensor(n, (H + 1) // 2, (W + 1) // 2, 64)
+        check(self.lib.glsdet_resnet_stem(img.data_ptr(), n, cin, H, W, packed[0].data_ptr(), packed[1].data_ptr(), packed[2].data_ptr(),
+                                          ACT[act], C.byref(out.as_c()), _stream_ptr(self.stream)), "resnet_stem")
+        return out
+
     def nchw_pack(self, img: torch.Tensor, out: Optional[TView] = None) -> TView:
         assert img.dtype == torch.float32 and img.is_contiguous() and img.device.type == "cuda"
         n, cin, H, W = img.shape

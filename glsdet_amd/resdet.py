@@ -20,6 +20,8 @@ from __future__ import annotations
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
+import os
+
 import torch
 
 from . import _lib
@@ -75,8 +77,16 @@ class ResDetBuilder:
     def resnet(self, p: str, img: torch.Tensor, depth: int = 50, out_indices: Sequence[int] = (0, 1, 2, 3)) -> List[TView]:
         """resnet.py:631-646."""
         e = self.e
-        x = e.nchw_pack(img)
-        x = e.conv(x, self._pack(p + ".conv1", [self._bn_part(p + ".conv1", p + ".bn1")], x.c), 2, 3, "relu")
+        w1 = self.sd[p + ".conv1.weight"]
+        if tuple(w1.shape) == (64, 3, 7, 7) and img.shape[1] == 3 and not os.environ.get("GLSDET_NO_RSTEM_FUSION"):
+            # stem conv straight from the fp32 NCHW image (glsdet_resnet_stem): no packed image, K = 7 x 8 x 4 instead of 7 x 7 x 8
+            key = (p + ".conv1", "rstem")
+            if key not in self._packed:
+                self._packed[key] = e.pack_resnet_stem(*self._bn_part(p + ".conv1", p + ".bn1"))
+            x = e.resnet_stem(img, self._packed[key], "relu")
+        else:
+            x = e.nchw_pack(img)
+            x = e.conv(x, self._pack(p + ".conv1", [self._bn_part(p + ".conv1", p + ".bn1")], x.c), 2, 3, "relu")
         x = e.pool2d(x, 3, 2, 1)
         outs = []
         for i, nblocks in enumerate(STAGE_BLOCKS[depth]):

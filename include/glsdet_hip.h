@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GLSDET_ABI_VERSION 9
+#define GLSDET_ABI_VERSION 10
 
 enum { GLSDET_F16 = 0, GLSDET_F32 = 1 };
 enum { GLSDET_ACT_NONE = 0, GLSDET_ACT_SILU = 1, GLSDET_ACT_RELU = 2, GLSDET_ACT_LRELU = 3,
@@ -282,6 +282,16 @@ int glsdet_pack_detections(const float* dets, const int32_t* count, int32_t n, i
  * multiple of 8): the input of the 7x7 s2 stem conv (ufp/mmdet/models/backbones/resnet.py:634). */
 int glsdet_nchw_pack(const float* img, int32_t n, int32_t cin, int32_t H, int32_t W,
                      const glsdet_view* y, void* stream);
+
+/* ResNet stem in one launch: y = act(scale * conv7x7 stride 2 pad 3 (img) + bias) straight from the fp32 NCHW image
+ * (ufp/mmdet/models/backbones/resnet.py:634-636 `x = self.relu(self.norm1(self.conv1(x)))`), replacing glsdet_nchw_pack +
+ * glsdet_conv2d over 3 channels padded to 8.  w: [64][7][8][4] elements of y's dtype = conv1.weight[co][c][r][s] at
+ * [co][r][s][c], zero for s = 7 and c = 3 (glsdet_resnet_stem_weight_elems elements); scale / bias: folded BN, fp32 [64];
+ * y: NHWC view [n, (H + 1) / 2, (W + 1) / 2, 64].  Same k order as the generic kernel minus its zero-padded channels:
+ * results agree to fp32 summation-order noise.                                                                          */
+int64_t glsdet_resnet_stem_weight_elems(void);
+int glsdet_resnet_stem(const float* img, int32_t n, int32_t cin, int32_t H, int32_t W, const void* w, const float* scale,
+                       const float* bias, int32_t act, const glsdet_view* y, void* stream);
 
 /* nn.MaxPool2d(k, stride, pad) (resnet.py:598: k3 s2 p1), floor mode, -inf padding.
  * y extent must be floor((x + 2*pad - k)/stride) + 1.                                      */

@@ -209,6 +209,28 @@ def test_groupnorm(engines, mode, c, g, hw):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("mode", ["f32", "f16"])
+@pytest.mark.parametrize("hw", [(64, 96), (70, 131), (37, 29), (7, 9), (160, 416)])
+def test_resnet_stem_from_the_fp32_image_equals_pack_plus_conv(engines, mode, hw):
+    """glsdet_resnet_stem (7x7 stride 2 + BN + ReLU straight from the fp32 NCHW image, K laid out [7][8][4]) against
+    glsdet_nchw_pack + glsdet_conv2d over the 8-channel padded image and against torch: the two HIP forms differ only by
+    fp32 summation order (the zero taps / channels sit at different k positions); odd extents, ragged strips, one tile."""
+    eng = engines[mode]
+    gen = torch.Generator().manual_seed(hw[0] * 7 + hw[1])
+    x = torch.randn(2, 3, hw[0], hw[1], generator=gen)
+    w = torch.randn(64, 3, 7, 7, generator=gen) / np.sqrt(147)
+    sc, bi = torch.rand(64, generator=gen) + 0.5, torch.randn(64, generator=gen) * 0.2
+    fused = eng.resnet_stem(x.cuda(), eng.pack_resnet_stem(w, sc, bi), "relu")
+    two = eng.conv(eng.nchw_pack(x.cuda()), eng.pack_conv([(w, sc, bi)], 8), 2, 3, "relu")
+    torch.cuda.synchronize()
+    want = torch.relu(F.conv2d(_r(x, mode), _r(w, mode), None, 2, 3) * sc[None, :, None, None] + bi[None, :, None, None])
+    a, b = fused.to_nchw(64).cpu(), two.to_nchw(64).cpu()
+    assert a.shape == want.shape
+    assert _err(a, want) <= (2e-5 if mode == "f32" else 4e-3)
+    assert _err(a, b) <= (2e-6 if mode == "f32" else 1.1e-3)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["f32", "f16"])
 @pytest.mark.parametrize("cin,cout,g,hw", [(256, 256, 32, (20, 24)), (256, 512, 64, (17, 33)), (64, 64, 8, (8, 16)), (128, 256, 32, (41, 70))])
 def test_conv_with_groupnorm_partials_equals_conv_then_two_pass_groupnorm(engines, monkeypatch, mode, cin, cout, g, hw):
     """glsdet_conv2d_gnstats + glsdet_groupnorm_multi_pre (the conv's store phase sums what it stores, the GroupNorm
