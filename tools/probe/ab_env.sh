@@ -4,9 +4,9 @@ V=$1; W=${2:-yolox_s_glfusion_1344x800_bs8}
 mkdir -p gpurun_out/abenv
 for rep in 1 2; do
   export GLSDET_TUNE_CACHE=/tmp/tc_off.json
-  env $V=1 timeout -k 10 400 python bench.py --no-secondary --no-cpu-baseline --workload $W --steps 50 --warmup 10 --op-table gpurun_out/abenv/ops_off.tsv > gpurun_out/abenv/off$rep.log 2>&1
+  env $V=1 timeout -k 10 400 python bench.py --no-secondary --no-cpu-baseline --workload $W --steps ${STEPS:-50} --warmup 10 --op-table gpurun_out/abenv/ops_off.tsv > gpurun_out/abenv/off$rep.log 2>&1
   export GLSDET_TUNE_CACHE=/tmp/tc_on.json
-  timeout -k 10 400 python bench.py --no-secondary --no-cpu-baseline --workload $W --steps 50 --warmup 10 --op-table gpurun_out/abenv/ops_on.tsv > gpurun_out/abenv/on$rep.log 2>&1
+  timeout -k 10 400 python bench.py --no-secondary --no-cpu-baseline --workload $W --steps ${STEPS:-50} --warmup 10 --op-table gpurun_out/abenv/ops_on.tsv > gpurun_out/abenv/on$rep.log 2>&1
 done
 for f in off1 on1 off2 on2; do tail -1 gpurun_out/abenv/$f.log | python -c "
 import json,sys; d=json.loads(sys.stdin.read()); r=d['roofline']; print('$f', d['value'], d['ms_per_step'], r['conv_ms_per_step'], r['all_ops_ms_per_step_eager'], r['launches_per_step'], r['frac'], r['frac_end_to_end'])"; done
