@@ -47,6 +47,8 @@ PEAK_HBM_GBS = 8000.0
 # (slightly larger, channel-padded) work the kernels execute.
 ALGORITHMIC_GMAC = {
     "yolox_s_glfusion_1344x800_bs8": (61.527, 0.565),
+    "yolox_s_glfusion_1344x800_bs4": (61.527, 0.565),
+    "yolox_s_glfusion_1344x800_bs16": (61.527, 0.565),
     "yolox_s_glfusion_640x640_bs8": (23.439, 0.082),
     "yolox_s_base_640x640_bs8": (13.268, 0.0),
 }
@@ -55,6 +57,9 @@ WORKLOADS = {
     # name: (detector kind, golden tag carrying the calibrated BN stats, H, W, per-GPU batch)
     "yolox_s_glfusion_1344x800_bs8": ("gl", "gl_s_seed0", 800, 1344, 8),
     "yolox_s_glfusion_640x640_bs8": ("gl", "gl_s_seed0", 640, 640, 8),
+    # probes of the batch-size / batches-in-flight trade-off (tools/probe/subbatch.sh), not the metric's configuration
+    "yolox_s_glfusion_1344x800_bs4": ("gl", "gl_s_seed0", 800, 1344, 4),
+    "yolox_s_glfusion_1344x800_bs16": ("gl", "gl_s_seed0", 800, 1344, 16),
     "yolox_s_base_640x640_bs8": ("base", "base_s_seed0", 640, 640, 8),
     # UFPMP-Det detectors (configs/UFPMP-Det/*.py): ResNet-50 (+ GL-fusion plug-in) + FPN + GFLHead / MPHead
     "mp_det_res50_gl_1344x800_bs8": ("mpdet_gl", None, 800, 1344, 8),
