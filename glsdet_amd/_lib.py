@@ -10,7 +10,7 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "lib", "libglsdet_hip.so")
-ABI_VERSION = 10
+ABI_VERSION = 11
 CAPTURE_LOCK = threading.RLock()        # hipGraph captures are serialised across host threads
 
 F16, F32 = 0, 1
@@ -74,6 +74,8 @@ _SIGS = {
                                          C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(View),
                                          C.c_void_p]),
     "glsdet_resnet_stem_weight_elems": (C.c_int64, []),
+    "glsdet_resnet_stem_pool": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                          C.POINTER(View), C.c_void_p]),
     "glsdet_resnet_stem": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_int32, C.POINTER(View), C.c_void_p]),
     "glsdet_channel_maxmean": (C.c_int, [C.POINTER(View), C.POINTER(View), C.c_void_p]),

@@ -567,6 +567,169 @@ __global__ __launch_bounds__(256) void resnet_stem_kernel(const RStemArgs a) {
   (void)P_BYTES; (void)E_BYTES;
 }
 
+template <typename T> struct StemVec;
+template <> struct StemVec<f16> { typedef f16x8 type; };
+template <> struct StemVec<float> { typedef f32x4 type; };
+
+// The same stem with the 3x3 stride-2 max pool that follows it (resnet.py:637 `x = self.maxpool(x)`) in the epilogue: the
+// 275 MB conv output is neither written nor read by a pooling pass (378 + 344 MB -> 172 MB).  A workgroup owns a 4 x 8
+// tile of POOLED pixels = a 9 x 17 tile of conv pixels (1.2x recompute at the tile seams), computed as above into LDS
+// (zero outside the conv map: the activation is ReLU, so a zero never wins a max that holds a real value), then every
+// thread reduces one (pooled pixel, 8-channel chunk) over its 3 x 3 window.
+template <typename T>
+__global__ __launch_bounds__(256) void resnet_stem_pool_kernel(const RStemArgs a) {
+  constexpr int ES = (int)sizeof(T);
+  constexpr int QH = 4, QW = 8, CH = 2 * QH + 1, CW = 2 * QW + 1, NC = CH * CW;      // pooled tile, conv tile (153 pixels)
+  constexpr int PH = 2 * (CH - 1) + 7, PW = 2 * (CW - 1) + 7, PWP = 48, STRIP = 6, CO_T = 64;
+  constexpr int PXB = 4 * ES, KROW = 224 * ES, WRS = KROW + 16, RB = 16 * ES, ORS = CO_T * ES + 16;
+  constexpr int W_BYTES = CO_T * WRS;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* sW = smem;
+  unsigned char* sP = smem + W_BYTES;                 // patch, later the conv tile [160 slots][ORS]
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, lh = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int t = blockIdx.x;
+  const int sx = t % a.strips_x;
+  t /= a.strips_x;
+  const int ty = t % a.tiles_y, img = t / a.tiles_y;
+  const int qy0 = ty * QH;                            // pooled row origin; conv row origin = 2 qy0 - 1
+  const int Hc = (a.H + 6 - 7) / 2 + 1, Wc = (a.W + 6 - 7) / 2 + 1;
+
+  for (int q = tid; q < CO_T * (KROW / 16); q += 256) {
+    const int row = q / (KROW / 16), c = q - row * (KROW / 16);
+    *reinterpret_cast<u32x4*>(sW + row * WRS + c * 16) = *reinterpret_cast<const u32x4*>(a.w + (long)row * KROW + c * 16);
+  }
+  const long plane = (long)a.H * a.W;
+  const float* ibase = a.img + (long)img * 3 * plane;
+  constexpr int NQ = 3 * PH * PW, NL = (NQ + 255) / 256;
+  float pre[NL];
+  auto issue_loads = [&](int qx0) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      const int q = tid + i * 256;
+      const int px = q % PW, r = q / PW;
+      const int py = r % PH, c = r / PH;
+      const int Y = 2 * (2 * qy0 - 1) - 3 + py, X = 2 * (2 * qx0 - 1) - 3 + px;
+      pre[i] = 0.f;
+      if (q < NQ && (unsigned)Y < (unsigned)a.H && (unsigned)X < (unsigned)a.W) pre[i] = ibase[c * plane + (long)Y * a.W + X];
+    }
+  };
+  issue_loads(sx * STRIP * QW);
+  // ten (cout block, pixel block) tiles of 32 x 32 over four waves: tile k = wave + 4 i -> cout block k & 1, pixel block k >> 1
+  constexpr int NT = 3;
+  for (int s = 0; s < STRIP; ++s) {
+    const int tx = sx * STRIP + s;
+    if (tx >= a.tiles_x) break;                       // uniform
+    const int qx0 = tx * QW;
+    __syncthreads();                                  // the previous tile's pooling is done with sP
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      const int q = tid + i * 256;
+      if (q < NQ) {
+        const int px = q % PW, r = q / PW;
+        const int py = r % PH, c = r / PH;
+        reinterpret_cast<T*>(sP + (py * PWP + px) * PXB)[c] = (T)pre[i];
+      }
+    }
+    for (int q = tid; q < PH * PWP; q += 256) {
+      T* dst = reinterpret_cast<T*>(sP + q * PXB);
+      dst[3] = (T)0.f;
+      if (q % PWP >= PW) dst[0] = dst[1] = dst[2] = (T)0.f;
+    }
+    if (s + 1 < STRIP && tx + 1 < a.tiles_x) issue_loads(qx0 + QW);
+    __syncthreads();
+    f32x16 acc[NT];
+    int boff[NT], aoff0[NT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][e] = 0.0f;
+      const int k = wave + 4 * i;
+      int p = (k >> 1) * 32 + l31;
+      p = p < NC ? p : NC - 1;                        // junk lanes of the last block read a valid pixel
+      const int cy = p / CW, cx = p - cy * CW;
+      boff[i] = ((2 * cy) * PWP + 2 * cx) * PXB + (ES == 2 ? 2 * lh * PXB : lh * 16);
+      aoff0[i] = ((k & 1) * 32 + l31) * WRS + lh * 16;
+    }
+#pragma unroll
+    for (int r = 0; r < 7; ++r) {
+#pragma unroll
+      for (int hs = 0; hs < 2; ++hs) {
+#pragma unroll
+        for (int kk = 0; kk < RB / 32; ++kk) {
+          const int bo = (r * PWP + 4 * hs) * PXB + (ES == 2 ? 0 : kk * 32);
+          const int ao = (r * 2 + hs) * RB + (ES == 2 ? 0 : kk * 32);
+#pragma unroll
+          for (int i = 0; i < NT; ++i) {
+            if (wave + 4 * i < 10) {
+              const u32x4 bf = *reinterpret_cast<const u32x4*>(sP + boff[i] + bo);
+              const u32x4 af = *reinterpret_cast<const u32x4*>(sW + aoff0[i] + ao);
+              MMA<T>::run(af, bf, acc[i]);
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();                                  // all waves are done reading the patch: it becomes the conv tile
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+      const int k = wave + 4 * i;
+      const int p = (k >> 1) * 32 + l31;
+      if (k < 10 && p < NC) {
+        const int cy = p / CW, cx = p - cy * CW;
+        const int cr = 2 * qy0 - 1 + cy, cc = 2 * qx0 - 1 + cx;
+        const bool inside = (unsigned)cr < (unsigned)Hc && (unsigned)cc < (unsigned)Wc;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int co = (k & 1) * 32 + 8 * g + 4 * lh;
+          const f32x4 sc = *reinterpret_cast<const f32x4*>(a.scale + co), bi = *reinterpret_cast<const f32x4*>(a.bias + co);
+          const f32x4 xv = {acc[i][4 * g], acc[i][4 * g + 1], acc[i][4 * g + 2], acc[i][4 * g + 3]};
+          f32x4 yv = scale_bias_act4<T>(xv, sc, bi, GLSDET_ACT_RELU);
+          if (!inside) yv = f32x4{0.f, 0.f, 0.f, 0.f};
+          const float v[4] = {yv[0], yv[1], yv[2], yv[3]};
+          store4(sP + p * ORS + co * ES, v, (T*)nullptr);
+        }
+      }
+    }
+    __syncthreads();
+    {                                                 // one (pooled pixel, 16-byte channel chunk) per thread
+      constexpr int VO = 16 / ES, OCPR = CO_T / VO;
+      for (int q = tid; q < QH * QW * OCPR; q += 256) {
+        const int pq = q / OCPR, cq = q - pq * OCPR;
+        const int py = pq / QW, px = pq - py * QW;
+        const int ho = qy0 + py, wo = qx0 + px;
+        if (ho < a.Ho && wo < a.Wo) {
+          typedef typename StemVec<T>::type V;
+          V m = *reinterpret_cast<const V*>(sP + ((2 * py) * CW + 2 * px) * ORS + cq * 16);
+#pragma unroll
+          for (int d = 1; d < 9; ++d) {
+            const V v = *reinterpret_cast<const V*>(sP + ((2 * py + d / 3) * CW + 2 * px + d % 3) * ORS + cq * 16);
+            m = __builtin_elementwise_max(m, v);
+          }
+          const long yo = (long)img * a.y_sn + (long)ho * a.y_sh + (long)wo * a.y_sw + cq * VO;
+          *reinterpret_cast<V*>(a.y + yo * (long)ES) = m;
+        }
+      }
+    }
+  }
+}
+
+template <typename T>
+static int launch_rstem_pool(const RStemArgs& a, hipStream_t st) {
+  constexpr int ES = (int)sizeof(T);
+  constexpr int patch = 23 * 48 * 4 * ES, ctile = 160 * (64 * ES + 16);
+  constexpr int lds = 64 * (224 * ES + 16) + (patch > ctile ? patch : ctile);
+  static bool attr_set = false;
+  if (!attr_set && lds > 64 * 1024) {
+    GLS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(resnet_stem_pool_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    attr_set = true;
+  }
+  const long grid = (long)a.n * a.tiles_y * a.strips_x;
+  hipLaunchKernelGGL((resnet_stem_pool_kernel<T>), dim3((unsigned)grid), dim3(256), lds, st, a);
+  GLS_HIP(hipGetLastError());
+  return 0;
+}
+
 template <typename T>
 static int launch_rstem(const RStemArgs& a, hipStream_t st) {
   constexpr int ES = (int)sizeof(T);
@@ -588,6 +751,32 @@ static int launch_rstem(const RStemArgs& a, hipStream_t st) {
 using namespace glsdet;
 
 extern "C" int64_t glsdet_resnet_stem_weight_elems(void) { return 64 * 224; }
+
+extern "C" int glsdet_resnet_stem_pool(const float* img, int32_t n, int32_t cin, int32_t H, int32_t W, const void* w, const float* scale,
+                                       const float* bias, const glsdet_view* y, void* stream) {
+  if (!img || !w || !scale || !bias || !y) GLS_FAIL(GLSDET_E_ARG, "resnet_stem_pool: null argument");
+  if (cin != 3 || n < 1 || H < 7 || W < 7) GLS_FAIL(GLSDET_E_ARG, "resnet_stem_pool: needs a 3-channel image of at least 7 x 7");
+  if (((uintptr_t)img & 3) || ((uintptr_t)w | (uintptr_t)scale | (uintptr_t)bias) & 15) GLS_FAIL(GLSDET_E_ALIGN, "resnet_stem_pool: operand alignment");
+  int rc;
+  if ((rc = check_view(*y, "resnet_stem_pool.y"))) return rc;
+  const int Hc = (H + 6 - 7) / 2 + 1, Wc = (W + 6 - 7) / 2 + 1, Ho = (Hc + 2 - 3) / 2 + 1, Wo = (Wc + 2 - 3) / 2 + 1;
+  if (y->n != n || y->h != Ho || y->w != Wo || y->c != 64) GLS_FAIL(GLSDET_E_ARG, "resnet_stem_pool: output must be [n, %d, %d, 64]", Ho, Wo);
+  RStemArgs a;
+  a.img = img; a.w = (const unsigned char*)w; a.scale = scale; a.bias = bias;
+  a.y = (unsigned char*)y->base; a.y_sn = y->sn; a.y_sh = y->sh; a.y_sw = y->sw;
+  a.n = n; a.H = H; a.W = W; a.Ho = Ho; a.Wo = Wo; a.cout = 64; a.act = GLSDET_ACT_RELU;
+  a.tiles_x = (Wo + 7) / 8; a.tiles_y = (Ho + 3) / 4; a.strips_x = (a.tiles_x + 5) / 6;
+  const int dt = y->dtype;
+  OpRecord op;
+  op.kind = 0;
+  op.flops = 2.0 * (double)n * Hc * Wc * 64 * 147.0;
+  op.bytes = (double)n * 3 * H * W * 4.0 + (double)n * Ho * Wo * 64 * dtype_size(dt);
+  char nm[112];
+  snprintf(nm, sizeof nm, "resnet_stem_pool<%s> 7x7 s2 cin3 cout64 + relu + maxpool 3x3 s2 (fp32 NCHW image in)", dt ? "f32" : "f16");
+  op.name = nm;
+  op.launch = [a, dt](hipStream_t st) -> int { return dt == GLSDET_F16 ? launch_rstem_pool<f16>(a, st) : launch_rstem_pool<float>(a, st); };
+  return submit(std::move(op), stream);
+}
 
 extern "C" int glsdet_resnet_stem(const float* img, int32_t n, int32_t cin, int32_t H, int32_t W, const void* w, const float* scale,
                                   const float* bias, int32_t act, const glsdet_view* y, void* stream) {

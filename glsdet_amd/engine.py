@@ -706,6 +706,17 @@ class Engine:
                                           ACT[act], C.byref(out.as_c()), _stream_ptr(self.stream)), "resnet_stem")
         return out
 
+    def resnet_stem_pool(self, img: torch.Tensor, packed, out: Optional[TView] = None) -> TView:
+        """... + ReLU + MaxPool2d(3, 2, 1) in the same launch (glsdet_resnet_stem_pool)"""
+        assert img.dtype == torch.float32 and img.is_contiguous() and img.device.type == "cuda"
+        n, cin, H, W = img.shape
+        hc, wc = (H + 1) // 2, (W + 1) // 2
+        if out is None:
+            out = self.tensor(n, (hc + 1) // 2, (wc + 1) // 2, 64)
+        check(self.lib.glsdet_resnet_stem_pool(img.data_ptr(), n, cin, H, W, packed[0].data_ptr(), packed[1].data_ptr(),
+                                               packed[2].data_ptr(), C.byref(out.as_c()), _stream_ptr(self.stream)), "resnet_stem_pool")
+        return out
+
     def nchw_pack(self, img: torch.Tensor, out: Optional[TView] = None) -> TView:
         assert img.dtype == torch.float32 and img.is_contiguous() and img.device.type == "cuda"
         n, cin, H, W = img.shape

@@ -83,11 +83,14 @@ class ResDetBuilder:
             key = (p + ".conv1", "rstem")
             if key not in self._packed:
                 self._packed[key] = e.pack_resnet_stem(*self._bn_part(p + ".conv1", p + ".bn1"))
-            x = e.resnet_stem(img, self._packed[key], "relu")
+            if getattr(self, "trace", None) is None and not os.environ.get("GLSDET_NO_RSTEM_POOL"):
+                x = e.resnet_stem_pool(img, self._packed[key])            # ... and the max pool in its epilogue
+            else:
+                x = e.pool2d(e.resnet_stem(img, self._packed[key], "relu"), 3, 2, 1)
         else:
             x = e.nchw_pack(img)
             x = e.conv(x, self._pack(p + ".conv1", [self._bn_part(p + ".conv1", p + ".bn1")], x.c), 2, 3, "relu")
-        x = e.pool2d(x, 3, 2, 1)
+            x = e.pool2d(x, 3, 2, 1)
         outs = []
         for i, nblocks in enumerate(STAGE_BLOCKS[depth]):
             for j in range(nblocks):

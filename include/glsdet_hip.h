@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GLSDET_ABI_VERSION 10
+#define GLSDET_ABI_VERSION 11
 
 enum { GLSDET_F16 = 0, GLSDET_F32 = 1 };
 enum { GLSDET_ACT_NONE = 0, GLSDET_ACT_SILU = 1, GLSDET_ACT_RELU = 2, GLSDET_ACT_LRELU = 3,
@@ -290,6 +290,11 @@ int glsdet_nchw_pack(const float* img, int32_t n, int32_t cin, int32_t H, int32_
  * y: NHWC view [n, (H + 1) / 2, (W + 1) / 2, 64].  Same k order as the generic kernel minus its zero-padded channels:
  * results agree to fp32 summation-order noise.                                                                          */
 int64_t glsdet_resnet_stem_weight_elems(void);
+/* ... and with `x = self.maxpool(x)` (resnet.py:637: MaxPool2d(3, stride 2, padding 1)) in the epilogue: the stem's output
+ * is never written; act is ReLU (a zero stands in for the pool's -inf padding).  y: [n, ((H+1)/2 + 1) / 2, ((W+1)/2 + 1) / 2, 64].
+ * Equals glsdet_resnet_stem + glsdet_pool2d bit for bit.                                                                */
+int glsdet_resnet_stem_pool(const float* img, int32_t n, int32_t cin, int32_t H, int32_t W, const void* w, const float* scale,
+                            const float* bias, const glsdet_view* y, void* stream);
 int glsdet_resnet_stem(const float* img, int32_t n, int32_t cin, int32_t H, int32_t W, const void* w, const float* scale,
                        const float* bias, int32_t act, const glsdet_view* y, void* stream);
 

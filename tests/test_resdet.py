@@ -227,6 +227,12 @@ def test_resnet_stem_from_the_fp32_image_equals_pack_plus_conv(engines, mode, hw
     assert a.shape == want.shape
     assert _err(a, want) <= (2e-5 if mode == "f32" else 4e-3)
     assert _err(a, b) <= (2e-6 if mode == "f32" else 1.1e-3)
+    # ... and with the 3x3 stride-2 max pool in the epilogue: the same bits as stem + glsdet_pool2d
+    pooled = eng.resnet_stem_pool(x.cuda(), eng.pack_resnet_stem(w, sc, bi))
+    ref = eng.pool2d(fused, 3, 2, 1)
+    torch.cuda.synchronize()
+    assert torch.equal(pooled.to_nchw(64).cpu(), ref.to_nchw(64).cpu())
+    assert _err(pooled.to_nchw(64).cpu(), F.max_pool2d(want, 3, 2, 1)) <= (2e-5 if mode == "f32" else 4e-3)
 
 
 @pytest.mark.gpu
