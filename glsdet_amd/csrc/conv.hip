@@ -827,6 +827,31 @@ static int time_variants(std::vector<OpRecord>& ops, const std::vector<int>& ids
       if (u < us[i]) us[i] = u;
     }
   }
+  // play-off: candidates within 4 % of the fastest are measured again, longer (near-ties used to flip between runs and
+  // moved a whole workload by up to 1.5 %: the same build picked ring vs ring_k64 for the tower convs on two boxes)
+  float lo = 1e30f;
+  for (size_t i = 0; i < ops.size(); ++i)
+    if (!dead[i] && us[i] < lo) lo = us[i];
+  std::vector<size_t> close;
+  for (size_t i = 0; i < ops.size(); ++i)
+    if (!dead[i] && us[i] <= 1.04f * lo) close.push_back(i);
+  if (close.size() > 1) {
+    constexpr int REPS2 = 12;
+    for (size_t i : close) us[i] = 1e30f;
+    for (int t = 0; t < 4; ++t)
+      for (size_t i : close) {
+        if (dead[i]) continue;
+        int rc = 0;
+        (void)hipEventRecord(e0, st);
+        for (int r = 0; r < REPS2 && !rc; ++r) rc = ops[i].launch(st);
+        (void)hipEventRecord(e1, st);
+        if (hipEventSynchronize(e1) != hipSuccess || rc) { dead[i] = 1; continue; }
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        const float u = ms * 1000.f / REPS2;
+        if (u < us[i]) us[i] = u;
+      }
+  }
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
   *any = 0;

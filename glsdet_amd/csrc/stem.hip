@@ -586,6 +586,8 @@ __global__ __launch_bounds__(256) void resnet_stem_pool_kernel(const RStemArgs a
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* sW = smem;
   unsigned char* sP = smem + W_BYTES;                 // patch, later the conv tile [160 slots][ORS]
+  constexpr int B_BYTES = (PH * PWP * PXB > 160 * ORS ? PH * PWP * PXB : 160 * ORS);
+  unsigned char* sSB = sP + B_BYTES;                  // scale | bias (64 floats each), parked once per workgroup
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, lh = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   int t = blockIdx.x;
@@ -599,6 +601,7 @@ __global__ __launch_bounds__(256) void resnet_stem_pool_kernel(const RStemArgs a
     const int row = q / (KROW / 16), c = q - row * (KROW / 16);
     *reinterpret_cast<u32x4*>(sW + row * WRS + c * 16) = *reinterpret_cast<const u32x4*>(a.w + (long)row * KROW + c * 16);
   }
+  if (tid < 32) *reinterpret_cast<f32x4*>(sSB + tid * 16) = *reinterpret_cast<const f32x4*>((tid < 16 ? a.scale : a.bias - 64) + tid * 4);
   const long plane = (long)a.H * a.W;
   const float* ibase = a.img + (long)img * 3 * plane;
   constexpr int NQ = 3 * PH * PW, NL = (NQ + 255) / 256;
@@ -682,7 +685,7 @@ __global__ __launch_bounds__(256) void resnet_stem_pool_kernel(const RStemArgs a
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const int co = (k & 1) * 32 + 8 * g + 4 * lh;
-          const f32x4 sc = *reinterpret_cast<const f32x4*>(a.scale + co), bi = *reinterpret_cast<const f32x4*>(a.bias + co);
+          const f32x4 sc = *reinterpret_cast<const f32x4*>(sSB + co * 4), bi = *reinterpret_cast<const f32x4*>(sSB + 256 + co * 4);
           const f32x4 xv = {acc[i][4 * g], acc[i][4 * g + 1], acc[i][4 * g + 2], acc[i][4 * g + 3]};
           f32x4 yv = scale_bias_act4<T>(xv, sc, bi, GLSDET_ACT_RELU);
           if (!inside) yv = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -718,7 +721,7 @@ template <typename T>
 static int launch_rstem_pool(const RStemArgs& a, hipStream_t st) {
   constexpr int ES = (int)sizeof(T);
   constexpr int patch = 23 * 48 * 4 * ES, ctile = 160 * (64 * ES + 16);
-  constexpr int lds = 64 * (224 * ES + 16) + (patch > ctile ? patch : ctile);
+  constexpr int lds = 64 * (224 * ES + 16) + (patch > ctile ? patch : ctile) + 512;
   static bool attr_set = false;
   if (!attr_set && lds > 64 * 1024) {
     GLS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(resnet_stem_pool_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
