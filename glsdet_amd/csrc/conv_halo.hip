@@ -466,6 +466,232 @@ __global__ __launch_bounds__(256) void conv_halo_ring_kernel(const ConvArgs a, c
   halo_store_and_chain<T, TO, CO_T, PITCH, CH, GN>(smem, a, img, ty0, tx0, co0, tid);
 }
 
+// ------------------------------------------------------------------------------------------------
+// 8-WAVE form of the ring kernel (tile hints 12 / 13; the round-1 verdict's "128 x 256 tile, two waves per SIMD, half the
+// weight staging per MFMA"): one workgroup of 512 threads owns 128 cout rows x an 8 x 32 pixel tile; the waves are laid
+// out 2 (cout) x 4 (pairs of pixel rows), each with the 64 x 64 register tile of the 128-row 4-wave form, so a tap's
+// weight tile (one DMA ring slot) serves twice the pixels.  A 32-lane MFMA block is one full tile row of 32 pixels: no
+// row rotation needed.  No residual / chained / GroupNorm forms.  Measured in DESIGN.md section 3.
+template <typename T, int KS, int RING, int KB>
+__global__ __launch_bounds__(512) void conv_halo_ring8_kernel(const ConvArgs a, const int tiles_x, const int tiles_y) {
+  constexpr int TH = 8, TW = 32, CO_T = 128, NWV = 8;
+  constexpr int RS = KB + 16, CPRW = KB / 16, RPL = 256 / KB;
+  constexpr int VEC = 16 / (int)sizeof(T), KE = KB / (int)sizeof(T);
+  constexpr int PH = TH - 1 + KS, PW = TW - 1 + KS;
+  constexpr int NP = (PH * PW * CPRW + 511) / 512;
+  constexpr int TM = 2, TN = 2;
+  constexpr int A_BYTES = CO_T * KB;
+  constexpr int RPI = 64 / CPRW;                   // rows one DMA instruction fills
+  constexpr int NI = CO_T / RPI / NWV;             // DMA instructions per wave and tap
+  static_assert(CO_T % (RPI * NWV) == 0 && RING >= 3, "ring geometry");
+  constexpr int PATCH_OFF = RING * A_BYTES;
+  constexpr int ORS = CO_T * (int)sizeof(T) + 16;
+  constexpr int STAGE = RING * A_BYTES + PH * PW * RS, EPI = TH * TW * ORS;
+  constexpr int SB_OFF = ((STAGE > EPI ? STAGE : EPI) + 15) / 16 * 16;
+
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int tile;
+  {
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, local = bid >> 3;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+  }
+  int rest = gls_div(tile, a.nco_mul, a.nco_sh);
+  const int co0 = (tile - rest * a.n_co_tiles) * CO_T;
+  const int r1 = gls_div(rest, a.tx_mul, a.tx_sh);
+  const int tx0 = (rest - r1 * tiles_x) * TW;
+  const int img = gls_div(r1, a.ty_mul, a.ty_sh);
+  const int ty0 = (r1 - img * tiles_y) * TH;
+
+  unsigned char* sSB = smem + SB_OFF;
+  f32x4 sbv = {0.f, 0.f, 0.f, 0.f};
+  if (tid < CO_T / 2 && co0 + (tid % (CO_T / 4)) * 4 < a.cout_pad)
+    sbv = *reinterpret_cast<const f32x4*>((tid < CO_T / 4 ? a.scale : a.bias) + co0 + (tid % (CO_T / 4)) * 4);
+
+  const int kc = tid % CPRW;
+  const auto xrs = gls_make_rsrc(a.x_lo, a.x_bytes);
+  const auto wrs = gls_make_rsrc(a.w, a.w_bytes);
+  unsigned wd[NI];
+#pragma unroll
+  for (int q = 0; q < NI; ++q) {
+    const int row = RPI * (wave + NWV * q) + lane / CPRW;
+    const int ch = (lane % CPRW) ^ ((row / RPL) & (CPRW - 1));
+    wd[q] = (co0 + row) < a.cout_pad ? (unsigned)(((co0 + row) * a.kpad + ch * VEC) * (int)sizeof(T)) : GLS_OOB;
+  }
+  unsigned poff[NP];
+  constexpr int pad = KS / 2;
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    const int q = tid + i * 512;
+    const int pp = q / CPRW;
+    const int py = pp / PW, px = pp - py * PW;
+    const int hi = ty0 - pad + py, wi = tx0 - pad + px;
+    const bool ok = pp < PH * PW && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
+    poff[i] = ok ? a.x_off + (unsigned)(((long)img * a.x_sn + (long)hi * a.x_sh + (long)wi * a.x_sw + kc * VEC) * (long)sizeof(T)) : GLS_OOB;
+  }
+  u32x4 rp[NP];
+  const int nchunks = a.Cin / KE;
+  constexpr int ntaps = KS * KS;
+  const int nsteps = nchunks * ntaps;
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  int dg = 0, dtap = 0, dslot = 0;
+  unsigned dadd = 0;
+  const unsigned tap_bytes = (unsigned)(a.Cin * (int)sizeof(T));
+  const unsigned chunk_fix = (unsigned)(KE * (int)sizeof(T)) - (unsigned)ntaps * tap_bytes;
+  auto dma_next = [&]() __attribute__((always_inline)) {
+    unsigned char* dst = smem + dslot * A_BYTES + wave * 1024;
+#pragma unroll
+    for (int q = 0; q < NI; ++q)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lds_ptr)(dst + q * NWV * 1024), 16, (int)(wd[q] + dadd), 0, 0, 0);
+    dslot = dslot + 1 == RING ? 0 : dslot + 1;
+    dadd += tap_bytes;
+    if (++dtap == ntaps) {
+      dtap = 0;
+      dadd += chunk_fix;
+    }
+    if (++dg >= nsteps) dadd = GLS_OOB;
+  };
+  auto load_patch = [&](int cc) __attribute__((always_inline)) {
+    const unsigned coff = (unsigned)(cc * KE * (int)sizeof(T));
+#pragma unroll
+    for (int i = 0; i < NP; ++i) rp[i] = gls_buf_load16(xrs, poff[i] + coff);
+  };
+  auto store_patch = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const int q = tid + i * 512;
+      if (q < PH * PW * CPRW) *reinterpret_cast<u32x4*>(smem + PATCH_OFF + (q / CPRW) * RS + (q % CPRW) * 16) = rp[i];
+    }
+  };
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+  const int wco = wave % 2, wpx = wave / 2;         // 2 cout halves x 4 pairs of pixel rows
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int a_row = (wco * 64 + l31) * KB;
+  int a_sw[KB / 32];
+#pragma unroll
+  for (int kk = 0; kk < KB / 32; ++kk) a_sw[kk] = ((2 * kk + lh) ^ ((l31 / RPL) & (CPRW - 1))) << 4;
+  int b_off[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) b_off[j] = PATCH_OFF + ((wpx * 2 + j) * PW + l31) * RS + lh * 16;      // tile row wpx * 2 + j, column l31
+
+  load_patch(0);
+#pragma unroll
+  for (int g = 0; g < RING - 1; ++g) dma_next();
+  store_patch();
+  if (tid < CO_T / 2) *reinterpret_cast<f32x4*>(sSB + tid * 16) = sbv;
+
+  int g = 0;
+  auto mma_tap = [&](int tap_off) __attribute__((always_inline)) {
+    const unsigned char* sA = smem + g * A_BYTES + a_row;
+#pragma unroll
+    for (int kk = 0; kk < KB / 32; ++kk) {
+      u32x4 af[TM], bf[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const u32x4*>(sA + i * 32 * KB + a_sw[kk]);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const u32x4*>(smem + b_off[j] + tap_off + kk * 32);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) MMA<T>::run(af[i], bf[j], acc[i][j]);
+    }
+  };
+  for (int cc = 0; cc < nchunks; ++cc) {
+    int tap_off = 0, ts = 0;
+    for (int tap = 0; tap < ntaps - 1; ++tap) {
+      halo_wait_vm_barrier<NI * (RING - 2)>();
+      dma_next();
+      mma_tap(tap_off);
+      g = g + 1 == RING ? 0 : g + 1;
+      ++ts;
+      tap_off += (ts == KS) ? (PW - KS + 1) * RS : RS;
+      ts = (ts == KS) ? 0 : ts;
+    }
+    halo_wait_vm_barrier<NI * (RING - 2)>();
+    dma_next();
+    const bool more = cc + 1 < nchunks;
+    if (more) load_patch(cc + 1);
+    mma_tap(tap_off);
+    g = g + 1 == RING ? 0 : g + 1;
+    if (more) {
+      halo_lds_barrier();
+      store_patch();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+  }
+  halo_wait_vm_barrier<0>();
+
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) {
+      const int co_l = wco * 64 + i * 32 + 8 * gq + 4 * lh;
+      const f32x4 sc = *reinterpret_cast<const f32x4*>(sSB + co_l * 4), bi = *reinterpret_cast<const f32x4*>(sSB + CO_T * 4 + co_l * 4);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int px_l = (wpx * 2 + j) * 32 + l31;
+        const f32x4 xv = {acc[i][j][4 * gq], acc[i][j][4 * gq + 1], acc[i][j][4 * gq + 2], acc[i][j][4 * gq + 3]};
+        const f32x4 yv = scale_bias_act4<T>(xv, sc, bi, a.act);
+        const float v[4] = {yv[0], yv[1], yv[2], yv[3]};
+        store4(smem + px_l * ORS + co_l * (int)sizeof(T), v, (T*)nullptr);
+      }
+    }
+  }
+  __syncthreads();
+  constexpr int OCPR = CO_T / VEC;
+  for (int q = tid; q < TH * TW * OCPR; q += 512) {
+    const int px_l = q / OCPR, cq = q - px_l * OCPR;
+    const int ho = ty0 + (px_l >> 5), wo = tx0 + (px_l & 31), co = co0 + cq * VEC;
+    if (ho < a.Ho && wo < a.Wo && co < a.Cout) {
+      const long yo = (long)img * a.y_sn + (long)ho * a.y_sh + (long)wo * a.y_sw + co;
+      *reinterpret_cast<u32x4*>(a.y + yo * (long)sizeof(T)) = *reinterpret_cast<const u32x4*>(smem + px_l * ORS + cq * 16);
+    }
+  }
+}
+
+template <typename T, int KS, int RING, int KB>
+static int launch_halo_ring8(const ConvArgs& a, hipStream_t st) {
+  constexpr int PH = 7 + KS, PW = 31 + KS, ORS = 128 * (int)sizeof(T) + 16;
+  constexpr int stage = RING * 128 * KB + PH * PW * (KB + 16), epi = 256 * ORS;
+  constexpr int lds = ((stage > epi ? stage : epi) + 15) / 16 * 16 + 128 * 8;
+  static_assert(lds <= 160 * 1024, "LDS");
+  auto kern = conv_halo_ring8_kernel<T, KS, RING, KB>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    GLS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    attr_set = true;
+  }
+  ConvArgs b = a;
+  b.n_co_tiles = (a.Cout + 127) / 128;
+  const int tiles_x = (a.Wo + 31) / 32, tiles_y = (a.Ho + 7) / 8;
+  gls_fastdiv(b.n_co_tiles, &b.nco_mul, &b.nco_sh);
+  gls_fastdiv(tiles_x, &b.tx_mul, &b.tx_sh);
+  gls_fastdiv(tiles_y, &b.ty_mul, &b.ty_sh);
+  const long grid = (long)b.n_co_tiles * tiles_x * tiles_y * a.N;
+  if (grid <= 0 || grid > 0x7fffffffL) GLS_FAIL(GLSDET_E_ARG, "conv2d(halo ring8): grid %ld out of range", grid);
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), lds, st, b, tiles_x, tiles_y);
+  GLS_HIP(hipGetLastError());
+  return 0;
+}
+
+template <typename T>
+static int halo_ring8_dispatch(const ConvArgs& a, bool k64, hipStream_t st) {
+  switch (a.R) {
+    case 3: return k64 ? launch_halo_ring8<T, 3, 4, 64>(a, st) : launch_halo_ring8<T, 3, 3, 128>(a, st);
+    case 5: return k64 ? launch_halo_ring8<T, 5, 4, 64>(a, st) : launch_halo_ring8<T, 5, 3, 128>(a, st);
+    case 7: return k64 ? launch_halo_ring8<T, 7, 4, 64>(a, st) : launch_halo_ring8<T, 7, 3, 128>(a, st);
+  }
+  GLS_FAIL(GLSDET_E_ARG, "conv2d(halo ring8): unsupported kernel size %d", a.R);
+}
+
 // (the chained 1x1 exists for 3x3 stride 1 only: a CSP Bottleneck's conv2 -> the next Bottleneck's conv1)
 // and so do the GroupNorm partials (glsdet_conv2d_gnstats: the 3x3 tower convs of GFLHead / MPHead)
 template <typename T, typename TO, int CO_T, int KS, int RING, int KB = 128, int STR = 1, bool CH = false, bool GN = false>
@@ -566,6 +792,20 @@ static int halo_ring_k64_by_ks(const ConvArgs& a, hipStream_t st) {
 // Returns 1 when the halo kernel does not apply (caller falls back to the generic kernel),
 // 0 when `op` was filled in.
 int conv_halo_try(const ConvArgs& a, int xdt, int ydt, int hint, OpRecord* op) {
+  if (hint == 12 || hint == 13) {      // 8-wave 128 x 256 form of the ring kernel (13: 64-byte channel chunks)
+    const int es8 = dtype_size(xdt);
+    if (a.w2 || a.res || a.gn_part || xdt != ydt || a.stride != 1 || a.R != a.S || (a.R != 3 && a.R != 5 && a.R != 7) || a.pad != a.R / 2 ||
+        a.cout_pad <= 64 || (a.Cin * es8) % (hint == 13 ? 64 : 128))
+      return 1;
+    const bool k64 = hint == 13;
+    char nm8[96];
+    snprintf(nm8, sizeof nm8, "conv_halo_ring8%s<%s,128x8x32> %dx%d s1 cin%d cout%d", k64 ? "_k64" : "", xdt ? "f32" : "f16", a.R, a.S, a.Cin, a.Cout);
+    op->name = nm8;
+    op->launch = [a, xdt, k64](hipStream_t st) -> int {
+      return xdt == GLSDET_F16 ? halo_ring8_dispatch<f16>(a, k64, st) : halo_ring8_dispatch<float>(a, k64, st);
+    };
+    return 0;
+  }
   if (hint == 1 || hint == 3 || (hint > 5 && hint != 8 && hint != 9 && hint != 10 && hint != 11)) return 1;          // hint 1 / explicit tile = the generic kernel
   const int es = dtype_size(xdt);
   if (a.w2 && (a.R != 3 || a.stride != 1)) return 1;      // chained 1x1: compiled into the 3x3 stride-1 forms only

@@ -11,7 +11,7 @@ from tests.test_hip_ops import TOL, _cmp, _to_view
 
 pytestmark = pytest.mark.gpu
 
-HINTS = [0, 1, 2, 3, 4, 5, 8, 9, 10, 11, (128 << 16) | 128, (64 << 16) | 128, (64 << 16) | 64, (32 << 16) | 128,
+HINTS = [0, 1, 2, 3, 4, 5, 8, 9, 10, 11, 12, 13, (128 << 16) | 128, (64 << 16) | 128, (64 << 16) | 64, (32 << 16) | 128,
          (64 << 16) | 64 | 0x8000, (128 << 16) | 128 | 0x8000]
 
 
@@ -95,7 +95,7 @@ def _kxk_cases(n, seed):
 @pytest.mark.parametrize("mode", ["f16", "f32"])
 @pytest.mark.parametrize("case", _kxk_cases(16, 11), ids=lambda c: "n%d_ci%d_co%d_k%d_s%d_%dx%d_%s_r%d_e%d" % c)
 def test_conv2d_random_kxk_problem_halo_family(engines, mode, case):
-    _run_case(engines, mode, case, [0, 1, 2, 4, 5, 8, 9, 10, 11])
+    _run_case(engines, mode, case, [0, 1, 2, 4, 5, 8, 9, 10, 11, 12, 13])
 
 
 def _s2_cases(n, seed):
