@@ -130,5 +130,9 @@ def test_conv2d_filter_resident_stride2_kernel(engines, case):
     flight): strips that end inside / outside the map, odd extents, one tile, embedded input views, cout < 64."""
     _run_case(engines, "f16", case, [1, 14])
     from glsdet_amd._lib import GlsdetError
-    with pytest.raises(GlsdetError):                     # f32 / other channel counts are refused, nothing is launched
-        _run_case(engines, "f32", case, [14])
+    eng = engines["f32"]                                 # f32 (and other channel counts) are refused, nothing is launched
+    n_img, cin, cout, k, stride, h, w, act, res, embed = case
+    x = torch.randn(n_img, cin, h, w)
+    pk = eng.pack_conv([(torch.randn(cout, cin, k, k), torch.ones(cout), torch.zeros(cout))], cin)
+    with pytest.raises(GlsdetError):
+        eng.conv(_to_view(eng, x), pk, stride, 1, act, tile_hint=14)
