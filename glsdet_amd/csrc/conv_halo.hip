@@ -692,141 +692,6 @@ static int halo_ring8_dispatch(const ConvArgs& a, bool k64, hipStream_t st) {
   GLS_FAIL(GLSDET_E_ARG, "conv2d(halo ring8): unsupported kernel size %d", a.R);
 }
 
-// ------------------------------------------------------------------------------------------------
-// 3x3 STRIDE 2 over 32 fp16 channels (dark2.0: 32 -> 64 on the 400 x 672 stem map; tile hint 14).  On the flat-pixel kernel
-// this layer is INSTRUCTION bound (profiles/r02_pmc: 19 vector + 24 scalar instructions per MFMA, nine barrier-synchronised
-// K steps for 18 MFMAs per wave, 2.6 TB/s).  The focus_stem recipe instead: the WHOLE filter (64 rows x 9 taps x 64 bytes =
-// 37 KB) resident in LDS, one 512-thread workgroup per CU walking a strip of 8 x 16 output tiles, the 17 x 33 input patch
-// of the NEXT tile in flight in registers while the current one is multiplied (eight waves: four pixel blocks x two cout
-// blocks, 18 MFMAs each, no barrier between taps), columns de-interleaved as in the stride-2 ring kernel.
-template <int STRIP>
-__global__ __launch_bounds__(512) void conv_small_s2_kernel(const ConvArgs a, const int tiles_x, const int tiles_y, const int strips_x) {
-  typedef f16 T;
-  constexpr int ES = 2, VEC = 8, CIN = 32, CO_T = 64;
-  constexpr int PH = 17, PW = 33, HALF = 17, PITCH = 66, NSLOT = PH * PW;
-  constexpr int PRS = CIN * ES + 16;                 // 80-byte patch rows
-  constexpr int WRS = 9 * CIN * ES + 16;             // 592-byte weight rows: the whole filter of one cout
-  constexpr int ORS = CO_T * ES + 16;
-  constexpr int W_BYTES = CO_T * WRS;
-  constexpr int NCH = NSLOT * 4, NL = (NCH + 511) / 512;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char* sW = smem;
-  unsigned char* sP = smem + W_BYTES;                 // patch, later the staged output tile
-  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, lh = lane >> 5;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  int t = blockIdx.x;
-  const int sx = t % strips_x;
-  t /= strips_x;
-  const int ty = t % tiles_y, img = t / tiles_y;
-  const int ty0 = ty * 8;
-  const auto xrs = gls_make_rsrc(a.x_lo, a.x_bytes);
-  const auto wrs = gls_make_rsrc(a.w, a.w_bytes);
-
-  for (int q = tid; q < CO_T * 36; q += 512) {        // 36 chunks of 16 bytes per weight row
-    const int row = q / 36, c = q - row * 36;
-    *reinterpret_cast<u32x4*>(sW + row * WRS + c * 16) = gls_buf_load16(wrs, row < a.cout_pad ? (unsigned)((row * a.kpad) * ES + c * 16) : GLS_OOB);
-  }
-  const int pb = wave & 3, cb = wave >> 2;            // pixel block (two tile rows), cout block
-  f32x4 scv[4], biv[4];
-#pragma unroll
-  for (int g = 0; g < 4; ++g) {
-    const int co = cb * 32 + 8 * g + 4 * lh;
-    scv[g] = biv[g] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (co < a.cout_pad) {
-      scv[g] = *reinterpret_cast<const f32x4*>(a.scale + co);
-      biv[g] = *reinterpret_cast<const f32x4*>(a.bias + co);
-    }
-  }
-  // patch chunk -> (slot, channel chunk) is tile independent; only the pixel origin moves along the strip
-  int pyv[NL], pxv[NL];
-#pragma unroll
-  for (int i = 0; i < NL; ++i) {
-    const int q = tid + i * 512, pp = q >> 2;
-    const int py = pp / PW, ps = pp - py * PW;
-    pyv[i] = q < NCH ? py : -100000;                  // (a row far outside the image: reads as zeros)
-    pxv[i] = ps < HALF ? 2 * ps : 2 * (ps - HALF) + 1;
-  }
-  const int kc = tid & 3;
-  u32x4 pre[NL];
-  auto issue_loads = [&](int tx0) __attribute__((always_inline)) {
-#pragma unroll
-    for (int i = 0; i < NL; ++i) {
-      const int hi = 2 * ty0 - 1 + pyv[i], wi = 2 * tx0 - 1 + pxv[i];
-      const bool ok = (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
-      pre[i] = gls_buf_load16(xrs, ok ? a.x_off + (unsigned)(((long)img * a.x_sn + (long)hi * a.x_sh + (long)wi * a.x_sw + kc * VEC) * (long)ES) : GLS_OOB);
-    }
-  };
-  int oy, ox;
-  pix_to_xy16<PITCH>(pb * 32 + l31, oy, ox);
-  const unsigned char* bbase = sP + ((2 * oy) * PW + ox) * PRS + lh * 16;
-  const unsigned char* abase = sW + (cb * 32 + l31) * WRS + lh * 16;
-
-  issue_loads(sx * STRIP * 16);
-  for (int s = 0; s < STRIP; ++s) {
-    const int tx = sx * STRIP + s;
-    if (tx >= tiles_x) break;                         // uniform
-    const int tx0 = tx * 16;
-    __syncthreads();                                  // the previous tile's store phase is done with sP
-#pragma unroll
-    for (int i = 0; i < NL; ++i) {
-      const int q = tid + i * 512;
-      if (q < NCH) *reinterpret_cast<u32x4*>(sP + (q >> 2) * PRS + kc * 16) = pre[i];
-    }
-    if (s + 1 < STRIP && tx + 1 < tiles_x) issue_loads(tx0 + 16);
-    __syncthreads();
-    f32x16 acc;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
-#pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-      const int r = tap / 3, c = tap - 3 * r;
-      const int toff = (r * PW + (c == 1 ? HALF : (c >> 1))) * PRS;
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
-        const u32x4 bf = *reinterpret_cast<const u32x4*>(bbase + toff + kk * 32);
-        const u32x4 af = *reinterpret_cast<const u32x4*>(abase + tap * 64 + kk * 32);
-        MMA<T>::run(af, bf, acc);
-      }
-    }
-    __syncthreads();                                  // all waves are done reading the patch: it becomes the output stage
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int co_l = cb * 32 + 8 * g + 4 * lh;
-      const f32x4 xv = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
-      const f32x4 yv = scale_bias_act4<T>(xv, scv[g], biv[g], a.act);
-      const float v[4] = {yv[0], yv[1], yv[2], yv[3]};
-      store4(sP + (pb * 32 + l31) * ORS + co_l * ES, v, (T*)nullptr);
-    }
-    __syncthreads();
-    for (int q = tid; q < 128 * 8; q += 512) {
-      const int px_l = q >> 3, cq = q & 7;
-      int py2, px2;
-      pix_to_xy16<PITCH>(px_l, py2, px2);
-      const int ho = ty0 + py2, wo = tx0 + px2, co = cq * VEC;
-      if (ho < a.Ho && wo < a.Wo && co < a.Cout) {
-        const long yo = (long)img * a.y_sn + (long)ho * a.y_sh + (long)wo * a.y_sw + co;
-        *reinterpret_cast<u32x4*>(a.y + yo * (long)ES) = *reinterpret_cast<const u32x4*>(sP + px_l * ORS + cq * 16);
-      }
-    }
-  }
-}
-
-static int launch_small_s2(const ConvArgs& a, hipStream_t st) {
-  constexpr int STRIP = 6;
-  constexpr int lds = 64 * (9 * 64 + 16) + 17 * 33 * 80;
-  static bool attr_set = false;
-  if (!attr_set) {
-    GLS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_small_s2_kernel<STRIP>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    attr_set = true;
-  }
-  const int tiles_x = (a.Wo + 15) / 16, tiles_y = (a.Ho + 7) / 8, strips_x = (tiles_x + STRIP - 1) / STRIP;
-  const long grid = (long)a.N * tiles_y * strips_x;
-  if (grid <= 0 || grid > 0x7fffffffL) GLS_FAIL(GLSDET_E_ARG, "conv2d(small s2): grid %ld out of range", grid);
-  hipLaunchKernelGGL(conv_small_s2_kernel<STRIP>, dim3((unsigned)grid), dim3(512), lds, st, a, tiles_x, tiles_y, strips_x);
-  GLS_HIP(hipGetLastError());
-  return 0;
-}
-
 // (the chained 1x1 exists for 3x3 stride 1 only: a CSP Bottleneck's conv2 -> the next Bottleneck's conv1)
 // and so do the GroupNorm partials (glsdet_conv2d_gnstats: the 3x3 tower convs of GFLHead / MPHead)
 template <typename T, typename TO, int CO_T, int KS, int RING, int KB = 128, int STR = 1, bool CH = false, bool GN = false>
@@ -927,16 +792,6 @@ static int halo_ring_k64_by_ks(const ConvArgs& a, hipStream_t st) {
 // Returns 1 when the halo kernel does not apply (caller falls back to the generic kernel),
 // 0 when `op` was filled in.
 int conv_halo_try(const ConvArgs& a, int xdt, int ydt, int hint, OpRecord* op) {
-  if (hint == 14) {                    // whole-filter-resident 3x3 stride 2 over 32 fp16 channels (dark2.0)
-    if (a.w2 || a.res || a.gn_part || xdt != GLSDET_F16 || ydt != GLSDET_F16 || a.stride != 2 || a.R != 3 || a.S != 3 || a.pad != 1 ||
-        a.Cin != 32 || a.cout_pad > 64)
-      return 1;
-    char nm14[96];
-    snprintf(nm14, sizeof nm14, "conv_small_s2<f16,64x8x16> 3x3 s2 cin32 cout%d (filter resident)", a.Cout);
-    op->name = nm14;
-    op->launch = [a](hipStream_t st) -> int { return launch_small_s2(a, st); };
-    return 0;
-  }
   if (hint == 12 || hint == 13) {      // 8-wave 128 x 256 form of the ring kernel (13: 64-byte channel chunks)
     const int es8 = dtype_size(xdt);
     if (a.w2 || a.res || a.gn_part || xdt != ydt || a.stride != 1 || a.R != a.S || (a.R != 3 && a.R != 5 && a.R != 7) || a.pad != a.R / 2 ||

@@ -86,8 +86,7 @@ typedef struct glsdet_conv_desc {
   int32_t tile_hint;       /* 0 auto | 1 generic | 2 halo (s1 kxk) | 4 halo, wave-private weights | 5 halo, 64-row cout tiles |
                             * 8 / 9 halo with the weight tiles in an LDS-DMA ring (64- / 128-row cout tiles) | 10 / 11 the same with
                             *   64-byte channel chunks (64 / 128 rows) | 12 / 13 the 8-wave form: 128 cout rows x 8 x 32 pixels per
-                            *   512-thread workgroup (128- / 64-byte chunks; no residual) | 14 3x3 stride 2 over 32 fp16 channels with
-                            *   the whole filter resident in LDS | 3 weight-stationary 1x1 |
+                            *   512-thread workgroup (128- / 64-byte chunks; no residual) | 3 weight-stationary 1x1 |
                             * co_tile<<16|px_tile (|0x8000: 64-byte K steps) */
 } glsdet_conv_desc;
 
