@@ -397,6 +397,14 @@ def run_workload(args, workload, rank, world, dev, with_cpu_baseline):
             dist.barrier()
         torch.cuda.synchronize()
 
+    # settle (untimed, before the W warmup steps): the first GPU process on a fresh box ran the same build at 3000-3200
+    # instead of 4100-4300 img/s for its first ~0.2 s twice this round (clocks / power state still ramping); a run of the
+    # real step until --settle seconds have passed puts the measurement on the steady state the later steps see anyway
+    t_settle = time.perf_counter()
+    while time.perf_counter() - t_settle < args.settle:
+        for _ in range(8):
+            step()
+        fence()
     for _ in range(args.warmup):
         step()
     fence()
@@ -485,7 +493,8 @@ def run_workload(args, workload, rank, world, dev, with_cpu_baseline):
            "config": {"workload": workload, "detector": DETECTOR_NAME[kind],
                       "input": [bs, 3, H, W], "images_per_gpu": bs, "global_batch": bs * world, "num_classes": 10,
                       "post": post, "head_calibration": calib, "hip_graph": not args.no_graph,
-                      "batches_in_flight": nstreams, "input_from_host_each_step": bool(args.from_host),
+                      "batches_in_flight": nstreams, "settle_seconds_untimed": args.settle,
+                      "input_from_host_each_step": bool(args.from_host),
                       "detections_per_image_rank0": [int(len(d)) for d in dets],
                       "candidates_per_image_rank0": cand_counts,
                       "suppressed_frac": round(suppressed, 4),
@@ -555,6 +564,8 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend; gloo is for rehearsing the N>1 control flow on a box with fewer "
                          "GPUs than ranks (ranks then share devices round-robin) -- never for a reported number")
+    ap.add_argument("--settle", type=float, default=1.5,
+                    help="seconds of untimed steps before the warmup (clock / power ramp of a cold box); 0 = none")
     ap.add_argument("--no-autotune", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the BASELINE config-3 leg (`secondary`)")
