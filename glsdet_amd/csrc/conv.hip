@@ -36,19 +36,19 @@ constexpr int conv_lds_bytes(bool wide) {        // wide: fp32 staging of an fp1
 // CH: the chained 1x1 (glsdet_conv2d_chain) is compiled in.  A flag, not a runtime branch: with the chain code present
 // every instantiation carried its accumulators and staged chunks (64x64 tile: 60 -> 89 VGPRs, 6 -> 3 waves per SIMD;
 // the 128-row halo kernels 82-118 -> 238), which cost the plain launches 5-20 % (round 2 regression, found in the op table).
-template <typename T, typename TO, int CO_T, int PX_T, int KB, int WCO, bool UT, bool CH = false>
+template <typename T, typename TO, int CO_T, int PX_T, int KB, int WCO, bool UT, bool CH = false, int NTHR = 256>
 __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid, const int nwg) {
   constexpr int RS = KB + 16;                    // LDS row stride, bytes
   constexpr int VEC = 16 / (int)sizeof(T);       // elements per 16-B chunk
   constexpr int KE = KB / (int)sizeof(T);        // k elements per step
   constexpr int CPR = KB / 16;                   // chunks per tile row
-  constexpr int NA = (CO_T * CPR + 255) / 256;   // chunks per thread, weight tile
-  constexpr int NB = (PX_T * CPR + 255) / 256;   // chunks per thread, im2col tile
-  constexpr int WPX = 4 / WCO;
+  constexpr int NA = (CO_T * CPR + NTHR - 1) / NTHR;   // chunks per thread, weight tile
+  constexpr int NB = (PX_T * CPR + NTHR - 1) / NTHR;   // chunks per thread, im2col tile
+  constexpr int WPX = (NTHR / 64) / WCO;       // NTHR = 512: eight waves on a 128 x 256 tile (tile 128<<16|256), 64 x 64 each
   constexpr int WT_CO = CO_T / WCO, WT_PX = PX_T / WPX;
   constexpr int TM = WT_CO / 32, TN = WT_PX / 32;
   constexpr int STAGE = (CO_T + PX_T) * RS;
-  static_assert(TM >= 1 && TN >= 1 && 256 % CPR == 0, "tile shape");
+  static_assert(TM >= 1 && TN >= 1 && NTHR % CPR == 0 && (NTHR == 256 || !CH), "tile shape");
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
@@ -68,7 +68,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
 
   const int kc = tid % CPR;
   const int row0 = tid / CPR;                    // row of chunk i is row0 + i*(256/CPR)
-  constexpr int ROWS_PER_PASS = 256 / CPR;
+  constexpr int ROWS_PER_PASS = NTHR / CPR;
 
   const auto xrs = gls_make_rsrc(a.x_lo, a.x_bytes);
   const auto wrs = gls_make_rsrc(a.w, a.w_bytes);
@@ -300,13 +300,13 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
   if constexpr (CH && sizeof(T) == sizeof(TO)) if (chain && a.res) {
     // the FINAL tile (after the residual) must stand in LDS for the chained product: pass 1 computes every chunk in
     // registers (and stores it to y), pass 2 writes the chunks back in the TO row layout
-    constexpr int NITC = (PX_T * OCPR + 255) / 256;
+    constexpr int NITC = (PX_T * OCPR + NTHR - 1) / NTHR;
     constexpr int ORSW = CO_T * 4 + 16;
     u32x4 fin[NITC];
     bool okc[NITC];
 #pragma unroll
     for (int b = 0; b < NITC; ++b) {
-      const int q = tid + b * 256;
+      const int q = tid + b * NTHR;
       const int px_l = q / OCPR, cc = q - px_l * OCPR;
       const int p = px0 + px_l, co = co0 + cc * VO;
       okc[b] = q < PX_T * OCPR && p < a.M && co < a.Cout;
@@ -328,7 +328,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
     __syncthreads();
 #pragma unroll
     for (int b = 0; b < NITC; ++b) {
-      const int q = tid + b * 256;
+      const int q = tid + b * NTHR;
       const int px_l = q / OCPR, cc = q - px_l * OCPR;
       if (q < PX_T * OCPR) *reinterpret_cast<u32x4*>(smem + px_l * ORS + cc * 16) = fin[b];
     }
@@ -336,14 +336,14 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
     return;
   }
   if (wide) {                                    // residual loads batched four deep, fp32 add, one rounding
-    constexpr int ORSW = CO_T * 4 + 16, NITW = (PX_T * OCPR + 255) / 256, EBW = NITW < 4 ? NITW : 4;
+    constexpr int ORSW = CO_T * 4 + 16, NITW = (PX_T * OCPR + NTHR - 1) / NTHR, EBW = NITW < 4 ? NITW : 4;
     for (int it0 = 0; it0 < NITW; it0 += EBW) {
       u32x4 rv[EBW];
       long yo[EBW];
       bool ok[EBW];
 #pragma unroll
       for (int b = 0; b < EBW; ++b) {
-        const int q = tid + (it0 + b) * 256;
+        const int q = tid + (it0 + b) * NTHR;
         const int px_l = q / OCPR, cc = q - px_l * OCPR;
         const int p = px0 + px_l, co = co0 + cc * VO;
         ok[b] = q < PX_T * OCPR && p < a.M && co < a.Cout;
@@ -357,7 +357,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
 #pragma unroll
       for (int b = 0; b < EBW; ++b) {
         if (ok[b]) {
-          const int q = tid + (it0 + b) * 256;
+          const int q = tid + (it0 + b) * NTHR;
           const int px_l = q / OCPR, cc = q - px_l * OCPR;
           const f32x4 lo = *reinterpret_cast<const f32x4*>(smem + px_l * ORSW + cc * 32);
           const f32x4 hi = *reinterpret_cast<const f32x4*>(smem + px_l * ORSW + cc * 32 + 16);
@@ -371,9 +371,9 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
   // first add / store, so a residual layer keeps EB x 16 B per thread in flight instead of one
   // (measured: +3...8 % on the residual 1x1 layers with 64-wide tiles; on the 128x128 tile, 8 chunks
   // per thread, the extra live registers cost 25 % -- there the chunks go one by one)
-  constexpr int NIT = (PX_T * OCPR + 255) / 256;
+  constexpr int NIT = (PX_T * OCPR + NTHR - 1) / NTHR;
   if constexpr (NIT > 4) {
-    for (int q = tid; q < PX_T * OCPR; q += 256) {
+    for (int q = tid; q < PX_T * OCPR; q += NTHR) {
       const int px_l = q / OCPR, cc = q - px_l * OCPR;
       const int p = px0 + px_l, co = co0 + cc * VO;
       if (p < a.M && co < a.Cout) {
@@ -398,7 +398,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
     bool ok[EB];
 #pragma unroll
     for (int b = 0; b < EB; ++b) {
-      const int q = tid + (it0 + b) * 256;
+      const int q = tid + (it0 + b) * NTHR;
       const int px_l = q / OCPR, cc = q - px_l * OCPR;
       const int p = px0 + px_l, co = co0 + cc * VO;
       ok[b] = q < PX_T * OCPR && p < a.M && co < a.Cout;
@@ -414,7 +414,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
 #pragma unroll
     for (int b = 0; b < EB; ++b) {
       if (ok[b]) {
-        const int q = tid + (it0 + b) * 256;
+        const int q = tid + (it0 + b) * NTHR;
         const int px_l = q / OCPR, cc = q - px_l * OCPR;
         u32x4 v = *reinterpret_cast<const u32x4*>(smem + px_l * ORS + cc * 16);
         if (a.res) v = add_chunk(v, rv[b], (TO*)nullptr, a.act_post);
@@ -427,9 +427,9 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
   }
 }
 
-template <typename T, typename TO, int CO_T, int PX_T, int KB, int WCO, bool UT, bool CH = false>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
-  conv_igemm_body<T, TO, CO_T, PX_T, KB, WCO, UT, CH>(a, blockIdx.x, gridDim.x);
+template <typename T, typename TO, int CO_T, int PX_T, int KB, int WCO, bool UT, bool CH = false, int NTHR = 256>
+__global__ __launch_bounds__(NTHR) void conv_igemm_kernel(const ConvArgs a) {
+  conv_igemm_body<T, TO, CO_T, PX_T, KB, WCO, UT, CH, NTHR>(a, blockIdx.x, gridDim.x);
 }
 
 // Several independent convolutions of the SAME shape class (kernel size, stride, channels, dtypes:
@@ -453,16 +453,16 @@ __global__ __launch_bounds__(256) void conv_igemm_multi_kernel(const ConvArgsN m
 }
 
 // ---- host side --------------------------------------------------------------------------
-template <typename T, typename TO, int CO_T, int PX_T, int KB, int WCO, bool UT, bool CH = false>
+template <typename T, typename TO, int CO_T, int PX_T, int KB, int WCO, bool UT, bool CH = false, int NTHR = 256>
 static int launch_conv(const ConvArgs& a, hipStream_t st) {
-  if constexpr (!CH && UT && CO_T >= 64 && sizeof(T) == sizeof(TO)) {
+  if constexpr (!CH && UT && CO_T >= 64 && sizeof(T) == sizeof(TO) && NTHR == 256) {
     if (a.w2) return launch_conv<T, TO, CO_T, PX_T, KB, WCO, UT, true>(a, st);
   }
   if (a.w2 && !CH) GLS_FAIL(GLSDET_E_ARG, "conv2d_chain: this tile of the generic kernel has no chained form");
   int lds = conv_lds_bytes<CO_T, PX_T, KB, TO>(a.res != nullptr);
   if (a.w2 && chain_lds_bytes<T>(CO_T, PX_T, a) > lds) lds = chain_lds_bytes<T>(CO_T, PX_T, a);
   static int attr_lds = 64 * 1024;
-  auto kern = conv_igemm_kernel<T, TO, CO_T, PX_T, KB, WCO, UT, CH>;
+  auto kern = conv_igemm_kernel<T, TO, CO_T, PX_T, KB, WCO, UT, CH, NTHR>;
   const int want_attr = lds > conv_lds_bytes<CO_T, PX_T, KB, TO>(true) ? lds : conv_lds_bytes<CO_T, PX_T, KB, TO>(true);
   if (want_attr > attr_lds) {
     GLS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, want_attr));
@@ -476,7 +476,7 @@ static int launch_conv(const ConvArgs& a, hipStream_t st) {
   b.n_px_tiles = (a.M + PX_T - 1) / PX_T;
   const long grid = (long)b.n_co_tiles * b.n_px_tiles;
   if (grid <= 0 || grid > 0x7fffffffL) GLS_FAIL(GLSDET_E_ARG, "conv2d: grid %ld out of range", grid);
-  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, st, b);
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NTHR), lds, st, b);
   GLS_HIP(hipGetLastError());
   return 0;
 }
@@ -544,6 +544,10 @@ static int dispatch_tile(const ConvArgs& a, int co_t, int px_t, int kb, hipStrea
   GLS_CASE(32, 128, 1)
   GLS_CASE(64, 64, 2)
 #undef GLS_CASE
+  if (co_t == 128 && px_t == 256) {          // eight waves, 64 x 64 each (uniform-tap problems only)
+    if (!ut || a.w2) GLS_FAIL(GLSDET_E_ARG, "conv2d: the 128x256 tile needs Cin to be a whole number of K steps and no chained conv");
+    return kb == 128 ? launch_conv<T, TO, 128, 256, 128, 2, true, false, 512>(a, st) : launch_conv<T, TO, 128, 256, 64, 2, true, false, 512>(a, st);
+  }
   GLS_FAIL(GLSDET_E_ARG, "conv2d: no kernel for tile %dx%d", co_t, px_t);
 }
 
@@ -551,6 +555,7 @@ static void pick_tile(const ConvArgs& a, int elem, int hint, int* co_t, int* px_
   if (hint) {
     *co_t = hint >> 16;
     *px_t = hint & 0xff;
+    if (*px_t == 0) *px_t = 256;        // co<<16 | 0: the eight-wave 128 x 256 tile (bits 8..10 of a tile hint are diagnostic switches)
   } else {
     // largest tile that still gives the chip >= 3 workgroups per CU; below that the layer
     // is latency bound and more, smaller workgroups win over MFMA density
@@ -1024,11 +1029,13 @@ static int conv_tune(const glsdet_conv_desc* d, const glsdet_conv_chain* c, void
   hipStream_t st = (hipStream_t)stream;
   // (6 / 7, the persistent LDS-DMA halo kernel, is not offered: slower than 8 / 9 on every layer measured)
   const int hints[] = {2, 4, 5, 8, 9, 10, 11, 12, 13, 3, (128 << 16) | 128, (64 << 16) | 128, (64 << 16) | 64, (32 << 16) | 128,
-                       (64 << 16) | 64 | 0x8000, (64 << 16) | 128 | 0x8000, (128 << 16) | 128 | 0x8000};
+                       (64 << 16) | 64 | 0x8000, (64 << 16) | 128 | 0x8000, (128 << 16) | 128 | 0x8000, (128 << 16),
+                       (128 << 16) | 0x8000};
   std::vector<OpRecord> ops;
   std::vector<int> ids;
   for (int h : hints) {
     OpRecord op;
+    if ((h >> 16) == 128 && (h & 0xff) == 0 && (c || d->y.c <= 64)) continue;      // the eight-wave tile: wide layers, no chain
     if (build_conv_op(d, h, op, c)) continue;          // variant does not apply
     if ((h >> 16) == 32 && d->y.c > 32) continue;
     ops.push_back(std::move(op));

@@ -87,7 +87,7 @@ typedef struct glsdet_conv_desc {
                             * 8 / 9 halo with the weight tiles in an LDS-DMA ring (64- / 128-row cout tiles) | 10 / 11 the same with
                             *   64-byte channel chunks (64 / 128 rows) | 12 / 13 the 8-wave form: 128 cout rows x 8 x 32 pixels per
                             *   512-thread workgroup (128- / 64-byte chunks; no residual) | 3 weight-stationary 1x1 |
-                            * co_tile<<16|px_tile (|0x8000: 64-byte K steps) */
+                            * co_tile<<16|px_tile (|0x8000: 64-byte K steps); 128<<16|0 = the 8-wave 128 x 256 tile */
 } glsdet_conv_desc;
 
 int     glsdet_conv2d(const glsdet_conv_desc* d, void* stream);

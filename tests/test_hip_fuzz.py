@@ -12,7 +12,7 @@ from tests.test_hip_ops import TOL, _cmp, _to_view
 pytestmark = pytest.mark.gpu
 
 HINTS = [0, 1, 2, 3, 4, 5, 8, 9, 10, 11, 12, 13, (128 << 16) | 128, (64 << 16) | 128, (64 << 16) | 64, (32 << 16) | 128,
-         (64 << 16) | 64 | 0x8000, (128 << 16) | 128 | 0x8000]
+         (64 << 16) | 64 | 0x8000, (128 << 16) | 128 | 0x8000, (128 << 16), (128 << 16) | 0x8000]
 
 
 def _cases(n, seed):

@@ -43,7 +43,7 @@ RESNET = [  # ResNet-50 / FPN / head layers at 8 x 800 x 1344
 ]
 HINTS = {"auto": 0, "halo": 2, "halowp": 4, "halo64": 5, "dma64": 6, "dma128": 7, "ring64": 8, "ring128": 9, "ring64k64": 10, "ring128k64": 11, "ring8": 12, "ring8k64": 13, "ws1x1": 3, "g128x128": (128 << 16) | 128, "g64x128": (64 << 16) | 128,
          "g64x64": (64 << 16) | 64, "g64x64k64": (64 << 16) | 64 | 0x8000, "g64x128k64": (64 << 16) | 128 | 0x8000, "g32x128": (32 << 16) | 128,
-         "g128x128k64": (128 << 16) | 128 | 0x8000}
+         "g128x128k64": (128 << 16) | 128 | 0x8000, "g128x256": (128 << 16), "g128x256k64": (128 << 16) | 0x8000}
 
 
 def main():

@@ -26,7 +26,8 @@ import bench
 HINTS = {"generic": 1, "halo": 2, "halo_wp": 4, "halo_co64": 5, "halo_ring64": 8, "halo_ring128": 9,
          "halo_ring64k64": 10, "halo_ring128k64": 11, "halo_ring8": 12, "halo_ring8k64": 13, "ws1x1": 3, "g128x128": (128 << 16) | 128, "g64x128": (64 << 16) | 128,
          "g64x64": (64 << 16) | 64, "g32x128": (32 << 16) | 128, "g64x64k64": (64 << 16) | 64 | 0x8000,
-         "g64x128k64": (64 << 16) | 128 | 0x8000, "g128x128k64": (128 << 16) | 128 | 0x8000}
+         "g64x128k64": (64 << 16) | 128 | 0x8000, "g128x128k64": (128 << 16) | 128 | 0x8000, "g128x256": (128 << 16),
+         "g128x256k64": (128 << 16) | 0x8000}
 MULTI = {"m128x128": (128 << 16) | 128, "m64x128": (64 << 16) | 128, "m64x64": (64 << 16) | 64,
          "m64x64k64": (64 << 16) | 64 | 0x8000, "m64x128k64": (64 << 16) | 128 | 0x8000, "m128x128k64": (128 << 16) | 128 | 0x8000}
 dev = "cuda:0"
