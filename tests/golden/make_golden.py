@@ -341,10 +341,129 @@ def eval_cases():
     print("eval:", len(cases), "cases,", os.path.getsize(os.path.join(HERE, "eval_golden.npz")), "bytes")
 
 
+def _mmcv_building_blocks():
+    """Stand-ins for the FIVE mmcv names resnet.py / res_layer.py / fpn.py import (mmcv-full is not installable here).
+    Each is the documented behaviour of the mmcv function for the arguments these files pass -- nothing of the reference's
+    own composition logic (strides, 'pytorch' style, downsample, stage structure, top-down path, extra convs) is restated:
+      build_conv_layer(None, ...)          -> nn.Conv2d(...)
+      build_norm_layer(dict(type='BN'), c, postfix) -> ('bn<postfix>', nn.BatchNorm2d(c))    (requires_grad honoured)
+      build_plugin_layer                   -> never called (plugins=None)
+      BaseModule / Sequential              -> nn.Module / nn.Sequential accepting init_cfg
+      ConvModule(conv_cfg=None, norm_cfg=None, act_cfg=None) -> .conv = nn.Conv2d(bias=True); forward = conv
+      auto_fp16 / force_fp32               -> identity decorators
+    """
+    mmcv = _stub("mmcv")
+    cnn = _stub("mmcv.cnn")
+    runner = _stub("mmcv.runner")
+
+    def build_conv_layer(cfg, *a, **k):
+        assert cfg is None
+        return torch.nn.Conv2d(*a, **k)
+
+    def build_norm_layer(cfg, num_features, postfix=""):
+        assert cfg["type"] == "BN"
+        m = torch.nn.BatchNorm2d(num_features, eps=cfg.get("eps", 1e-5))
+        for p_ in m.parameters():
+            p_.requires_grad = cfg.get("requires_grad", True)
+        return "bn" + str(postfix), m
+
+    class BaseModule(torch.nn.Module):
+        def __init__(self, init_cfg=None):
+            super().__init__()
+            self.init_cfg = init_cfg
+
+    class Sequential(torch.nn.Sequential):
+        def __init__(self, *a, init_cfg=None):
+            super().__init__(*a)
+
+    class ConvModule(torch.nn.Module):
+        def __init__(self, cin, cout, k, stride=1, padding=0, conv_cfg=None, norm_cfg=None, act_cfg=dict(type="ReLU"), inplace=True):
+            super().__init__()
+            assert conv_cfg is None and norm_cfg is None and act_cfg is None, "FPN builds plain convs"
+            self.conv = torch.nn.Conv2d(cin, cout, k, stride, padding)
+
+        def forward(self, x):
+            return self.conv(x)
+
+    ident = lambda *a, **k: (lambda f: f)
+    cnn.build_conv_layer, cnn.build_norm_layer, cnn.build_plugin_layer, cnn.ConvModule = build_conv_layer, build_norm_layer, None, ConvModule
+    runner.BaseModule, runner.Sequential, runner.auto_fp16, runner.force_fp32 = BaseModule, Sequential, ident, ident
+    mmcv.cnn, mmcv.runner = cnn, runner
+    return mmcv
+
+
+def _load_ref_module(name, path):
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(name, path)
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[name] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def resdet_cases():
+    """the reference's OWN mmdet/models/backbones/resnet.py (ResNet, Bottleneck),
+    utils/res_layer.py (ResLayer) and necks/fpn.py (FPN) executed on seeded data -- loaded by file path under their package
+    names with the mmcv building blocks stood in (above) and an empty registry.  Pins the composition the restatement
+    (oracle/mpdet_oracle.py) and the HIP path (glsdet_amd/resdet.py) must reproduce."""
+    saved = {k: sys.modules.get(k) for k in ("mmcv", "mmcv.cnn", "mmcv.runner", "mmdet", "mmdet.models", "mmdet.models.builder",
+                                             "mmdet.models.utils", "mmdet.models.utils.res_layer", "mmdet.models.backbones",
+                                             "mmdet.models.backbones.resnet", "mmdet.models.necks", "mmdet.models.necks.fpn")}
+    try:
+        _mmcv_building_blocks()
+        root = os.path.join("/root/reference", "yolox-ufp", "mmdet", "models")
+        for pkg in ("mmdet", "mmdet.models", "mmdet.models.utils", "mmdet.models.backbones", "mmdet.models.necks"):
+            m = _stub(pkg)
+            m.__path__ = []
+        reg = type("Registry", (), {"register_module": lambda self, *a, **k: (lambda c: c)})()
+        b = _stub("mmdet.models.builder")
+        b.BACKBONES = b.NECKS = reg
+        rl = _load_ref_module("mmdet.models.utils.res_layer", os.path.join(root, "utils", "res_layer.py"))
+        sys.modules["mmdet.models.utils"].ResLayer = rl.ResLayer
+        rn = _load_ref_module("mmdet.models.backbones.resnet", os.path.join(root, "backbones", "resnet.py"))
+        fp = _load_ref_module("mmdet.models.necks.fpn", os.path.join(root, "necks", "fpn.py"))
+        out = {}
+        block = make_block(out)
+
+        class Trunk(torch.nn.Module):       # configs/UFPMP-Det: ResNet-50 (4 stages, out 0..3, BN eval, pytorch style) + FPN
+            def __init__(self, fpn_kw):
+                super().__init__()
+                self.backbone = rn.ResNet(depth=50, num_stages=4, out_indices=(0, 1, 2, 3), frozen_stages=1,
+                                          norm_cfg=dict(type="BN", requires_grad=True), norm_eval=True, style="pytorch")
+                self.neck = fp.FPN(in_channels=[256, 512, 1024, 2048], out_channels=256, **fpn_kw) if fpn_kw is not None else None
+
+            def forward(self, x):
+                f = self.backbone(x)
+                if self.neck is not None:
+                    f = self.neck(f)
+                return torch.cat([t.flatten(1) for t in f], 1)
+        with torch.no_grad():
+            block("res50_c2_c5", lambda: Trunk(None), (1, 3, 64, 96), calibrate=True)
+            block("res50_fpn_gfl", lambda: Trunk(dict(start_level=1, add_extra_convs="on_output", num_outs=5)), (2, 3, 96, 128),
+                  seed=1, calibrate=True)
+            block("res50_fpn_all_levels_odd", lambda: Trunk(dict(start_level=0, add_extra_convs="on_input", num_outs=5)), (1, 3, 72, 104),
+                  seed=2, calibrate=True)
+            block("res_bottleneck_s2_down", lambda: rn.Bottleneck(64, 32, stride=2, style="pytorch",
+                                                                  downsample=torch.nn.Sequential(torch.nn.Conv2d(64, 128, 1, 2, bias=False),
+                                                                                                 torch.nn.BatchNorm2d(128))),
+                  (2, 64, 20, 24), seed=3)
+        np.savez_compressed(os.path.join(HERE, "resdet_golden.npz"), **out)
+        print("resdet:", len(out), "arrays,", os.path.getsize(os.path.join(HERE, "resdet_golden.npz")), "bytes")
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+
+
 def main():
     if "--merge-eval-only" in sys.argv:
         merge_cases()
         eval_cases()
+        return
+    if "--resdet-only" in sys.argv:
+        resdet_cases()
         return
     if "--attention-only" in sys.argv:
         att = {}
