@@ -457,6 +457,120 @@ def resdet_cases():
                 sys.modules[k] = v
 
 
+def head_cases():
+    """SURVEY section 8a row A11 (forward part): the reference's OWN GFLHead / MPHead / Integral
+    (yolox-ufp/mmdet/models/dense_heads/{gfl_head,mp_head,anchor_head,base_dense_head,dense_test_mixins}.py), loaded by file
+    path.  Stand-ins: the mmcv building blocks (ConvModule = conv without bias -> GroupNorm -> ReLU with mmcv's attribute
+    names `conv`, `gn`; Scale = x * scalar parameter; init helpers = no-ops), `mmdet.core` as a namespace of dummies except
+    multi_apply (mmcv's five-line map/zip), nltk (imported by mp_head.py for training only), an empty registry, and
+    constructor-only dummies for build_loss / build_bbox_coder / build_prior_generator (strides and one prior per position are
+    all __init__ reads).  What is pinned: the towers, predictors, per-level Scale, the fp32 cast, MPHead's gfl_cls_conv +
+    forward_proxy (normalisation, per-class softmax-weighted mean over its proxies, gamma), Integral."""
+    names = ["mmcv", "mmcv.cnn", "mmcv.cnn.utils", "mmcv.cnn.utils.weight_init", "mmcv.runner", "mmcv.ops", "nltk", "nltk.cluster",
+             "nltk.cluster.kmeans", "mmdet", "mmdet.core", "mmdet.core.utils", "mmdet.utils", "mmdet.utils.contextmanagers", "mmdet.models",
+             "mmdet.models.builder",
+             "mmdet.models.dense_heads", "mmdet.models.dense_heads.base_dense_head", "mmdet.models.dense_heads.dense_test_mixins",
+             "mmdet.models.dense_heads.anchor_head", "mmdet.models.dense_heads.gfl_head", "mmdet.models.dense_heads.mp_head"]
+    saved = {k: sys.modules.get(k) for k in names}
+    try:
+        mmcv = _mmcv_building_blocks()
+        nn = torch.nn
+
+        class ConvModule(nn.Module):
+            def __init__(self, cin, cout, k, stride=1, padding=0, conv_cfg=None, norm_cfg=None, act_cfg=dict(type="ReLU"), inplace=True):
+                super().__init__()
+                assert conv_cfg is None and norm_cfg is not None and norm_cfg["type"] == "GN" and act_cfg["type"] == "ReLU"
+                self.conv = nn.Conv2d(cin, cout, k, stride, padding, bias=False)      # bias='auto': none under a norm
+                self.gn = nn.GroupNorm(norm_cfg["num_groups"], cout)
+                self.activate = nn.ReLU(inplace=inplace)
+
+            def forward(self, x):
+                return self.activate(self.gn(self.conv(x)))
+
+        class Scale(nn.Module):
+            def __init__(self, scale=1.0):
+                super().__init__()
+                self.scale = nn.Parameter(torch.tensor(scale, dtype=torch.float))
+
+            def forward(self, x):
+                return x * self.scale
+        noop = lambda *a, **k: None
+        mmcv.cnn.ConvModule, mmcv.cnn.Scale, mmcv.cnn.bias_init_with_prob, mmcv.cnn.normal_init = ConvModule, Scale, (lambda p_: 0.0), noop
+        u = _stub("mmcv.cnn.utils")
+        wi = _stub("mmcv.cnn.utils.weight_init", constant_init=noop)
+        u.weight_init = wi
+        _stub("mmcv.ops", batched_nms=None)
+        _stub("nltk")
+        _stub("nltk.cluster")
+        _stub("nltk.cluster.kmeans", KMeansClusterer=None)
+
+        def multi_apply(func, *args, **kwargs):           # mmdet/core/utils/misc.py:10-30
+            from functools import partial
+            pfunc = partial(func, **kwargs) if kwargs else func
+            return tuple(map(list, zip(*map(pfunc, *args))))
+
+        class _Prior:
+            strides = [(8, 8), (16, 16), (32, 32), (64, 64), (128, 128)]
+            num_base_priors = [1] * 5
+        core = _stub("mmdet.core", multi_apply=multi_apply, build_prior_generator=lambda cfg: _Prior(),
+                     build_anchor_generator=lambda cfg: _Prior(), build_bbox_coder=lambda cfg: object())
+        for nm in ("anchor_inside_flags", "bbox_overlaps", "build_assigner", "build_sampler", "images_to_levels", "reduce_mean", "unmap",
+                   "multiclass_nms", "bbox_mapping_back", "merge_aug_proposals"):
+            setattr(core, nm, None)
+        _stub("mmdet.core.utils", filter_scores_and_topk=None, select_single_mlvl=None)
+        _stub("mmdet.utils")
+        _stub("mmdet.utils.contextmanagers", completed=None)      # (async test path of dense_test_mixins.py, python >= 3.7 only)
+        for pkg in ("mmdet", "mmdet.models", "mmdet.models.dense_heads"):
+            m = _stub(pkg)
+            m.__path__ = []
+        reg = type("Registry", (), {"register_module": lambda self, *a, **k: (lambda c: c)})()
+        _stub("mmdet.models.builder", HEADS=reg, build_loss=lambda cfg: nn.Identity())
+        root = os.path.join("/root/reference", "yolox-ufp", "mmdet", "models", "dense_heads")
+        for f in ("base_dense_head", "dense_test_mixins", "anchor_head", "gfl_head", "mp_head"):
+            _load_ref_module("mmdet.models.dense_heads." + f, os.path.join(root, f + ".py"))
+        gfl = sys.modules["mmdet.models.dense_heads.gfl_head"]
+        mp = sys.modules["mmdet.models.dense_heads.mp_head"]
+        out = {}
+        block = make_block(out)
+        common = dict(num_classes=10, in_channels=64, feat_channels=64, stacked_convs=4,
+                      anchor_generator=dict(type="AnchorGenerator", ratios=[1.0], octave_base_scale=8, scales_per_octave=1,
+                                            strides=[8, 16, 32, 64, 128]),
+                      loss_cls=dict(type="QualityFocalLoss", use_sigmoid=True, beta=2.0, loss_weight=1.0),
+                      loss_dfl=dict(type="DistributionFocalLoss", loss_weight=0.25), reg_max=16,
+                      loss_bbox=dict(type="GIoULoss", loss_weight=2.0))
+
+        def levels_of(x):                                  # five pyramid levels from one seeded tensor (mirrored by the tests)
+            f = [x]
+            for _ in range(4):
+                f.append(torch.nn.functional.avg_pool2d(f[-1], 2, ceil_mode=True))
+            return f
+
+        def wrap(ctor):
+            class Head(nn.Module):
+                def __init__(self):
+                    super().__init__()
+                    self.bbox_head = ctor()
+
+                def forward(self, x):
+                    cls, reg = self.bbox_head(levels_of(x))
+                    return torch.cat([t.flatten(1) for t in cls] + [t.flatten(1) for t in reg], 1)
+            return Head
+        block("gfl_head_forward", wrap(lambda: gfl.GFLHead(**common)), (2, 64, 24, 40))
+        block("mp_head_forward", wrap(lambda: mp.MPHead(num_words=8, gamma=10, proxies_list=[2, 3, 2, 5, 4, 8, 8, 4, 3, 3], **common)),
+              (2, 64, 20, 28), seed=1)
+        x = synth_input((37, 68), 5) * 3.0
+        out["integral/x"] = x.numpy()
+        out["integral/y"] = gfl.Integral(16)(x).numpy()
+        np.savez_compressed(os.path.join(HERE, "head_golden.npz"), **out)
+        print("heads:", len(out), "arrays,", os.path.getsize(os.path.join(HERE, "head_golden.npz")), "bytes")
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+
+
 def main():
     if "--merge-eval-only" in sys.argv:
         merge_cases()
@@ -464,6 +578,7 @@ def main():
         return
     if "--resdet-only" in sys.argv:
         resdet_cases()
+        head_cases()
         return
     if "--attention-only" in sys.argv:
         att = {}

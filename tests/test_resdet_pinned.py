@@ -86,3 +86,65 @@ def test_hip_resnet_fpn_vs_the_reference_golden(engines, gold, mode, tag):
         assert _err(got, want) <= max(1e-4, 2 * noise)
     else:
         assert rms <= 3e-2 and _err(got, want) <= 0.35
+
+
+# ----------------------------------------------------------------------------------------------- A11 (forward part)
+@pytest.fixture(scope="module")
+def hgold():
+    return np.load(os.path.join(ROOT, "tests", "golden", "head_golden.npz"))
+
+
+PROXIES = [2, 3, 2, 5, 4, 8, 8, 4, 3, 3]
+
+
+def _levels(x):
+    f = [x]
+    for _ in range(4):
+        f.append(torch.nn.functional.avg_pool2d(f[-1], 2, ceil_mode=True))
+    return f
+
+
+def _head_oracle(tag, sd, x):
+    if tag == "gfl_head_forward":
+        cls, reg = M.gfl_head(sd, "m.bbox_head", _levels(x), 4)
+    else:
+        cls, reg = M.mp_head(sd, "m.bbox_head", _levels(x), PROXIES, 10.0, 4)
+    return torch.cat([t.flatten(1) for t in cls] + [t.flatten(1) for t in reg], 1)
+
+
+@pytest.mark.parametrize("tag", ["gfl_head_forward", "mp_head_forward"])
+def test_oracle_matches_the_reference_heads(hgold, tag):
+    """outputs of the reference's own GFLHead / MPHead classes (towers of conv -> GN32 -> ReLU, shared over five levels,
+    gfl_cls / gfl_cls_conv + forward_proxy, gfl_reg x per-level Scale, fp32) -- make_golden.py head_cases()"""
+    sd, x, want = block_case(hgold, tag)
+    got = _head_oracle(tag, sd, x)
+    assert got.shape == want.shape
+    assert _err(got, want) <= 5e-5
+
+
+def test_oracle_integral_matches_the_reference_class(hgold):
+    got = M.integral(torch.from_numpy(hgold["integral/x"]), 16)
+    assert float((got - torch.from_numpy(hgold["integral/y"])).abs().max()) <= 1e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["f32", "f16"])
+@pytest.mark.parametrize("tag", ["gfl_head_forward", "mp_head_forward"])
+def test_hip_heads_vs_the_reference_golden(engines, hgold, mode, tag):
+    from glsdet_amd.resdet import ResDetBuilder
+    from tests.test_hip_ops import _to_view
+    eng = engines[mode]
+    sd, x, want = block_case(hgold, tag)
+    b = ResDetBuilder(eng, sd)
+    feats = [_to_view(eng, f) for f in _levels(x)]
+    if tag == "gfl_head_forward":
+        cls, reg = b.gfl_head("m.bbox_head", feats, 4)
+        nc = 10
+    else:
+        cls, reg = b.mp_head("m.bbox_head", feats, PROXIES, 10.0, 4)
+        nc = 10
+    torch.cuda.synchronize()
+    got = torch.cat([t.to_nchw(nc).cpu().flatten(1) for t in cls] + [t.to_nchw(68).cpu().flatten(1) for t in reg], 1)
+    assert got.shape == want.shape
+    print("%s %s: err %.3e" % (tag, mode, _err(got, want)))
+    assert _err(got, want) <= (1e-4 if mode == "f32" else 3e-2)
