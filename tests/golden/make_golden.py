@@ -532,7 +532,7 @@ def head_cases():
         mp = sys.modules["mmdet.models.dense_heads.mp_head"]
         out = {}
         block = make_block(out)
-        common = dict(num_classes=10, in_channels=64, feat_channels=64, stacked_convs=4,
+        common = dict(num_classes=10, in_channels=256, feat_channels=256, stacked_convs=4,
                       anchor_generator=dict(type="AnchorGenerator", ratios=[1.0], octave_base_scale=8, scales_per_octave=1,
                                             strides=[8, 16, 32, 64, 128]),
                       loss_cls=dict(type="QualityFocalLoss", use_sigmoid=True, beta=2.0, loss_weight=1.0),
@@ -555,9 +555,9 @@ def head_cases():
                     cls, reg = self.bbox_head(levels_of(x))
                     return torch.cat([t.flatten(1) for t in cls] + [t.flatten(1) for t in reg], 1)
             return Head
-        block("gfl_head_forward", wrap(lambda: gfl.GFLHead(**common)), (2, 64, 24, 40))
+        block("gfl_head_forward", wrap(lambda: gfl.GFLHead(**common)), (2, 256, 24, 40))
         block("mp_head_forward", wrap(lambda: mp.MPHead(num_words=8, gamma=10, proxies_list=[2, 3, 2, 5, 4, 8, 8, 4, 3, 3], **common)),
-              (2, 64, 20, 28), seed=1)
+              (2, 256, 20, 28), seed=1)
         x = synth_input((37, 68), 5) * 3.0
         out["integral/x"] = x.numpy()
         out["integral/y"] = gfl.Integral(16)(x).numpy()
