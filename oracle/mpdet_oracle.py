@@ -160,16 +160,16 @@ def integral(x: Tensor, reg_max: int = 16) -> Tensor:
     return F.linear(x, torch.linspace(0, reg_max, reg_max + 1).type_as(x)).reshape(-1, 4)
 
 
-def gfl_get_bboxes(cls_scores: Sequence[Tensor], bbox_preds: Sequence[Tensor], strides: Sequence[int],
-                   img_shapes: Sequence[Sequence[int]], score_thr: float, nms_pre: int, iou_thr: float,
-                   max_per_img: int, scale_factors=None, reg_max: int = 16):
-    """base_dense_head.get_bboxes -> gfl_head._get_bboxes_single :380-471 -> _bbox_post_process
-    :226-301.  Per image and level: sigmoid scores, (position, class) pairs with score >
-    score_thr, the nms_pre best of them (filter_scores_and_topk, misc.py:119-165; ties keep the
-    lower flat index first = stable sort), Integral * stride, distance2bbox from the anchor
-    centre (x*stride, y*stride) clamped to img_shape; levels concatenated, / scale_factor when
-    given, per-class NMS, first max_per_img.
-    -> list[img] of (dets ndarray(n,5) x1,y1,x2,y2,score ; labels ndarray(n) int64)."""
+def gfl_pre_nms(cls_scores: Sequence[Tensor], bbox_preds: Sequence[Tensor], strides: Sequence[int],
+                img_shapes: Sequence[Sequence[int]], score_thr: float, nms_pre: int, scale_factors=None,
+                reg_max: int = 16) -> List[Tuple[Tensor, Tensor, Tensor]]:
+    """base_dense_head.get_bboxes -> gfl_head._get_bboxes_single :380-471 -> _bbox_post_process :226-301 with
+    with_nms=False.  Per image and level: sigmoid scores, (position, class) pairs with score > score_thr, the nms_pre
+    best of them (filter_scores_and_topk, misc.py:119-165; ties keep the lower flat index first = stable sort),
+    Integral * stride, distance2bbox from the anchor centre (x*stride, y*stride) clamped to img_shape; levels
+    concatenated, / scale_factor when given.  -> list[img] of (boxes [k,4], scores [k], labels [k]).
+    PINNED by tests/golden/head_golden.npz (the reference's own get_bboxes with its AnchorGenerator, bbox coder and
+    filter_scores_and_topk)."""
     nc = cls_scores[0].shape[1]
     results = []
     for b in range(cls_scores[0].shape[0]):
@@ -193,6 +193,17 @@ def gfl_get_bboxes(cls_scores: Sequence[Tensor], bbox_preds: Sequence[Tensor], s
         boxes, scores, labels = torch.cat(boxes), torch.cat(scores), torch.cat(labels)
         if scale_factors is not None:
             boxes = boxes / torch.as_tensor(np.asarray(scale_factors[b], np.float32))
+        results.append((boxes, scores, labels))
+    return results
+
+
+def gfl_get_bboxes(cls_scores: Sequence[Tensor], bbox_preds: Sequence[Tensor], strides: Sequence[int],
+                   img_shapes: Sequence[Sequence[int]], score_thr: float, nms_pre: int, iou_thr: float,
+                   max_per_img: int, scale_factors=None, reg_max: int = 16):
+    """gfl_pre_nms, then per-class NMS (mmcv.ops.batched_nms -- a compiled op, restated: parity unpinned) and the first
+    max_per_img.  -> list[img] of (dets ndarray(n,5) x1,y1,x2,y2,score ; labels ndarray(n) int64)."""
+    results = []
+    for boxes, scores, labels in gfl_pre_nms(cls_scores, bbox_preds, strides, img_shapes, score_thr, nms_pre, scale_factors, reg_max):
         if boxes.numel() == 0:
             results.append((np.zeros((0, 5), np.float32), np.zeros((0,), np.int64)))
             continue

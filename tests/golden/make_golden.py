@@ -470,7 +470,10 @@ def head_cases():
              "nltk.cluster.kmeans", "mmdet", "mmdet.core", "mmdet.core.utils", "mmdet.utils", "mmdet.utils.contextmanagers", "mmdet.models",
              "mmdet.models.builder",
              "mmdet.models.dense_heads", "mmdet.models.dense_heads.base_dense_head", "mmdet.models.dense_heads.dense_test_mixins",
-             "mmdet.models.dense_heads.anchor_head", "mmdet.models.dense_heads.gfl_head", "mmdet.models.dense_heads.mp_head"]
+             "mmdet.models.dense_heads.anchor_head", "mmdet.models.dense_heads.gfl_head", "mmdet.models.dense_heads.mp_head",
+             "mmdet.core.anchor", "mmdet.core.anchor.builder", "mmdet.core.anchor.anchor_generator", "mmdet.core.bbox",
+             "mmdet.core.bbox.builder", "mmdet.core.bbox.transforms", "mmdet.core.bbox.coder", "mmdet.core.bbox.coder.base_bbox_coder",
+             "mmdet.core.bbox.coder.distance_point_bbox_coder", "mmdet.core.mask", "mmdet.core.mask.structures", "mmdet.core.utils.misc"]
     saved = {k: sys.modules.get(k) for k in names}
     try:
         mmcv = _mmcv_building_blocks()
@@ -561,6 +564,51 @@ def head_cases():
         x = synth_input((37, 68), 5) * 3.0
         out["integral/x"] = x.numpy()
         out["integral/y"] = gfl.Integral(16)(x).numpy()
+
+        # ---- get_bboxes up to (not including) the NMS: base_dense_head.get_bboxes -> gfl_head._get_bboxes_single(with_nms=False)
+        # with the reference's REAL AnchorGenerator, DistancePointBBoxCoder / distance2bbox, filter_scores_and_topk and
+        # select_single_mlvl (loaded by path; only their registries and mask imports are stood in).  mmcv.ops.batched_nms is a
+        # compiled op: the NMS itself stays unpinned, exactly as torchvision's for the YOLOX path.
+        core_root = os.path.join("/root/reference", "yolox-ufp", "mmdet", "core")
+        for pkg in ("mmdet.core.anchor", "mmdet.core.bbox", "mmdet.core.bbox.coder", "mmdet.core.mask"):
+            m = _stub(pkg)
+            m.__path__ = []
+        _stub("mmdet.core.anchor.builder", PRIOR_GENERATORS=reg, ANCHOR_GENERATORS=reg)
+        _stub("mmdet.core.bbox.builder", BBOX_CODERS=reg)
+        _stub("mmdet.core.mask.structures", BitmapMasks=type("BitmapMasks", (), {}), PolygonMasks=type("PolygonMasks", (), {}))
+        sys.modules["mmcv"].is_tuple_of = lambda seq, t: isinstance(seq, tuple) and all(isinstance(v, t) for v in seq)
+        ag = _load_ref_module("mmdet.core.anchor.anchor_generator", os.path.join(core_root, "anchor", "anchor_generator.py"))
+        _load_ref_module("mmdet.core.bbox.transforms", os.path.join(core_root, "bbox", "transforms.py"))
+        _load_ref_module("mmdet.core.bbox.coder.base_bbox_coder", os.path.join(core_root, "bbox", "coder", "base_bbox_coder.py"))
+        dc = _load_ref_module("mmdet.core.bbox.coder.distance_point_bbox_coder",
+                              os.path.join(core_root, "bbox", "coder", "distance_point_bbox_coder.py"))
+        misc = _load_ref_module("mmdet.core.utils.misc", os.path.join(core_root, "utils", "misc.py"))
+        bdh = sys.modules["mmdet.models.dense_heads.base_dense_head"]
+        gfl.filter_scores_and_topk = misc.filter_scores_and_topk
+        bdh.filter_scores_and_topk, bdh.select_single_mlvl = misc.filter_scores_and_topk, misc.select_single_mlvl
+
+        class Cfg(dict):
+            __getattr__ = dict.get
+        head = gfl.GFLHead(**common)
+        head.prior_generator = ag.AnchorGenerator(strides=[8, 16, 32, 64, 128], ratios=[1.0], octave_base_scale=8, scales_per_octave=1)
+        head.bbox_coder = dc.DistancePointBBoxCoder()
+        head.eval()
+        sizes = [(12, 20), (6, 10), (3, 5), (2, 3), (1, 2)]
+        rng = np.random.default_rng(11)
+        cls = [torch.from_numpy(rng.normal(-2.0, 1.5, (2, 10) + s).astype(np.float32)) for s in sizes]
+        reg = [torch.from_numpy(rng.normal(0.0, 2.0, (2, 68) + s).astype(np.float32)) for s in sizes]
+        metas = [dict(img_shape=(90, 150, 3), scale_factor=np.array([1.25, 1.25, 1.25, 1.25], np.float32)),
+                 dict(img_shape=(96, 160, 3), scale_factor=np.array([0.8, 0.75, 0.8, 0.75], np.float32))]
+        for i, l in enumerate(cls):
+            out["bboxes/cls/%d" % i] = l.numpy()
+            out["bboxes/reg/%d" % i] = reg[i].numpy()
+        for tag, rescale, cfg in (("plain", False, Cfg(nms_pre=1000, score_thr=0.05, max_per_img=100)),
+                                  ("topk_rescale", True, Cfg(nms_pre=40, score_thr=0.2, max_per_img=100))):
+            res = head.get_bboxes(cls, reg, img_metas=metas, cfg=cfg, rescale=rescale, with_nms=False)
+            for b, (bx, sc, lb) in enumerate(res):
+                out["bboxes/%s/%d/boxes" % (tag, b)] = bx.numpy()
+                out["bboxes/%s/%d/scores" % (tag, b)] = sc.numpy()
+                out["bboxes/%s/%d/labels" % (tag, b)] = lb.numpy()
         np.savez_compressed(os.path.join(HERE, "head_golden.npz"), **out)
         print("heads:", len(out), "arrays,", os.path.getsize(os.path.join(HERE, "head_golden.npz")), "bytes")
     finally:

@@ -148,3 +148,60 @@ def test_hip_heads_vs_the_reference_golden(engines, hgold, mode, tag):
     assert got.shape == want.shape
     print("%s %s: err %.3e" % (tag, mode, _err(got, want)))
     assert _err(got, want) <= (1e-4 if mode == "f32" else 3e-2)
+
+
+BB_CASES = {"plain": dict(rescale=False, nms_pre=1000, thr=0.05), "topk_rescale": dict(rescale=True, nms_pre=40, thr=0.2)}
+BB_STRIDES = [8, 16, 32, 64, 128]
+BB_SHAPES = [(90, 150, 3), (96, 160, 3)]
+BB_SF = [[1.25, 1.25, 1.25, 1.25], [0.8, 0.75, 0.8, 0.75]]
+
+
+def _bb_inputs(hgold):
+    cls = [torch.from_numpy(hgold["bboxes/cls/%d" % i]) for i in range(5)]
+    reg = [torch.from_numpy(hgold["bboxes/reg/%d" % i]) for i in range(5)]
+    return cls, reg
+
+
+@pytest.mark.parametrize("tag", sorted(BB_CASES))
+def test_oracle_pre_nms_candidates_match_the_reference_get_bboxes(hgold, tag):
+    """GFLHead.get_bboxes(with_nms=False) of the reference -- its own AnchorGenerator (anchor centres), Integral,
+    filter_scores_and_topk (threshold, per-level top-k, order), DistancePointBBoxCoder / distance2bbox (clamp to the image
+    shape), rescale -- against oracle.gfl_pre_nms: same candidates in the same ORDER, boxes to 1e-4."""
+    c = BB_CASES[tag]
+    cls, reg = _bb_inputs(hgold)
+    got = M.gfl_pre_nms(cls, reg, BB_STRIDES, BB_SHAPES, c["thr"], c["nms_pre"], BB_SF if c["rescale"] else None)
+    for b, (bx, sc, lb) in enumerate(got):
+        wb, ws, wl = (hgold["bboxes/%s/%d/%s" % (tag, b, k)] for k in ("boxes", "scores", "labels"))
+        assert len(lb) == len(wl) and len(wl) > 20
+        np.testing.assert_array_equal(lb.numpy(), wl)
+        np.testing.assert_allclose(sc.numpy(), ws, atol=1e-6)
+        np.testing.assert_allclose(bx.numpy(), wb, atol=1e-4, rtol=1e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", sorted(BB_CASES))
+def test_hip_gfl_detect_candidates_vs_the_reference_get_bboxes(engines, hgold, tag):
+    """glsdet_gfl_detect with an IoU threshold no pair can reach (so its NMS keeps everything) and a max_per_img above the
+    candidate count: the device's candidate SET (position/class pairs after threshold and per-level top-k, decoded,
+    clamped, rescaled) must be the reference's; the device returns it sorted by score, the reference level by level."""
+    from tests.test_resdet import _fp32_view
+    eng = engines["f32"]
+    c = BB_CASES[tag]
+    cls, reg = _bb_inputs(hgold)
+    nb = eng.gfl_buffers(2, 5, 4096, c["nms_pre"], 2000)
+    hw = torch.tensor([[s[0], s[1]] for s in BB_SHAPES], dtype=torch.float32).cuda()
+    sft = torch.tensor(BB_SF, dtype=torch.float32).cuda() if c["rescale"] else None
+    dets, count, status = eng.gfl_detect([_fp32_view(eng, t) for t in cls], [_fp32_view(eng, t) for t in reg], BB_STRIDES, 10, 16,
+                                         96, 160, c["thr"], 1.01, nb, img_hw=hw, scale_factors=sft)
+    torch.cuda.synchronize()
+    assert int(status.item()) == 0
+    count, dets = count.cpu().numpy(), dets.cpu().numpy()
+    for b in range(2):
+        wb, ws, wl = (hgold["bboxes/%s/%d/%s" % (tag, b, k)] for k in ("boxes", "scores", "labels"))
+        assert count[b] == len(wl)
+        got = dets[b, : count[b]]
+        key = lambda box, s, l: np.lexsort((box[:, 3], box[:, 2], box[:, 1], box[:, 0], l, -s))
+        go, wo = key(got[:, :4], got[:, 4], got[:, 6]), key(wb, ws, wl.astype(np.float32))
+        np.testing.assert_array_equal(got[go, 6].astype(np.int64), wl[wo])
+        np.testing.assert_allclose(got[go, 4], ws[wo], atol=1e-6)
+        np.testing.assert_allclose(got[go, :4], wb[wo], atol=1e-3, rtol=1e-5)
