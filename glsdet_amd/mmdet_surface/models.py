@@ -134,13 +134,16 @@ def _pafpn_table(in_channels: Sequence[int], out_channels: int, n: int, gl: bool
     c = list(in_channels)
     t = _Table()
     extra = 1 if gl else 0
+    # registration order of the reference's YOLOXPAFPN.__init__ (necks/yolox_pafpn.py:60-118: the two ModuleLists of the
+    # top-down path, then the two of the bottom-up path) -- pinned by tests/test_mmdet_pinned.py against the state_dict of
+    # the reference's own module (round 1 interleaved them, which only the ORDER of state_dict() shows)
     t.conv_bn("reduce_layers.0", c[2], c[1], 1)
-    _mm_csp(t, "top_down_blocks.0", (2 + extra) * c[1], c[1], n)
     t.conv_bn("reduce_layers.1", c[1], c[0], 1)
+    _mm_csp(t, "top_down_blocks.0", (2 + extra) * c[1], c[1], n)
     _mm_csp(t, "top_down_blocks.1", 2 * c[0], c[0], n)
     t.conv_bn("downsamples.0", c[0], c[0], 3)
-    _mm_csp(t, "bottom_up_blocks.0", (2 + extra) * c[0], c[1], n)
     t.conv_bn("downsamples.1", c[1], c[1], 3)
+    _mm_csp(t, "bottom_up_blocks.0", (2 + extra) * c[0], c[1], n)
     _mm_csp(t, "bottom_up_blocks.1", 2 * c[1], c[2], n)
     for i in range(3):
         t.conv_bn("out_convs.%d" % i, c[i], out_channels, 1)

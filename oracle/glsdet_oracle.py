@@ -610,6 +610,24 @@ from glsdet_amd.synth import synth_input, synth_state_dict, synth_tensor  # noqa
 
 
 # --------------------------------------------------------------------------- mmdet flavour
+def mlvl_point_priors(sizes, strides) -> Tensor:
+    """MlvlPointGenerator(strides, offset=0).grid_priors(sizes, with_stride=True), levels concatenated: [x, y, s, s] per
+    position, x fastest (ufp/mmdet/core/anchor/point_generator.py:100-177).  Pinned by tests/golden/yolox_mmdet_golden.npz."""
+    out = []
+    for (h, w), s in zip(sizes, strides):
+        gy, gx = torch.meshgrid(torch.arange(h), torch.arange(w), indexing="ij")
+        out.append(torch.stack((gx.flatten() * s, gy.flatten() * s, torch.full((h * w,), s), torch.full((h * w,), s)), 1).float())
+    return torch.cat(out)
+
+
+def mmdet_bbox_decode(priors: Tensor, preds: Tensor) -> Tensor:
+    """YOLOXHead._bbox_decode (ufp/mmdet/models/dense_heads/yolox_head.py:298-308): centre = pred_xy * stride + prior_xy,
+    size = exp(pred_wh) * stride, -> x1, y1, x2, y2."""
+    xys = preds[..., :2] * priors[:, 2:] + priors[:, :2]
+    whs = preds[..., 2:4].exp() * priors[:, 2:]
+    return torch.cat((xys - whs / 2, xys + whs / 2), -1)
+
+
 def mmdet_yolox_get_bboxes(outs: Sequence[Tensor], num_classes: int, strides: Sequence[int], score_thr: float,
                            iou_thr: float, scale_factors=None):
     """YOLOXHead.get_bboxes / _bbox_decode / _bboxes_nms + bbox2result restated
@@ -617,16 +635,9 @@ def mmdet_yolox_get_bboxes(outs: Sequence[Tensor], num_classes: int, strides: Se
     offset=0, core/bbox/transforms.py:116-133).  `outs` = per level [B, 4+1+nc, H, W] in the
     drone channel order (reg, obj, cls).  -> list[img] of list[class] of ndarray(n,5)."""
     B = outs[0].shape[0]
-    priors, flat = [], []
-    for o, s in zip(outs, strides):
-        h, w = o.shape[-2:]
-        gy, gx = torch.meshgrid(torch.arange(h), torch.arange(w), indexing="ij")
-        priors.append(torch.stack((gx.flatten() * s, gy.flatten() * s, torch.full((h * w,), s), torch.full((h * w,), s)), 1).float())
-        flat.append(o.permute(0, 2, 3, 1).reshape(B, -1, o.shape[1]))
-    priors, flat = torch.cat(priors), torch.cat(flat, 1).float()
-    xys = flat[..., :2] * priors[:, 2:] + priors[:, :2]
-    whs = flat[..., 2:4].exp() * priors[:, 2:]
-    boxes = torch.cat((xys - whs / 2, xys + whs / 2), -1)
+    flat = [o.permute(0, 2, 3, 1).reshape(B, -1, o.shape[1]) for o in outs]
+    priors, flat = mlvl_point_priors([o.shape[-2:] for o in outs], strides), torch.cat(flat, 1).float()
+    boxes = mmdet_bbox_decode(priors, flat[..., :4])
     if scale_factors is not None:
         boxes = boxes / torch.as_tensor(np.asarray(scale_factors, np.float32)).reshape(B, 1, 4)
     obj, cls = flat[..., 4].sigmoid(), flat[..., 5:5 + num_classes].sigmoid()

@@ -619,6 +619,105 @@ def head_cases():
                 sys.modules[k] = v
 
 
+def yolox_mmdet_cases():
+    """The mmdet flavour of the YOLOX path (SURVEY 8a note: yolox-ufp/mmdet CSPDarknet / YOLOXPAFPN / YOLOXHead are the same
+    network as yolox-drone's under other parameter names): the reference's OWN backbones/csp_darknet.py, utils/csp_layer.py,
+    necks/yolox_pafpn.py, dense_heads/yolox_head.py (+ base_dense_head, dense_test_mixins, core/anchor/point_generator.py),
+    loaded by path.  Stand-ins: ConvModule = conv (no bias under a norm) -> BatchNorm2d(eps, momentum of the cfg) -> Swish
+    under mmcv's attribute names `conv`, `bn`, `activate`; BaseModule; registries; constructor-only dummies for the losses.
+    Pins the module structure and parameter NAMES the mmdet_surface twins and `mmdet_to_drone_key` must reproduce, the raw
+    head outputs, and `_bbox_decode` on the reference's own priors."""
+    names = ["mmcv", "mmcv.cnn", "mmcv.runner", "mmcv.ops", "mmcv.ops.nms", "mmcv.cnn.utils", "mmcv.cnn.utils.weight_init", "mmdet",
+             "mmdet.core", "mmdet.core.utils", "mmdet.core.anchor", "mmdet.core.anchor.builder", "mmdet.core.anchor.point_generator",
+             "mmdet.utils", "mmdet.utils.contextmanagers", "mmdet.models", "mmdet.models.builder", "mmdet.models.utils",
+             "mmdet.models.utils.csp_layer", "mmdet.models.backbones", "mmdet.models.backbones.csp_darknet", "mmdet.models.necks",
+             "mmdet.models.necks.yolox_pafpn", "mmdet.models.dense_heads", "mmdet.models.dense_heads.base_dense_head",
+             "mmdet.models.dense_heads.dense_test_mixins", "mmdet.models.dense_heads.yolox_head"]
+    saved = {k: sys.modules.get(k) for k in names}
+    try:
+        mmcv = _mmcv_building_blocks()
+        nn = torch.nn
+
+        class Swish(nn.Module):
+            def forward(self, x):
+                return x * torch.sigmoid(x)
+
+        class ConvModule(nn.Module):
+            def __init__(self, cin, cout, k, stride=1, padding=0, dilation=1, groups=1, bias="auto", conv_cfg=None, norm_cfg=None,
+                         act_cfg=dict(type="ReLU"), inplace=True):
+                super().__init__()
+                assert conv_cfg is None and norm_cfg["type"] == "BN" and act_cfg["type"] == "Swish" and bias == "auto"
+                self.conv = nn.Conv2d(cin, cout, k, stride, padding, dilation, groups, bias=False)
+                self.bn = nn.BatchNorm2d(cout, eps=norm_cfg.get("eps", 1e-5), momentum=norm_cfg.get("momentum", 0.1))
+                self.activate = Swish()
+
+            def forward(self, x):
+                return self.activate(self.bn(self.conv(x)))
+        noop = lambda *a, **k: None
+        mmcv.cnn.ConvModule, mmcv.cnn.DepthwiseSeparableConvModule, mmcv.cnn.bias_init_with_prob = ConvModule, None, (lambda p_: 0.0)
+        _stub("mmcv.cnn.utils")
+        _stub("mmcv.cnn.utils.weight_init", constant_init=noop)
+        _stub("mmcv.ops", batched_nms=None)
+        _stub("mmcv.ops.nms", batched_nms=None)
+        for pkg in ("mmdet", "mmdet.models", "mmdet.models.utils", "mmdet.models.backbones", "mmdet.models.necks",
+                    "mmdet.models.dense_heads", "mmdet.core.anchor"):
+            m = _stub(pkg)
+            m.__path__ = []
+        reg = type("Registry", (), {"register_module": lambda self, *a, **k: (lambda c: c)})()
+        _stub("mmdet.models.builder", BACKBONES=reg, NECKS=reg, HEADS=reg, build_loss=lambda cfg: nn.Identity())
+        _stub("mmdet.core.anchor.builder", PRIOR_GENERATORS=reg)
+        _stub("mmdet.utils")
+        _stub("mmdet.utils.contextmanagers", completed=None)
+        core_root = os.path.join("/root/reference", "yolox-ufp", "mmdet", "core")
+        pg = _load_ref_module("mmdet.core.anchor.point_generator", os.path.join(core_root, "anchor", "point_generator.py"))
+
+        def multi_apply(func, *args, **kwargs):
+            from functools import partial
+            pfunc = partial(func, **kwargs) if kwargs else func
+            return tuple(map(list, zip(*map(pfunc, *args))))
+        core = _stub("mmdet.core", MlvlPointGenerator=pg.MlvlPointGenerator, multi_apply=multi_apply)
+        for nm in ("bbox_xyxy_to_cxcywh", "build_assigner", "build_sampler", "reduce_mean", "bbox_mapping_back", "merge_aug_proposals"):
+            setattr(core, nm, None)
+        _stub("mmdet.core.utils", filter_scores_and_topk=None, select_single_mlvl=None)
+        root = os.path.join("/root/reference", "yolox-ufp", "mmdet", "models")
+        csp = _load_ref_module("mmdet.models.utils.csp_layer", os.path.join(root, "utils", "csp_layer.py"))
+        sys.modules["mmdet.models.utils"].CSPLayer = csp.CSPLayer
+        bb = _load_ref_module("mmdet.models.backbones.csp_darknet", os.path.join(root, "backbones", "csp_darknet.py"))
+        nk = _load_ref_module("mmdet.models.necks.yolox_pafpn", os.path.join(root, "necks", "yolox_pafpn.py"))
+        for f in ("base_dense_head", "dense_test_mixins", "yolox_head"):
+            _load_ref_module("mmdet.models.dense_heads." + f, os.path.join(root, "dense_heads", f + ".py"))
+        yh = sys.modules["mmdet.models.dense_heads.yolox_head"]
+        out = {}
+        block = make_block(out)
+
+        class Det(nn.Module):        # configs/yolox/yolox_s_8x8_300e_coco.py:6-22 with 10 classes
+            def __init__(self):
+                super().__init__()
+                self.backbone = bb.CSPDarknet(deepen_factor=0.33, widen_factor=0.5)
+                self.neck = nk.YOLOXPAFPN(in_channels=[128, 256, 512], out_channels=128, num_csp_blocks=1)
+                self.bbox_head = yh.YOLOXHead(num_classes=10, in_channels=128, feat_channels=128)
+
+            def forward(self, x):
+                cls, reg, obj = self.bbox_head(self.neck(self.backbone(x)))
+                return torch.cat([torch.cat((r, o, c), 1).flatten(1) for c, r, o in zip(cls, reg, obj)], 1)
+        with torch.no_grad():
+            block("yolox_s_mmdet", Det, (2, 3, 96, 128), calibrate=True)
+            head = yh.YOLOXHead(num_classes=10, in_channels=128, feat_channels=128)
+            priors = torch.cat(head.prior_generator.grid_priors([(12, 16), (6, 8), (3, 4)], device="cpu", with_stride=True))
+            preds = synth_input((2, priors.shape[0], 4), 9)
+            out["decode/preds"] = preds.numpy()
+            out["decode/priors"] = priors.numpy()
+            out["decode/boxes"] = head._bbox_decode(priors, preds).numpy()
+        np.savez_compressed(os.path.join(HERE, "yolox_mmdet_golden.npz"), **out)
+        print("yolox mmdet:", len(out), "arrays,", os.path.getsize(os.path.join(HERE, "yolox_mmdet_golden.npz")), "bytes")
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+
+
 def main():
     if "--merge-eval-only" in sys.argv:
         merge_cases()
@@ -627,6 +726,7 @@ def main():
     if "--resdet-only" in sys.argv:
         resdet_cases()
         head_cases()
+        yolox_mmdet_cases()
         return
     if "--attention-only" in sys.argv:
         att = {}
