@@ -205,3 +205,16 @@ def test_hip_gfl_detect_candidates_vs_the_reference_get_bboxes(engines, hgold, t
         np.testing.assert_array_equal(got[go, 6].astype(np.int64), wl[wo])
         np.testing.assert_allclose(got[go, 4], ws[wo], atol=1e-6)
         np.testing.assert_allclose(got[go, :4], wb[wo], atol=1e-3, rtol=1e-5)
+
+
+@pytest.mark.parametrize("cfg,tag,opts", [("configs/UFPMP-Det/coarse_det.py", "gfl_head_forward", {}),
+                                          ("configs/UFPMP-Det/mp_det_res50.py", "mp_head_forward", {"model.bbox_head.num_words": 8})])
+def test_surface_state_dicts_are_the_reference_mmdet_state_dicts(gold, hgold, cfg, tag, opts):
+    """GFL / MPDet of glsdet_amd.mmdet_surface list exactly what the reference's own ResNet + FPN (+ GFLHead / MPHead incl.
+    its BoIW buffers) register: names, shapes, order -- a reference checkpoint loads key for key."""
+    from glsdet_amd.mmdet_surface import init_detector
+    from tests.helpers import meta_of
+    ours = [(k, list(v.shape)) for k, v in init_detector(os.path.join(ROOT, cfg), device="cpu", cfg_options=opts).state_dict().items()]
+    ref = [(k, list(v)) for k, v in meta_of(gold, "block/res50_fpn_gfl/meta")["shapes"].items()] + \
+          [(k, list(v)) for k, v in meta_of(hgold, "block/%s/meta" % tag)["shapes"].items()]
+    assert ours == ref
