@@ -583,6 +583,15 @@ def head_cases():
         dc = _load_ref_module("mmdet.core.bbox.coder.distance_point_bbox_coder",
                               os.path.join(core_root, "bbox", "coder", "distance_point_bbox_coder.py"))
         misc = _load_ref_module("mmdet.core.utils.misc", os.path.join(core_root, "utils", "misc.py"))
+        tr = sys.modules["mmdet.core.bbox.transforms"]              # bbox2result (transforms.py:116-133): the result format
+        rng2 = np.random.default_rng(3)
+        bb = np.concatenate([rng2.uniform(0, 100, (23, 4)), rng2.uniform(0, 1, (23, 1))], 1).astype(np.float32)
+        lb = rng2.integers(0, 10, 23).astype(np.int64)
+        out["bbox2result/boxes"], out["bbox2result/labels"] = bb, lb
+        for c, arr in enumerate(tr.bbox2result(torch.from_numpy(bb), torch.from_numpy(lb), 10)):
+            out["bbox2result/class%d" % c] = arr
+        for c, arr in enumerate(tr.bbox2result(np.zeros((0, 5), np.float32), np.zeros((0,), np.int64), 3)):
+            out["bbox2result/empty%d" % c] = arr
         bdh = sys.modules["mmdet.models.dense_heads.base_dense_head"]
         gfl.filter_scores_and_topk = misc.filter_scores_and_topk
         bdh.filter_scores_and_topk, bdh.select_single_mlvl = misc.filter_scores_and_topk, misc.select_single_mlvl

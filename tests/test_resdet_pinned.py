@@ -218,3 +218,16 @@ def test_surface_state_dicts_are_the_reference_mmdet_state_dicts(gold, hgold, cf
     ref = [(k, list(v)) for k, v in meta_of(gold, "block/res50_fpn_gfl/meta")["shapes"].items()] + \
           [(k, list(v)) for k, v in meta_of(hgold, "block/%s/meta" % tag)["shapes"].items()]
     assert ours == ref
+
+
+def test_bbox2result_equals_the_reference_function(hgold):
+    """mmdet's result format (core/bbox/transforms.py:116-133): per class an (n, 5) float32 array in the input order"""
+    from glsdet_amd.mmdet_surface.resdet_models import bbox2result
+    got = bbox2result(hgold["bbox2result/boxes"], hgold["bbox2result/labels"], 10)
+    assert len(got) == 10
+    for c, a in enumerate(got):
+        w = hgold["bbox2result/class%d" % c]
+        assert a.dtype == w.dtype and a.shape == w.shape
+        np.testing.assert_array_equal(a, w)
+    empty = bbox2result(np.zeros((0, 5), np.float32), np.zeros((0,), np.int64), 3)
+    assert [e.shape for e in empty] == [hgold["bbox2result/empty%d" % c].shape for c in range(3)] and all(e.dtype == np.float32 for e in empty)
