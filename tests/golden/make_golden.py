@@ -847,6 +847,9 @@ def main():
     with open(os.path.join(HERE, "shapes.json"), "w") as f:
         json.dump(shapes_all, f, separators=(",", ":"))
     print("wrote", len(out), "arrays;", os.path.getsize(os.path.join(HERE, "drone_golden.npz")), "bytes")
+    resdet_cases()              # yolox-ufp/mmdet: ResNet + FPN, GFLHead / MPHead / get_bboxes, the mmdet flavour of YOLOX
+    head_cases()
+    yolox_mmdet_cases()
 
 
 if __name__ == "__main__":
