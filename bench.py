@@ -400,8 +400,18 @@ def run_workload(args, workload, rank, world, dev, with_cpu_baseline):
     # settle (untimed, before the W warmup steps): the first GPU process on a fresh box ran the same build at 3000-3200
     # instead of 4100-4300 img/s for its first ~0.2 s twice this round (clocks / power state still ramping); a run of the
     # real step until --settle seconds have passed puts the measurement on the steady state the later steps see anyway
+    # (N > 1: every round carries collectives, so the ranks agree on each further round -- a clock of its own per rank would
+    # let one rank leave the loop a round early and pair its warmup gathers with the others' barrier)
     t_settle = time.perf_counter()
-    while time.perf_counter() - t_settle < args.settle:
+    more = torch.zeros(1, dtype=torch.int32, device=dev)
+    while True:
+        go = time.perf_counter() - t_settle < args.settle
+        if world > 1:
+            more.fill_(int(go))
+            dist.all_reduce(more, op=dist.ReduceOp.MAX)
+            go = bool(int(more.item()))
+        if not go:
+            break
         for _ in range(8):
             step()
         fence()
@@ -509,6 +519,91 @@ def run_workload(args, workload, rank, world, dev, with_cpu_baseline):
     return res
 
 
+def run_two_stage(args, rank, world, dev):
+    """BASELINE configs[4]: the two-stage UFPMP-Det evaluation flow (ufpmp_det_eval.py:253-300) -- coarse GFL detector,
+    host packing, device mosaic, fine MPDet, device back-mapping + merge NMS -- with the two detectors pipelined on separate
+    HIP streams (glsdet_amd.ufp.TwoStagePipeline, three lanes).  Synthetic 540 x 1024 BGR frames (VisDrone's common size;
+    the data set is not available), synthetic weights, thresholds bisected so that the coarse stage proposes ~80 boxes and
+    the fine stage ~600 candidates per mosaic.  Frames shard round-robin over the ranks; per pass ONE all_gather of the
+    per-frame detection counts + the first `cap` boxes (N > 1).  A "step" here is one pass over the rank's 32 frames."""
+    import torch.distributed as dist
+    from glsdet_amd.resdet import HipGflDetector
+    from glsdet_amd.synth import synth_input, synth_resdet_state_dict
+    from glsdet_amd.ufp import TwoStagePipeline, UfpSecondStage, two_stage_detect
+
+    def frame(seed, h=540, w=1024):
+        rng = np.random.default_rng([seed, 0x1A6E])
+        yy, xx = np.mgrid[0:h, 0:w].astype(np.float64)
+        img = np.stack([127 + 120 * np.sin(xx / (5 + 3 * c) + seed) * np.cos(yy / (7 + 2 * c)) for c in range(3)], -1)
+        img += rng.normal(0, 25, img.shape)
+        img[: h // 5, : w // 4] = 255
+        img[-(h // 6):, -(w // 5):] = 0
+        return np.clip(img, 0, 255).astype(np.uint8)[:, :, ::-1].copy()
+    calib = synth_input((1, 3, 128, 160), 100)
+    coarse = HipGflDetector("gfl", synth_resdet_state_dict("gfl", 0, calib), dtype=args.dtype, autotune=not args.no_autotune)
+    fine = HipGflDetector("mpdet", synth_resdet_state_dict("mpdet", 1, calib), dtype=args.dtype, autotune=not args.no_autotune)
+    stage = UfpSecondStage()
+
+    def thr_for(det, x, keep):
+        cls, _ = det.forward_raw(x)
+        p = torch.sigmoid(torch.cat([c.flatten() for c in cls]))
+        return float(torch.topk(p, keep).values[-1])
+    img0 = frame(2)
+    x1, _ = stage.pipeline_input(torch.from_numpy(img0).to(dev).contiguous())
+    c1 = dict(score_thr=thr_for(coarse, x1, 80), iou_thr=0.6, nms_pre=1000, max_per_img=100)
+    _, mid = two_stage_detect(coarse, fine, img0, stage, c1, dict(score_thr=0.9999, iou_thr=0.6))
+    x2, _ = stage.pipeline_input(mid["canvas"])
+    c2 = dict(score_thr=thr_for(fine, x2, 600), iou_thr=0.6, nms_pre=1000, max_per_img=500)
+    per_rank, lanes, cap = 32, 3, 500
+    frames = [frame(100 + (rank + world * i) % 8) for i in range(per_rank)]          # global frame g = rank + world * i
+    pipe = TwoStagePipeline(coarse, fine, stage, c1, c2, workers=lanes)
+    pipe.run(frames[:8] * lanes)                    # every lane compiles (and tunes) every mosaic shape once
+    record = torch.zeros(per_rank, cap + 1, 6, dtype=torch.float32, device=dev)
+    gathered = torch.empty((world * per_rank, cap + 1, 6), dtype=torch.float32, device=dev) if world > 1 else None
+
+    def one_pass():
+        res = pipe.run(frames)
+        host = np.zeros((per_rank, cap + 1, 6), np.float32)
+        for i, per_class in enumerate(res):
+            rows = [np.concatenate([a[:, :5], np.full((len(a), 1), c, np.float32)], 1) for c, a in enumerate(per_class) if len(a)]
+            rows = np.concatenate(rows)[:cap] if rows else np.zeros((0, 6), np.float32)
+            host[i, : len(rows)] = rows
+            host[i, cap, 0] = len(rows)
+        record.copy_(torch.from_numpy(host))
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, record)
+        return res
+    one_pass()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    passes = max(2, args.steps // 50)
+    t0 = time.perf_counter()
+    for _ in range(passes):
+        res = one_pass()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    n_det = [int(sum(len(a) for a in r)) for r in res]
+    return {"workload": "ufpmp_two_stage_540x1024", "metric": "frames/sec, two-stage UFPMP-Det (coarse GFL -> packing -> mosaic -> fine MPDet -> merge NMS)",
+            "value": round(world * per_rank * passes / elapsed, 1), "unit": "frames/s", "ms_per_frame": round(elapsed / (per_rank * passes) * 1e3, 3),
+            "n_gpus": world, "passes": passes, "frames_per_rank_and_pass": per_rank, "data": "synthetic", "dtype": args.dtype,
+            "config": {"frame": [540, 1024], "lanes": lanes, "coarse": "GFL ResNet-50 + FPN (configs/UFPMP-Det/coarse_det.py)",
+                       "fine": "MPDet ResNet-50 + FPN + MPHead (configs/UFPMP-Det/mp_det_res50.py)",
+                       "coarse_post": {k: (round(v, 4) if isinstance(v, float) else v) for k, v in c1.items()},
+                       "fine_post": {k: (round(v, 4) if isinstance(v, float) else v) for k, v in c2.items()},
+                       "chips_frame0": int(len(mid["chips"])), "mosaic_frame0": [int(mid["canvas"].shape[0]), int(mid["canvas"].shape[1])],
+                       "detections_per_frame_rank0": n_det[:8], "exchange_cap": cap,
+                       "parallelism": "frame-sharded dp%d, one all_gather of the per-frame results per pass" % world},
+            "note": "BASELINE.json configs[4] (two-stage UFPMP eval, detectors pipelined on separate HIP streams) on synthetic frames: "
+                    "VisDrone-val is not available offline"}
+
+
 def spawn_ranks(n):
     """`python bench.py --gpus N` without a launcher: start N fresh processes (this one has not touched the GPU),
     rank r on GPU r, rendezvous on 127.0.0.1.  Rank 0 inherits stdout and prints the line."""
@@ -569,8 +664,14 @@ def main():
     ap.add_argument("--no-autotune", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the BASELINE config-3 leg (`secondary`)")
+    ap.add_argument("--no-tertiary", action="store_true", help="skip the BASELINE config-5 leg (`tertiary`: two-stage UFPMP pipeline)")
     ap.add_argument("--op-table", default="", help="write the per-op timing table (tsv) here")
+    ap.add_argument("--hang-dump", type=int, default=0, metavar="SECONDS",
+                    help="dump every thread's stack to stderr and exit if the run is still going after SECONDS (debugging aid)")
     args = ap.parse_args()
+    if args.hang_dump and ("WORLD_SIZE" in os.environ or args.gpus == 1):        # the ranks, not the launcher
+        import faulthandler
+        faulthandler.dump_traceback_later(args.hang_dump, exit=True)
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(spawn_ranks(args.gpus))                 # before any GPU call of this process
@@ -592,11 +693,22 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=torch.device(dev))
 
+    def progress(what):
+        if rank == 0:
+            print("[bench %6.1fs] %s" % (time.perf_counter() - t_start, what), file=sys.stderr, flush=True)
+    t_start = time.perf_counter()
     base = world == 1 and not args.no_cpu_baseline
+    progress("workload %s on %d rank(s)" % (args.workload, world))
     main_res = run_workload(args, args.workload, rank, world, dev, base)
     second = None
     if not args.no_secondary and args.workload != SECONDARY:
+        progress("secondary workload %s" % SECONDARY)
         second = run_workload(args, SECONDARY, rank, world, dev, base)
+    third = None
+    if not args.no_tertiary and not args.no_secondary and args.workload == "yolox_s_glfusion_1344x800_bs8" and not args.no_graph:
+        progress("tertiary workload ufpmp_two_stage_540x1024")
+        third = run_two_stage(args, rank, world, dev)
+    progress("done")
     if rank == 0:
         line = {
             "metric": "images/sec fwd @1333x800 bs=8 (detection forward incl. decode+NMS)",
@@ -612,6 +724,8 @@ def main():
             line["secondary"] = dict(second, metric=line["metric"], n_gpus=world, steps=args.steps, warmup=args.warmup,
                                      dtype=args.dtype, note="BASELINE.json configs[2] (mp_det_res50: ResNet-50 + GL-fusion + "
                                      "decoupled MPHead, 1333x800 bs=8), same protocol as the primary line")
+        if third is not None:
+            line["tertiary"] = third
         print(json.dumps(line))
     if world > 1:
         dist.barrier()
