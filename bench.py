@@ -319,7 +319,7 @@ def run_workload(args, workload, rank, world, dev, with_cpu_baseline):
     """Build, calibrate, time (warmup + exactly --steps steps between barriers) and profile per op ONE workload.
     -> (result dict, elapsed seconds) on every rank."""
     import torch.distributed as dist
-    from glsdet_amd.dist import DetectionExchange
+    from glsdet_amd.dist import DetectionExchange, ranks_agree
 
     kind, tag, H, W, bs = WORKLOADS[workload]
     gen = torch.Generator(device=dev).manual_seed(rank)
@@ -403,15 +403,7 @@ def run_workload(args, workload, rank, world, dev, with_cpu_baseline):
     # (N > 1: every round carries collectives, so the ranks agree on each further round -- a clock of its own per rank would
     # let one rank leave the loop a round early and pair its warmup gathers with the others' barrier)
     t_settle = time.perf_counter()
-    more = torch.zeros(1, dtype=torch.int32, device=dev)
-    while True:
-        go = time.perf_counter() - t_settle < args.settle
-        if world > 1:
-            more.fill_(int(go))
-            dist.all_reduce(more, op=dist.ReduceOp.MAX)
-            go = bool(int(more.item()))
-        if not go:
-            break
+    while ranks_agree(time.perf_counter() - t_settle < args.settle, "any", dev):
         for _ in range(8):
             step()
         fence()
@@ -527,6 +519,7 @@ def run_two_stage(args, rank, world, dev):
     the fine stage ~600 candidates per mosaic.  Frames shard round-robin over the ranks; per pass ONE all_gather of the
     per-frame detection counts + the first `cap` boxes (N > 1).  A "step" here is one pass over the rank's 32 frames."""
     import torch.distributed as dist
+    from glsdet_amd.dist import ranks_agree
     from glsdet_amd.resdet import HipGflDetector
     from glsdet_amd.synth import synth_input, synth_resdet_state_dict
     from glsdet_amd.ufp import TwoStagePipeline, UfpSecondStage, two_stage_detect
@@ -539,41 +532,75 @@ def run_two_stage(args, rank, world, dev):
         img[: h // 5, : w // 4] = 255
         img[-(h // 6):, -(w // 5):] = 0
         return np.clip(img, 0, 255).astype(np.uint8)[:, :, ::-1].copy()
-    calib = synth_input((1, 3, 128, 160), 100)
-    coarse = HipGflDetector("gfl", synth_resdet_state_dict("gfl", 0, calib), dtype=args.dtype, autotune=not args.no_autotune)
-    fine = HipGflDetector("mpdet", synth_resdet_state_dict("mpdet", 1, calib), dtype=args.dtype, autotune=not args.no_autotune)
-    stage = UfpSecondStage()
+    def agree(ok):
+        """Every rank learns whether all ranks are fine, so that a failure on one rank ends this leg on all of them before
+        the next collective instead of leaving the others waiting in it (the headline line must still be printed)."""
+        return ranks_agree(ok, "all", dev)
 
-    def thr_for(det, x, keep):
-        cls, _ = det.forward_raw(x)
-        p = torch.sigmoid(torch.cat([c.flatten() for c in cls]))
-        return float(torch.topk(p, keep).values[-1])
-    img0 = frame(2)
-    x1, _ = stage.pipeline_input(torch.from_numpy(img0).to(dev).contiguous())
-    c1 = dict(score_thr=thr_for(coarse, x1, 80), iou_thr=0.6, nms_pre=1000, max_per_img=100)
-    _, mid = two_stage_detect(coarse, fine, img0, stage, c1, dict(score_thr=0.9999, iou_thr=0.6))
-    x2, _ = stage.pipeline_input(mid["canvas"])
-    c2 = dict(score_thr=thr_for(fine, x2, 600), iou_thr=0.6, nms_pre=1000, max_per_img=500)
+    def failed(where, err):
+        return {"workload": "ufpmp_two_stage_540x1024", "n_gpus": world,
+                "error": "%s: %s" % (where, err or "another rank failed (this one was fine)")}
     per_rank, lanes, cap = 32, 3, 500
-    frames = [frame(100 + (rank + world * i) % 8) for i in range(per_rank)]          # global frame g = rank + world * i
-    pipe = TwoStagePipeline(coarse, fine, stage, c1, c2, workers=lanes)
-    pipe.run(frames[:8] * lanes)                    # every lane compiles (and tunes) every mosaic shape once
-    record = torch.zeros(per_rank, cap + 1, 6, dtype=torch.float32, device=dev)
-    gathered = torch.empty((world * per_rank, cap + 1, 6), dtype=torch.float32, device=dev) if world > 1 else None
+    S, err = {}, None
 
-    def one_pass():
-        res = pipe.run(frames)
+    def setup():
+        calib = synth_input((1, 3, 128, 160), 100)
+        coarse = HipGflDetector("gfl", synth_resdet_state_dict("gfl", 0, calib), dtype=args.dtype, autotune=not args.no_autotune)
+        fine = HipGflDetector("mpdet", synth_resdet_state_dict("mpdet", 1, calib), dtype=args.dtype, autotune=not args.no_autotune)
+        stage = UfpSecondStage()
+
+        def thr_for(det, x, keep):
+            cls, _ = det.forward_raw(x)
+            p = torch.sigmoid(torch.cat([c.flatten() for c in cls]))
+            return float(torch.topk(p, keep).values[-1])
+        img0 = frame(2)
+        x1, _ = stage.pipeline_input(torch.from_numpy(img0).to(dev).contiguous())
+        c1 = dict(score_thr=thr_for(coarse, x1, 80), iou_thr=0.6, nms_pre=1000, max_per_img=100)
+        _, mid = two_stage_detect(coarse, fine, img0, stage, c1, dict(score_thr=0.9999, iou_thr=0.6))
+        x2, _ = stage.pipeline_input(mid["canvas"])
+        c2 = dict(score_thr=thr_for(fine, x2, 600), iou_thr=0.6, nms_pre=1000, max_per_img=500)
+        S["frames"] = [frame(100 + (rank + world * i) % 8) for i in range(per_rank)]          # global frame g = rank + world * i
+        S["pipe"] = TwoStagePipeline(coarse, fine, stage, c1, c2, workers=lanes)
+        S["pipe"].run(S["frames"][:8] * lanes)                    # every lane compiles (and tunes) every mosaic shape once
+        S["record"] = torch.zeros(per_rank, cap + 1, 6, dtype=torch.float32, device=dev)
+        S["gathered"] = torch.empty((world * per_rank, cap + 1, 6), dtype=torch.float32, device=dev) if world > 1 else None
+        S.update(c1=c1, c2=c2, mid=mid)
+
+    def local_pass():
+        if os.environ.get("GLSDET_BENCH_TERTIARY_FAIL", "") == str(rank):       # rehearsal of the failure path below
+            raise RuntimeError("injected failure on rank %d" % rank)
+        res = S["pipe"].run(S["frames"])
         host = np.zeros((per_rank, cap + 1, 6), np.float32)
         for i, per_class in enumerate(res):
             rows = [np.concatenate([a[:, :5], np.full((len(a), 1), c, np.float32)], 1) for c, a in enumerate(per_class) if len(a)]
             rows = np.concatenate(rows)[:cap] if rows else np.zeros((0, 6), np.float32)
             host[i, : len(rows)] = rows
             host[i, cap, 0] = len(rows)
-        record.copy_(torch.from_numpy(host))
-        if world > 1:
-            dist.all_gather_into_tensor(gathered, record)
+        S["record"].copy_(torch.from_numpy(host))
         return res
-    one_pass()
+
+    def one_pass():
+        """The rank's 32 frames, then (N > 1) the agreement and the ONE all_gather.  None = some rank failed."""
+        nonlocal err
+        res = None
+        try:
+            res = local_pass()
+        except Exception as e:                                    # reported in the line, see failed()
+            err = repr(e)
+        if not agree(err is None):
+            return None
+        if world > 1:
+            dist.all_gather_into_tensor(S["gathered"], S["record"])
+        return res
+    try:
+        setup()
+    except Exception as e:
+        err = repr(e)
+    if not agree(err is None):
+        return failed("setup", err)
+    c1, c2, mid = S["c1"], S["c2"], S["mid"]
+    if one_pass() is None:
+        return failed("first pass", err)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -581,6 +608,8 @@ def run_two_stage(args, rank, world, dev):
     t0 = time.perf_counter()
     for _ in range(passes):
         res = one_pass()
+        if res is None:
+            return failed("timed pass", err)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()

@@ -28,6 +28,18 @@ def shard_indices(num_images: int, rank: int, world: int) -> List[int]:
     return list(range(rank, num_images, world))
 
 
+def ranks_agree(flag: bool, mode: str = "all", device="cpu", group=None) -> bool:
+    """One answer for every rank: `mode="all"` -- True only if every rank passed True (a failure anywhere ends a
+    collective phase everywhere); `mode="any"` -- True if some rank passed True (a clock-driven loop with collectives
+    inside runs the same number of rounds on every rank).  A rank must never decide on its own whether to enter a
+    collective: the others would wait in it.  No process group -> the local answer."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return bool(flag)
+    t = torch.tensor([int(bool(flag))], dtype=torch.int32, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN if mode == "all" else dist.ReduceOp.MAX, group=group)
+    return bool(int(t.item()))
+
+
 def pack_detections(dets: torch.Tensor, count: torch.Tensor) -> torch.Tensor:
     """dets [n, max_det, 7] + count [>=n] int32 -> [n, max_det+1, 7] fp32 (count in [:, -1, 0])."""
     n, k, f = dets.shape

@@ -130,3 +130,46 @@ def test_gather_detections_gloo_world2(tmp_path):
         procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     outs = [p.communicate(timeout=240)[0].decode() for p in procs]
     assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+
+
+_AGREE_WORKER = r'''
+import os, sys, time
+sys.path.insert(0, %(root)r)
+import torch, torch.distributed as dist
+from glsdet_amd.dist import ranks_agree
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%(port)d", rank=rank, world_size=world)
+# a clock-driven loop with collectives inside (bench.py's settle phase): rank 1's clock runs out three rounds before
+# rank 0's -- both must run the same number of rounds, or the gathers below pair with the barrier after the loop
+budget = 6 if rank == 0 else 3
+rounds = 0
+buf = torch.empty(world, dtype=torch.int32)
+while ranks_agree(rounds < budget, "any"):
+    dist.all_gather_into_tensor(buf, torch.tensor([rounds], dtype=torch.int32))
+    assert buf.tolist() == [rounds, rounds]
+    rounds += 1
+dist.barrier()
+assert rounds == 6
+# a failure on one rank ends the phase on both
+assert ranks_agree(True, "all") is True
+assert ranks_agree(rank == 0, "all") is False
+assert ranks_agree(rank == 1, "any") is True
+dist.barrier(); dist.destroy_process_group()
+print("rank", rank, "ok")
+'''
+
+
+def test_ranks_agree_gloo_world2(tmp_path):
+    """the rule behind bench.py's N>1 control flow: no rank decides alone whether to enter a collective"""
+    import socket
+    from glsdet_amd.dist import ranks_agree
+    assert ranks_agree(True) is True and ranks_agree(False, "any") is False         # no process group: the local answer
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    script = tmp_path / "a.py"
+    script.write_text(_AGREE_WORKER % {"root": ROOT, "port": port})
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    outs = [p.communicate(timeout=240)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
