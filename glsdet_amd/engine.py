@@ -858,11 +858,16 @@ class Engine:
             return
         data = {}
         if os.path.exists(self._tune_cache_path):
-            with open(self._tune_cache_path) as f:
-                data = json.load(f)
+            try:
+                with open(self._tune_cache_path) as f:
+                    data = json.load(f)
+            except ValueError:                      # another rank's half-written file from before the rename below existed
+                data = {}
         data[self._dtype_name] = {json.dumps(list(k)): v for k, v in self._tuned.items()}
-        with open(self._tune_cache_path, "w") as f:
+        tmp = "%s.%d.tmp" % (self._tune_cache_path, os.getpid())          # ranks sharing one cache path: whole files only
+        with open(tmp, "w") as f:
             json.dump(data, f)
+        os.replace(tmp, self._tune_cache_path)
         self._tune_dirty = False
 
     def new_plan(self) -> Plan:
