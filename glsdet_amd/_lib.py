@@ -10,7 +10,7 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "lib", "libglsdet_hip.so")
-ABI_VERSION = 11
+ABI_VERSION = 12
 CAPTURE_LOCK = threading.RLock()        # hipGraph captures are serialised across host threads
 
 F16, F32 = 0, 1
@@ -82,6 +82,7 @@ _SIGS = {
     "glsdet_spp_pools": (C.c_int, [C.POINTER(View), C.POINTER(View), C.POINTER(View), C.POINTER(View), C.c_void_p]),
     "glsdet_maxpool2d": (C.c_int, [C.POINTER(View), C.POINTER(View), C.c_int32, C.c_void_p]),
     "glsdet_resample_copy": (C.c_int, [C.POINTER(View), C.POINTER(View), C.c_int32, C.c_void_p]),
+    "glsdet_copy_many": (C.c_int, [C.POINTER(View), C.POINTER(View), C.c_int32, C.c_void_p]),
     "glsdet_nonlocal": (C.c_int, [C.POINTER(View), C.POINTER(View), C.c_int32, C.c_void_p, C.c_void_p,
                                   C.c_void_p, C.POINTER(View), C.c_void_p]),
     "glsdet_nonlocal_multi": (C.c_int, [C.POINTER(View), C.POINTER(View), C.c_int32, C.c_int32, C.POINTER(C.c_void_p),

@@ -2,6 +2,9 @@
 // resample / strided copy, and the non-local block (re-associated dot-product form).
 // All are coalesced 16-byte-per-lane NHWC kernels; none of them is GEMM shaped enough to
 // deserve MFMA (the non-local block is 0.35 % of the model's MACs before re-association).
+#include <algorithm>
+#include <vector>
+
 #include "common.h"
 
 namespace glsdet {
@@ -227,6 +230,38 @@ __global__ __launch_bounds__(256) void resample_kernel(const unsigned char* x, l
     const int b = (int)(p / Ho);
     const uint4 v = *reinterpret_cast<const uint4*>(x + (b * xsn + (h / f) * xsh + (w / f) * xsw + cc * VN) * (long)sizeof(T));
     *reinterpret_cast<uint4*>(y + (b * ysn + h * ysh + w * ysw + cc * VN) * (long)sizeof(T)) = v;
+  }
+}
+
+
+// the same strided copy for up to GLS_COPY_JOBS independent (source, destination) pairs of one launch: blockIdx.y = pair
+// (the dense per-(image, quadrant) operand copies of the ResNet GL plug-in were 96 launches of 7 us per step)
+#define GLS_COPY_JOBS 32
+struct CopyJob {
+  const unsigned char* x;
+  unsigned char* y;
+  long xsn, xsh, xsw, ysn, ysh, ysw;
+  int n, h, w;
+};
+struct CopyManyArgs {
+  CopyJob j[GLS_COPY_JOBS];
+  int C;
+};
+template <typename T>
+__global__ __launch_bounds__(256) void copy_many_kernel(CopyManyArgs a) {
+  constexpr int VN = Vec16<T>::N;
+  const CopyJob& jb = a.j[blockIdx.y];
+  const int cchunks = a.C / VN;
+  const long total = (long)jb.n * jb.h * jb.w * cchunks;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int cc = (int)(i % cchunks);
+    long p = i / cchunks;
+    const int w = (int)(p % jb.w);
+    p /= jb.w;
+    const int h = (int)(p % jb.h);
+    const int b = (int)(p / jb.h);
+    const uint4 v = *reinterpret_cast<const uint4*>(jb.x + (b * jb.xsn + h * jb.xsh + w * jb.xsw + cc * VN) * (long)sizeof(T));
+    *reinterpret_cast<uint4*>(jb.y + (b * jb.ysn + h * jb.ysh + w * jb.ysw + cc * VN) * (long)sizeof(T)) = v;
   }
 }
 
@@ -587,6 +622,57 @@ extern "C" int glsdet_resample_copy(const glsdet_view* x, const glsdet_view* y, 
     else
       hipLaunchKernelGGL(resample_kernel<float>, dim3(g), dim3(256), 0, st, (const unsigned char*)a.base, a.sn, a.sh, a.sw, (unsigned char*)b.base, b.sn, b.sh, b.sw, b.n, b.h, b.w, b.c, factor);
     GLS_HIP(hipGetLastError());
+    return 0;
+  };
+  return submit(std::move(op), stream);
+}
+
+extern "C" int glsdet_copy_many(const glsdet_view* x, const glsdet_view* y, int32_t count, void* stream) {
+  if (!x || !y) GLS_FAIL(GLSDET_E_ARG, "copy_many: null argument");
+  if (count < 1 || count > 4096) GLS_FAIL(GLSDET_E_ARG, "copy_many: 1..4096 pairs, got %d", count);
+  int rc;
+  std::vector<CopyJob> jobs((size_t)count);
+  double bytes = 0;
+  for (int i = 0; i < count; ++i) {
+    if ((rc = check_view(x[i], "copy_many.x"))) return rc;
+    if ((rc = check_view(y[i], "copy_many.y"))) return rc;
+    if (x[i].dtype != x[0].dtype || y[i].dtype != x[0].dtype || x[i].c != x[0].c || y[i].c != x[0].c)
+      GLS_FAIL(GLSDET_E_ARG, "copy_many: pair %d: one dtype and one channel count per call", i);
+    if (x[i].n != y[i].n || x[i].h != y[i].h || x[i].w != y[i].w) GLS_FAIL(GLSDET_E_ARG, "copy_many: pair %d: extent mismatch", i);
+    CopyJob& j = jobs[(size_t)i];
+    j.x = (const unsigned char*)x[i].base;
+    j.y = (unsigned char*)y[i].base;
+    j.xsn = x[i].sn, j.xsh = x[i].sh, j.xsw = x[i].sw, j.ysn = y[i].sn, j.ysh = y[i].sh, j.ysw = y[i].sw;
+    j.n = x[i].n, j.h = x[i].h, j.w = x[i].w;
+    const long px = (long)j.n * j.h * j.w;
+    bytes += 2.0 * px * x[i].c * dtype_size(x[i].dtype);
+  }
+  if (x[0].c % 8) GLS_FAIL(GLSDET_E_ARG, "copy_many: channels must be a multiple of 8");
+  const int C = x[0].c, dt = x[0].dtype;
+  OpRecord op;
+  op.kind = 3;
+  op.flops = 0;
+  op.bytes = bytes;
+  op.name = "copy_many[" + std::to_string(count) + "]";
+  op.launch = [=](hipStream_t st) -> int {
+    const int vn = 16 / dtype_size(dt);
+    // the pairs share the chip: about four workgroups per CU over one launch, at least one per pair
+    for (int j0 = 0; j0 < count; j0 += GLS_COPY_JOBS) {
+      const int nj = std::min(GLS_COPY_JOBS, count - j0);
+      CopyManyArgs a = {};
+      long big = 0;
+      for (int i = 0; i < nj; ++i) {
+        a.j[i] = jobs[(size_t)(j0 + i)];
+        big = std::max(big, (long)a.j[i].n * a.j[i].h * a.j[i].w * (C / vn));
+      }
+      a.C = C;
+      const unsigned per = (unsigned)std::max(1L, std::min((big + 255) / 256, (long)std::max(1, 2048 / nj)));
+      if (dt == GLSDET_F16)
+        hipLaunchKernelGGL(copy_many_kernel<f16>, dim3(per, nj), dim3(256), 0, st, a);
+      else
+        hipLaunchKernelGGL(copy_many_kernel<float>, dim3(per, nj), dim3(256), 0, st, a);
+      GLS_HIP(hipGetLastError());
+    }
     return 0;
   };
   return submit(std::move(op), stream);

@@ -588,6 +588,15 @@ class Engine:
                                             _stream_ptr(self.stream)), "resample_copy")
         return out
 
+    def copy_many(self, xs: Sequence[TView], outs: Sequence[TView]) -> List[TView]:
+        """xs[i] -> outs[i] (strided copies of equal extents, one dtype / channel count) in one launch per 32 pairs."""
+        n = len(xs)
+        assert n == len(outs) and n > 0
+        xa = (View * n)(*[x.as_c() for x in xs])
+        ya = (View * n)(*[y.as_c() for y in outs])
+        check(self.lib.glsdet_copy_many(xa, ya, n, _stream_ptr(self.stream)), "copy_many")
+        return list(outs)
+
     def nonlocal_(self, x: TView, tpg: TView, ci: int, wout: torch.Tensor, bout: torch.Tensor,
                   out: Optional[TView] = None) -> TView:
         if out is None:

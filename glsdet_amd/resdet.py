@@ -153,12 +153,13 @@ class ResDetBuilder:
         e.conv_many(list(xs), [pk(p, "theta") for p in ps], 1, 0, "none", theta)
         th = {(b, q): theta[q].image(b) for b, q in jobs}
         # dense copy of each quadrant: rows = pixels (the weight operand of the transposed projections)
-        Xq = {}
+        Xq, dense = {}, []
         for (b, q) in jobs:
             m = e.matrix(Np, C_)
             Xq[b, q] = m
             x = xs[q]
-            e.resample(xq[b, q], 1, out=TView(m.buf, 0, 1, x.h, x.w, C_, x.h * x.w * m.sw, x.w * m.sw, m.sw, m.dtype))
+            dense.append(TView(m.buf, 0, 1, x.h, x.w, C_, x.h * x.w * m.sw, x.w * m.sw, m.sw, m.dtype))
+        e.copy_many([xq[j] for j in jobs], dense)            # one launch per 32 (image, quadrant) pairs
         if assoc == "re":
             # [Phi^T ; G^T] (2ci x Np) = [Wphi ; Wg] (as pixels) x Xq^T, bias per row through the residual operand
             PG = {j: e.matrix(2 * ci, Np) for j in jobs}

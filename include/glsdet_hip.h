@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GLSDET_ABI_VERSION 11
+#define GLSDET_ABI_VERSION 12
 
 enum { GLSDET_F16 = 0, GLSDET_F32 = 1 };
 enum { GLSDET_ACT_NONE = 0, GLSDET_ACT_SILU = 1, GLSDET_ACT_RELU = 2, GLSDET_ACT_LRELU = 3,
@@ -184,6 +184,12 @@ int glsdet_channel_maxmean(const glsdet_view* x, const glsdet_view* y, void* str
 /* nearest-neighbour resample by an integer factor (1 = strided copy, 2 = nn.Upsample(2))
  * drone/models/base/yolox.py:103,181,198 ; torch.cat is realised by views, not copies.   */
 int glsdet_resample_copy(const glsdet_view* x, const glsdet_view* y, int32_t factor, void* stream);
+
+/* `count` strided copies x[i] -> y[i] (same extents per pair, one dtype and channel count per call) in one launch per 32
+ * pairs: the per-(image, quadrant) `.view(b, c, -1)` / `.permute().contiguous()` operand copies of the non-local block
+ * (drone/models/new/Non_local_family.py:32-41) when it runs on a ResNet stage, where every product is a GEMM whose
+ * second operand must be a dense matrix.                                                                    */
+int glsdet_copy_many(const glsdet_view* x, const glsdet_view* y, int32_t count, void* stream);
 
 /* ---------------------------------------------------------------------------------
  * Non-local block, dot-product form       drone/models/block/non_local/Identity_Conv.py:152-173

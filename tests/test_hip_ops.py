@@ -182,6 +182,37 @@ def test_resample(engines, mode, factor):
 
 
 @pytest.mark.parametrize("mode", ["f32", "f16"])
+@pytest.mark.parametrize("count", [1, 5, 37])
+def test_copy_many(engines, mode, count):
+    """glsdet_copy_many: `count` independent strided copies of unequal extents (37 = two launches), bit exact, nothing
+    written outside the destinations; malformed pairs refused on the host."""
+    from glsdet_amd._lib import GlsdetError
+    eng = engines[mode]
+    rng = np.random.default_rng(count)
+    srcs, dsts, refs, bigs = [], [], [], []
+    for i in range(count):
+        n, h, w = int(rng.integers(1, 3)), int(rng.integers(1, 14)), int(rng.integers(1, 19))
+        x = O.synth_input((n, 24, h, w), 10 + i)
+        refs.append(x.half().float() if mode == "f16" else x)
+        srcs.append(_to_view(eng, x, embed=(40, 8)))
+        big = eng.tensor(n, h + 2, w + 1, 64)
+        bigs.append(big)
+        dsts.append(big.window(1, h + 1, 0, w).channels(16, 40))
+    eng.copy_many(srcs, dsts)
+    torch.cuda.synchronize()
+    for i in range(count):
+        _cmp(dsts[i].to_nchw(), refs[i], 0.0, "copy_many %d" % i)
+        full = bigs[i].to_nchw()
+        h, w = refs[i].shape[2:]
+        full[:, 16:40, 1:h + 1, 0:w] = 0
+        assert float(full.abs().max()) == 0.0
+    with pytest.raises(GlsdetError):
+        eng.copy_many([srcs[0]], [eng.tensor(srcs[0].n, srcs[0].h + 1, srcs[0].w, 24)])
+    with pytest.raises(GlsdetError):
+        eng.copy_many([srcs[0]], [eng.tensor(srcs[0].n, srcs[0].h, srcs[0].w, 32)])
+
+
+@pytest.mark.parametrize("mode", ["f32", "f16"])
 @pytest.mark.parametrize("shape,ci", [((2, 16, 10, 12), 16), ((2, 32, 5, 7), 16), ((1, 64, 25, 42), 64),
                                       ((1, 384, 6, 9), 384), ((2, 200, 7, 5), 136), ((1, 72, 9, 9), 264)])
 def test_nonlocal(engines, mode, shape, ci):
