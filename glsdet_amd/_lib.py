@@ -83,6 +83,7 @@ _SIGS = {
     "glsdet_maxpool2d": (C.c_int, [C.POINTER(View), C.POINTER(View), C.c_int32, C.c_void_p]),
     "glsdet_resample_copy": (C.c_int, [C.POINTER(View), C.POINTER(View), C.c_int32, C.c_void_p]),
     "glsdet_copy_many": (C.c_int, [C.POINTER(View), C.POINTER(View), C.c_int32, C.c_void_p]),
+    "glsdet_transpose_many": (C.c_int, [C.POINTER(View), C.POINTER(View), C.c_int32, C.c_void_p]),
     "glsdet_nonlocal": (C.c_int, [C.POINTER(View), C.POINTER(View), C.c_int32, C.c_void_p, C.c_void_p,
                                   C.c_void_p, C.POINTER(View), C.c_void_p]),
     "glsdet_nonlocal_multi": (C.c_int, [C.POINTER(View), C.POINTER(View), C.c_int32, C.c_int32, C.POINTER(C.c_void_p),

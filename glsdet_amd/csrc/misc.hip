@@ -265,6 +265,42 @@ __global__ __launch_bounds__(256) void copy_many_kernel(CopyManyArgs a) {
   }
 }
 
+
+// transposed form of the same: y[i] is a dense matrix [rows = channels][cols = pixels of x[i]] (row pitch ysw), i.e. the
+// `.view(b, c, -1)` operand of the non-local products with the pixel index contiguous; 64 pixels x 64 channels per
+// workgroup through LDS.  Columns [N, ceil_vec(N)) are written as zeros, later ones are left alone.
+template <typename T>
+__global__ __launch_bounds__(256) void transpose_many_kernel(CopyManyArgs a) {
+  constexpr int VN = Vec16<T>::N;
+  constexpr int PITCH = sizeof(T) == 2 ? 66 : 65;      // 33 / 65 words per tile row: the strided reads below hit distinct banks
+  __shared__ T tile[64 * PITCH];
+  const CopyJob& jb = a.j[blockIdx.z];
+  const int N = jb.h * jb.w;
+  const int p0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+  if (p0 >= N) return;                                  // whole-workgroup exit, before any barrier
+  constexpr int CV = 64 / VN;                           // vectors per pixel row of the tile
+  for (int i = threadIdx.x; i < 64 * CV; i += 256) {
+    const int px = i / CV, cv = i % CV;
+    const int p = p0 + px, c = c0 + cv * VN;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (p < N && c < a.C) v = *reinterpret_cast<const uint4*>(jb.x + ((long)(p / jb.w) * jb.xsh + (long)(p % jb.w) * jb.xsw + c) * (long)sizeof(T));
+    const T* e = reinterpret_cast<const T*>(&v);
+#pragma unroll
+    for (int k = 0; k < VN; ++k) tile[px * PITCH + cv * VN + k] = e[k];
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 64 * CV; i += 256) {
+    const int ch = i / CV, pg = i % CV;
+    const int c = c0 + ch, p = p0 + pg * VN;
+    if (c >= a.C || p >= N) continue;
+    uint4 v;
+    T* e = reinterpret_cast<T*>(&v);
+#pragma unroll
+    for (int k = 0; k < VN; ++k) e[k] = tile[(pg * VN + k) * PITCH + ch];
+    *reinterpret_cast<uint4*>(jb.y + ((long)c * jb.ysw + p) * (long)sizeof(T)) = v;
+  }
+}
+
 // ---------------------------------------------------------------- non-local block
 // Gp[z][b][c1][c2] = sum_{j in slice z} phi[b,j,c1] * g[b,j,c2]   (16x16 block per workgroup;
 // the position range is split over blockIdx.z for parallelism, partial sums are added in a
@@ -671,6 +707,58 @@ extern "C" int glsdet_copy_many(const glsdet_view* x, const glsdet_view* y, int3
         hipLaunchKernelGGL(copy_many_kernel<f16>, dim3(per, nj), dim3(256), 0, st, a);
       else
         hipLaunchKernelGGL(copy_many_kernel<float>, dim3(per, nj), dim3(256), 0, st, a);
+      GLS_HIP(hipGetLastError());
+    }
+    return 0;
+  };
+  return submit(std::move(op), stream);
+}
+
+extern "C" int glsdet_transpose_many(const glsdet_view* x, const glsdet_view* y, int32_t count, void* stream) {
+  if (!x || !y) GLS_FAIL(GLSDET_E_ARG, "transpose_many: null argument");
+  if (count < 1 || count > 4096) GLS_FAIL(GLSDET_E_ARG, "transpose_many: 1..4096 pairs, got %d", count);
+  int rc;
+  std::vector<CopyJob> jobs((size_t)count);
+  double bytes = 0;
+  for (int i = 0; i < count; ++i) {
+    if ((rc = check_view(x[i], "transpose_many.x"))) return rc;
+    if ((rc = check_view(y[i], "transpose_many.y"))) return rc;
+    if (x[i].dtype != x[0].dtype || y[i].dtype != x[0].dtype || x[i].c != x[0].c)
+      GLS_FAIL(GLSDET_E_ARG, "transpose_many: pair %d: one dtype and one channel count per call", i);
+    const int vn = 16 / dtype_size(x[i].dtype);
+    const long N = (long)x[i].h * x[i].w;
+    if (x[i].n != 1 || y[i].n != 1 || y[i].h != 1) GLS_FAIL(GLSDET_E_ARG, "transpose_many: pair %d: one image -> one matrix [1,1,rows,cols]", i);
+    if (y[i].w < x[i].c || y[i].c < (N + vn - 1) / vn * vn)
+      GLS_FAIL(GLSDET_E_ARG, "transpose_many: pair %d: matrix %d x %d too small for %d channels x %ld pixels", i, y[i].w, y[i].c, x[i].c, N);
+    CopyJob& j = jobs[(size_t)i];
+    j.x = (const unsigned char*)x[i].base;
+    j.y = (unsigned char*)y[i].base;
+    j.xsn = x[i].sn, j.xsh = x[i].sh, j.xsw = x[i].sw, j.ysn = y[i].sn, j.ysh = y[i].sh, j.ysw = y[i].sw;
+    j.n = 1, j.h = x[i].h, j.w = x[i].w;
+    bytes += 2.0 * N * x[i].c * dtype_size(x[i].dtype);
+  }
+  if (x[0].c % 8) GLS_FAIL(GLSDET_E_ARG, "transpose_many: channels must be a multiple of 8");
+  const int C = x[0].c, dt = x[0].dtype;
+  OpRecord op;
+  op.kind = 3;
+  op.flops = 0;
+  op.bytes = bytes;
+  op.name = "transpose_many[" + std::to_string(count) + "]";
+  op.launch = [=](hipStream_t st) -> int {
+    for (int j0 = 0; j0 < count; j0 += GLS_COPY_JOBS) {
+      const int nj = std::min(GLS_COPY_JOBS, count - j0);
+      CopyManyArgs a = {};
+      long big = 0;
+      for (int i = 0; i < nj; ++i) {
+        a.j[i] = jobs[(size_t)(j0 + i)];
+        big = std::max(big, (long)a.j[i].h * a.j[i].w);
+      }
+      a.C = C;
+      const dim3 grid((unsigned)((big + 63) / 64), (unsigned)((C + 63) / 64), (unsigned)nj);
+      if (dt == GLSDET_F16)
+        hipLaunchKernelGGL(transpose_many_kernel<f16>, grid, dim3(256), 0, st, a);
+      else
+        hipLaunchKernelGGL(transpose_many_kernel<float>, grid, dim3(256), 0, st, a);
       GLS_HIP(hipGetLastError());
     }
     return 0;

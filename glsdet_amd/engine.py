@@ -597,6 +597,16 @@ class Engine:
         check(self.lib.glsdet_copy_many(xa, ya, n, _stream_ptr(self.stream)), "copy_many")
         return list(outs)
 
+    def transpose_many(self, xs: Sequence[TView], mats: Sequence[TView]) -> List[TView]:
+        """mats[i][c][p] = xs[i] at pixel p, channel c (xs[i]: one image window, mats[i]: Engine.matrix with >= C rows and
+        >= h*w columns): one launch per 32 pairs."""
+        n = len(xs)
+        assert n == len(mats) and n > 0
+        xa = (View * n)(*[x.as_c() for x in xs])
+        ya = (View * n)(*[y.as_c() for y in mats])
+        check(self.lib.glsdet_transpose_many(xa, ya, n, _stream_ptr(self.stream)), "transpose_many")
+        return list(mats)
+
     def nonlocal_(self, x: TView, tpg: TView, ci: int, wout: torch.Tensor, bout: torch.Tensor,
                   out: Optional[TView] = None) -> TView:
         if out is None:

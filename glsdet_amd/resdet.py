@@ -117,10 +117,14 @@ class ResDetBuilder:
             out = x + conv_out( (theta^T phi / N) g^T )            (dot product, divide by N, no softmax)
         Every product is a 1x1 "conv" on the MFMA conv kernels whose weight operand is an activation matrix of the
         same image (Engine.matrix / as_weight), one problem per (image, quadrant), eight problems per launch.
-        Two associations, chosen per map by their multiply count (N = pixels of a quadrant, C = channels):
-          're'  : Phi^T|G^T = [Wphi;Wg] Xq^T ; M = Phi^T G / N ; P = Wout M^T ; out = x + Theta P^T + b   (2NC^2 + C^3)
-          'dir' : S = Theta Phi^T / N ; G^T = Wg Xq^T ; Y = S G ; out = x + Y Wout^T + b                   (2N^2C + NC^2)
-        (the reference order is 'dir' with fp32 intermediates; here S / Y / M / P are stored in the engine dtype)."""
+        Three associations, chosen per map by their multiply count (N = pixels of a quadrant, C = channels, ci = inner):
+          're'   : Phi^T|G^T = [Wphi;Wg] Xq^T ; M = Phi^T G / N ; P = Wout M^T ; out = x + Theta P^T + b   (4 ci C N + ci^2 N + C ci^2)
+          'dir'  : S = Theta Phi^T / N ; G^T = Wg Xq^T ; Y = S G ; out = x + Y Wout^T + b                   (2 N^2 ci + 3 N ci C)
+          'gram' : with x' = [x ; 1] (so that every bias is a matrix column):  G' = X'^T X' / N ;
+                   Q' = (Wout Wg') G' (Wphi'^T Wtheta') ; out = x + X' Q'^T + b                             (2 C^2 N + 2 C^3)
+                   -- the two weight products are constants folded at build time, so the only per-pixel work left is the
+                   Gram matrix of the quadrant and one C x C product per pixel (no theta / phi / g projections at all).
+        (the reference order is 'dir' with fp32 intermediates; here S / Y / M / P / G' / Q' are stored in the engine dtype)."""
         e = self.e
         ci = self.sd[ps[0] + ".theta.weight"].shape[0]
         C_ = xs[0].c
@@ -130,7 +134,9 @@ class ResDetBuilder:
         Np = (max(Ns) + 7) // 8 * 8
         if assoc == "auto":
             n = max(Ns)
-            assoc = "re" if 2 * n * ci * ci + ci * ci * C_ <= 2 * n * n * ci + n * ci * C_ else "dir"
+            cost = {"re": 4 * ci * C_ * n + ci * ci * n + C_ * ci * ci, "dir": 2 * n * n * ci + 3 * n * ci * C_,
+                    "gram": 2 * (C_ + 8) * (C_ + 8) * n + 2 * C_ * (C_ + 8) * (C_ + 8)}
+            assoc = os.environ.get("GLSDET_GL_ASSOC") or min(cost, key=cost.get)
         w2 = lambda p, nm: self.sd["%s.%s.weight" % (p, nm)].float().reshape(self.sd["%s.%s.weight" % (p, nm)].shape[0], -1)
         bias = lambda p, nm: self.sd["%s.%s.bias" % (p, nm)]
         pk = lambda p, nm: self._pack("%s.%s" % (p, nm), [self._plain_part("%s.%s" % (p, nm))], C_)
@@ -148,6 +154,8 @@ class ResDetBuilder:
         jobs = [(b, q) for b in range(nimg) for q in range(len(xs))]
         xq = {(b, q): xs[q].image(b) for b, q in jobs}
         oq = {(b, q): outs[q].image(b) for b, q in jobs}
+        if assoc == "gram":
+            return self._nonlocal_gram(ps, xs, outs, jobs, xq, oq, Ns, Np)
         # theta for every (image, quadrant): a plain conv per quadrant over the whole batch
         theta = [e.tensor(x.n, x.h, x.w, ci) for x in xs]
         e.conv_many(list(xs), [pk(p, "theta") for p in ps], 1, 0, "none", theta)
@@ -205,6 +213,59 @@ class ResDetBuilder:
         # out = x + Y Wout^T + bout, written as an NHWC quadrant
         yv = [TView(m.buf, 0, 1, th[j].h, th[j].w, m.c, th[j].h * th[j].w * m.sw, th[j].w * m.sw, m.sw, m.dtype) for m, j in zip(Y, jobs)]
         e.conv_many(yv, [pk(ps[q], "conv_out") for (b, q) in jobs], 1, 0, "none", [oq[j] for j in jobs], [xq[j] for j in jobs])
+        return list(outs)
+
+    def _nonlocal_gram(self, ps, xs, outs, jobs, xq, oq, Ns, Np):
+        """The 'gram' association of nonlocal_gemm (see there).  Per (image, quadrant): two copies of the window (row-major
+        X' [N x C+8] and transposed X'^T [C+8 x N], both with the constant-one channel C preset at build time), then
+            G' = X'^T X' / N  ((C+8) x (C+8), contraction over the pixels),   T = A G',   Q' = T B,
+            out = x + X' Q'^T + bout
+        with the constants A = Wout [Wg | bg] (C x C+8) and B = [Wphi | bphi]^T [Wtheta | btheta] ((C+8) x (C+8)) folded
+        on the host in float64."""
+        e = self.e
+        C_ = xs[0].c
+        Ca = C_ + 8
+        tdt = torch.float16 if e.dt == 0 else torch.float32
+
+        def aug(p, nm):                               # [W | b | 0...]  (ci x Ca), float64
+            w = self.sd["%s.%s.weight" % (p, nm)].double().reshape(self.sd["%s.%s.weight" % (p, nm)].shape[0], -1)
+            out = torch.zeros(w.shape[0], Ca, dtype=torch.float64)
+            out[:, :C_] = w
+            out[:, C_] = self.sd["%s.%s.bias" % (p, nm)].double()
+            return out
+
+        def consts(p):
+            k = ("gramconst", p)
+            if k not in self._packed:
+                wout = self.sd[p + ".conv_out.weight"].double().reshape(C_, -1)
+                A = (wout @ aug(p, "g")).float()                                         # C x Ca
+                Bt = (aug(p, "theta").t() @ aug(p, "phi")).float()                       # B^T: Ca x Ca
+                self._packed[k] = (self._wmat(p + ".gramA", A),
+                                   e.pack_conv([(Bt.reshape(Ca, Ca, 1, 1), torch.ones(Ca), torch.zeros(Ca))], Ca))
+            return self._packed[k]
+        Xr, Xt, dense = {}, {}, []
+        for (b, q) in jobs:
+            x, n = xs[q], Ns[q]
+            m = e.matrix(Np, Ca)
+            m.buf.view(tdt)[: Np * m.sw].view(Np, m.sw)[:n, C_] = 1.0
+            t = e.matrix(Ca, Np)
+            t.buf.view(tdt)[C_ * t.sw: C_ * t.sw + n] = 1.0
+            Xr[b, q], Xt[b, q] = m, t
+            dense.append(TView(m.buf, 0, 1, x.h, x.w, C_, x.h * x.w * m.sw, x.w * m.sw, m.sw, m.dtype))
+        e.copy_many([xq[j] for j in jobs], dense)
+        e.transpose_many([xq[j] for j in jobs], [Xt[j] for j in jobs])
+        G = {j: e.matrix(Ca, Ca) for j in jobs}
+        e.conv_many([Xt[j] for j in jobs], [e.as_weight(Xt[b, q], alpha=1.0 / Ns[q]) for (b, q) in jobs], 1, 0, "none",
+                    [G[j] for j in jobs])
+        T = {j: e.matrix(C_, Ca) for j in jobs}
+        e.conv_many([consts(ps[q])[0] for (b, q) in jobs], [e.as_weight(G[j]) for j in jobs], 1, 0, "none", [T[j] for j in jobs])
+        Q = {j: e.matrix(C_, Ca) for j in jobs}
+        e.conv_many([T[j] for j in jobs], [consts(ps[q])[1] for (b, q) in jobs], 1, 0, "none", [Q[j] for j in jobs])
+        bias = lambda p: self.sd[p + ".conv_out.bias"]
+        xa = [TView(Xr[b, q].buf, 0, 1, xs[q].h, xs[q].w, Ca, xs[q].h * xs[q].w * Xr[b, q].sw, xs[q].w * Xr[b, q].sw, Xr[b, q].sw,
+                    Xr[b, q].dtype) for (b, q) in jobs]
+        e.conv_many(xa, [e.as_weight(Q[b, q], bias=bias(ps[q])) for (b, q) in jobs], 1, 0, "none",
+                    [oq[j] for j in jobs], [xq[j] for j in jobs])
         return list(outs)
 
     def gl_fusion(self, p: str, x: TView, assoc: str = "auto") -> TView:

@@ -191,6 +191,12 @@ int glsdet_resample_copy(const glsdet_view* x, const glsdet_view* y, int32_t fac
  * second operand must be a dense matrix.                                                                    */
 int glsdet_copy_many(const glsdet_view* x, const glsdet_view* y, int32_t count, void* stream);
 
+/* The transposed form: x[i] is ONE image window [1,h,w,C], y[i] a dense matrix view [1,1,rows >= C, cols >= ceil8(h*w)]
+ * (row pitch y[i].sw); y[i][c][p] = x[i][p / w][p % w][c].  This is `x.view(b, c, -1)` (Non_local_family.py:33-39) for
+ * NHWC storage: the operand of the products that contract over the pixels (X^T X).  Columns beyond the pixels, rows
+ * beyond C are left as they are.                                                                            */
+int glsdet_transpose_many(const glsdet_view* x, const glsdet_view* y, int32_t count, void* stream);
+
 /* ---------------------------------------------------------------------------------
  * Non-local block, dot-product form       drone/models/block/non_local/Identity_Conv.py:152-173
  *   out = x + Wout * ( (theta^T phi / N) g^T ) + bout      (NO softmax, divide by N)

@@ -213,6 +213,44 @@ def test_copy_many(engines, mode, count):
 
 
 @pytest.mark.parametrize("mode", ["f32", "f16"])
+@pytest.mark.parametrize("count", [1, 6, 35])
+def test_transpose_many(engines, mode, count):
+    """glsdet_transpose_many: window [1,h,w,C] -> matrix[c][pixel], bit exact; rows beyond C and columns beyond the
+    pixels keep what they held (a preset ones row survives); too small a matrix is refused."""
+    from glsdet_amd._lib import GlsdetError
+    eng = engines[mode]
+    rng = np.random.default_rng(100 + count)
+    srcs, mats, refs = [], [], []
+    tdt = torch.float16 if mode == "f16" else torch.float32
+    for i in range(count):
+        h, w = int(rng.integers(1, 15)), int(rng.integers(1, 23))
+        c = 72
+        x = O.synth_input((1, c, h, w), 30 + i)
+        refs.append(x.half().float() if mode == "f16" else x)
+        srcs.append(_to_view(eng, x, embed=(96, 8)))
+        m = eng.matrix(c + 8, (h * w + 7) // 8 * 8 + 8)
+        m.buf.view(tdt)[c * m.sw: c * m.sw + h * w] = 1.0                 # the ones row of the augmented operand
+        mats.append(m)
+    for s_, m in zip(srcs, mats):
+        assert s_.c == 72
+    eng.transpose_many(srcs, mats)
+    torch.cuda.synchronize()
+    for i in range(count):
+        m, r = mats[i], refs[i]
+        n = r.shape[2] * r.shape[3]
+        full = m.buf.view(tdt)[: (72 + 8) * m.sw].view(72 + 8, m.sw).float().cpu()
+        assert torch.equal(full[:72, :n], r[0].reshape(72, n)), i
+        assert float(full[:72, n:].abs().max()) == 0.0
+        assert torch.equal(full[72, :n], torch.ones(n)) and float(full[72, n:].abs().max()) == 0.0
+        assert float(full[73:].abs().max()) == 0.0
+    with pytest.raises(GlsdetError):
+        eng.transpose_many([srcs[0]], [eng.matrix(64, srcs[0].h * srcs[0].w + 8)])
+    wide = _to_view(eng, O.synth_input((1, 72, 4, 8), 1))
+    with pytest.raises(GlsdetError):
+        eng.transpose_many([wide], [eng.matrix(80, 24)])                    # 32 pixels need 32 columns
+
+
+@pytest.mark.parametrize("mode", ["f32", "f16"])
 @pytest.mark.parametrize("shape,ci", [((2, 16, 10, 12), 16), ((2, 32, 5, 7), 16), ((1, 64, 25, 42), 64),
                                       ((1, 384, 6, 9), 384), ((2, 200, 7, 5), 136), ((1, 72, 9, 9), 264)])
 def test_nonlocal(engines, mode, shape, ci):
