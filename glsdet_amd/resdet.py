@@ -27,6 +27,11 @@ import torch
 from . import _lib
 from .engine import Engine, F32, TView, fold_bn
 
+# Width of the augmentation of the folded non-local associations ('gram' / 'pair': x' = [x ; 1 ; 0...], "C+a" in the comments
+# below).  One channel would do; 64 keeps the contraction length C+a a whole number of the conv kernels' 128-byte K steps
+# (their tail-free form).  Measured on config 3 as named (8 x 800 x 1344, one box): a = 8 / 32 / 64 -> 961 / 972 / 982 img/s.
+GL_AUG = int(os.environ.get("GLSDET_GL_AUG", "64"))
+
 RESNET_BN_EPS = 1e-5
 GN_EPS = 1e-5
 STAGE_BLOCKS = {50: (3, 4, 6, 3), 101: (3, 4, 23, 3)}
@@ -124,7 +129,11 @@ class ResDetBuilder:
                    Q' = (Wout Wg') G' (Wphi'^T Wtheta') ; out = x + X' Q'^T + b                             (2 C^2 N + 2 C^3)
                    -- the two weight products are constants folded at build time, so the only per-pixel work left is the
                    Gram matrix of the quadrant and one C x C product per pixel (no theta / phi / g projections at all).
-        (the reference order is 'dir' with fp32 intermediates; here S / Y / M / P / G' / Q' are stored in the engine dtype)."""
+          'pair' : S = X' (Wtheta'^T Wphi') X'^T / N  (the N x N pair matrix straight from the window) ;
+                   out = x + S (X' (Wout Wg')^T) + b                                                        (2 N C^2 + 2 N^2 C)
+                   -- 'dir' with theta/phi and g/conv_out folded pairwise at build time: four products instead of six.
+        (the reference order is 'dir' with fp32 intermediates; here S / Y / M / P / G' / Q' / U / V are stored in the engine
+        dtype)."""
         e = self.e
         ci = self.sd[ps[0] + ".theta.weight"].shape[0]
         C_ = xs[0].c
@@ -135,7 +144,8 @@ class ResDetBuilder:
         if assoc == "auto":
             n = max(Ns)
             cost = {"re": 4 * ci * C_ * n + ci * ci * n + C_ * ci * ci, "dir": 2 * n * n * ci + 3 * n * ci * C_,
-                    "gram": 2 * (C_ + 8) * (C_ + 8) * n + 2 * C_ * (C_ + 8) * (C_ + 8)}
+                    "gram": 2 * (C_ + GL_AUG) * (C_ + GL_AUG) * n + 2 * C_ * (C_ + GL_AUG) * (C_ + GL_AUG),
+                    "pair": n * (C_ + GL_AUG) * (C_ + GL_AUG) + 2 * n * n * (C_ + GL_AUG) + C_ * n * (C_ + GL_AUG)}
             assoc = os.environ.get("GLSDET_GL_ASSOC") or min(cost, key=cost.get)
         w2 = lambda p, nm: self.sd["%s.%s.weight" % (p, nm)].float().reshape(self.sd["%s.%s.weight" % (p, nm)].shape[0], -1)
         bias = lambda p, nm: self.sd["%s.%s.bias" % (p, nm)]
@@ -154,8 +164,9 @@ class ResDetBuilder:
         jobs = [(b, q) for b in range(nimg) for q in range(len(xs))]
         xq = {(b, q): xs[q].image(b) for b, q in jobs}
         oq = {(b, q): outs[q].image(b) for b, q in jobs}
-        if assoc == "gram":
-            return self._nonlocal_gram(ps, xs, outs, jobs, xq, oq, Ns, Np)
+        if assoc in ("gram", "pair"):            # the pixel count is a contraction length there: whole 64-byte K steps as well
+            np32 = (max(Ns) + 31) // 32 * 32
+            return (self._nonlocal_gram if assoc == "gram" else self._nonlocal_pair)(ps, xs, outs, jobs, xq, oq, Ns, np32)
         # theta for every (image, quadrant): a plain conv per quadrant over the whole batch
         theta = [e.tensor(x.n, x.h, x.w, ci) for x in xs]
         e.conv_many(list(xs), [pk(p, "theta") for p in ps], 1, 0, "none", theta)
@@ -215,44 +226,86 @@ class ResDetBuilder:
         e.conv_many(yv, [pk(ps[q], "conv_out") for (b, q) in jobs], 1, 0, "none", [oq[j] for j in jobs], [xq[j] for j in jobs])
         return list(outs)
 
+    def _gl_consts(self, p: str, C_: int):
+        """Build-time constants of the folded associations of one non-local block (float64 on the host), with
+        W' = [W | b | 0...] (ci x C+a):  A = Wout Wg' (C x C+a) as an activation matrix;  B = Wphi'^T Wtheta' ((C+a) x (C+a))
+        as conv weights in both orientations.  -> (A matrix, pack of B^T [out = T B], pack of B [out = X' (Wtheta'^T Wphi')])"""
+        e = self.e
+        Ca = C_ + GL_AUG
+        k = ("glconst", p)
+        if k not in self._packed:
+            def aug(nm):
+                w = self.sd["%s.%s.weight" % (p, nm)].double().reshape(self.sd["%s.%s.weight" % (p, nm)].shape[0], -1)
+                out = torch.zeros(w.shape[0], Ca, dtype=torch.float64)
+                out[:, :C_] = w
+                out[:, C_] = self.sd["%s.%s.bias" % (p, nm)].double()
+                return out
+            wout = self.sd[p + ".conv_out.weight"].double().reshape(C_, -1)
+            A = (wout @ aug("g")).float()                                            # C x Ca
+            B = (aug("phi").t() @ aug("theta")).float()                              # Ca x Ca
+            one, zero = torch.ones(Ca), torch.zeros(Ca)
+            self._packed[k] = (self._wmat(p + ".glA", A),
+                               e.pack_conv([(B.t().contiguous().reshape(Ca, Ca, 1, 1), one, zero)], Ca),
+                               e.pack_conv([(B.contiguous().reshape(Ca, Ca, 1, 1), one, zero)], Ca))
+        return self._packed[k]
+
+    def _gl_dense(self, xs, jobs, xq, Ns, Np):
+        """Row-major dense copies X' [Np x C+a] of the (image, quadrant) windows, channel C preset to one on the valid rows."""
+        e = self.e
+        C_ = xs[0].c
+        tdt = torch.float16 if e.dt == 0 else torch.float32
+        Xr, dense = {}, []
+        for (b, q) in jobs:
+            x, n = xs[q], Ns[q]
+            m = e.matrix(Np, C_ + GL_AUG)
+            m.buf.view(tdt)[: Np * m.sw].view(Np, m.sw)[:n, C_] = 1.0
+            Xr[b, q] = m
+            dense.append(TView(m.buf, 0, 1, x.h, x.w, C_, x.h * x.w * m.sw, x.w * m.sw, m.sw, m.dtype))
+        e.copy_many([xq[j] for j in jobs], dense)
+        return Xr
+
+    def _nonlocal_pair(self, ps, xs, outs, jobs, xq, oq, Ns, Np):
+        """The 'pair' association of nonlocal_gemm (see there).  Per (image, quadrant), X' = the window with a ones channel:
+            U = X' (Wtheta'^T Wphi')   (N x C+a)        S = U X'^T / N   (N x N: theta_i . phi_j / N)
+            V^T = (Wout Wg') X'^T      (C x N)          out = x + S V + bout"""
+        e = self.e
+        C_ = xs[0].c
+        Ca = C_ + GL_AUG
+        Xr = self._gl_dense(xs, jobs, xq, Ns, Np)
+        act = lambda m, n: TView(m.buf, 0, 1, 1, n, m.c, n * m.sw, n * m.sw, m.sw, m.dtype)       # the first n rows as pixels
+        U = {j: e.matrix(Np, Ca) for j in jobs}
+        e.conv_many([act(Xr[j], Ns[j[1]]) for j in jobs], [self._gl_consts(ps[q], C_)[2] for (b, q) in jobs], 1, 0, "none",
+                    [act(U[j], Ns[j[1]]) for j in jobs])
+        S = {(b, q): e.matrix(Ns[q], Np) for (b, q) in jobs}
+        e.conv_many([act(U[j], Ns[j[1]]) for j in jobs], [e.as_weight(Xr[b, q], alpha=1.0 / Ns[q]) for (b, q) in jobs], 1, 0, "none",
+                    [S[j] for j in jobs])
+        VT = {j: e.matrix(C_, Np) for j in jobs}
+        e.conv_many([self._gl_consts(ps[q], C_)[0] for (b, q) in jobs], [e.as_weight(Xr[j]) for j in jobs], 1, 0, "none",
+                    [VT[j] for j in jobs])
+        sv = [TView(S[b, q].buf, 0, 1, xs[q].h, xs[q].w, S[b, q].c, xs[q].h * xs[q].w * S[b, q].sw, xs[q].w * S[b, q].sw, S[b, q].sw,
+                    S[b, q].dtype) for (b, q) in jobs]
+        e.conv_many(sv, [e.as_weight(VT[b, q], bias=self.sd[ps[q] + ".conv_out.bias"]) for (b, q) in jobs], 1, 0, "none",
+                    [oq[j] for j in jobs], [xq[j] for j in jobs])
+        return list(outs)
+
     def _nonlocal_gram(self, ps, xs, outs, jobs, xq, oq, Ns, Np):
         """The 'gram' association of nonlocal_gemm (see there).  Per (image, quadrant): two copies of the window (row-major
-        X' [N x C+8] and transposed X'^T [C+8 x N], both with the constant-one channel C preset at build time), then
-            G' = X'^T X' / N  ((C+8) x (C+8), contraction over the pixels),   T = A G',   Q' = T B,
+        X' [N x C+a] and transposed X'^T [C+a x N], both with the constant-one channel C preset at build time), then
+            G' = X'^T X' / N  ((C+a) x (C+a), contraction over the pixels),   T = A G',   Q' = T B,
             out = x + X' Q'^T + bout
-        with the constants A = Wout [Wg | bg] (C x C+8) and B = [Wphi | bphi]^T [Wtheta | btheta] ((C+8) x (C+8)) folded
+        with the constants A = Wout [Wg | bg] (C x C+a) and B = [Wphi | bphi]^T [Wtheta | btheta] ((C+a) x (C+a)) folded
         on the host in float64."""
         e = self.e
         C_ = xs[0].c
-        Ca = C_ + 8
+        Ca = C_ + GL_AUG
         tdt = torch.float16 if e.dt == 0 else torch.float32
-
-        def aug(p, nm):                               # [W | b | 0...]  (ci x Ca), float64
-            w = self.sd["%s.%s.weight" % (p, nm)].double().reshape(self.sd["%s.%s.weight" % (p, nm)].shape[0], -1)
-            out = torch.zeros(w.shape[0], Ca, dtype=torch.float64)
-            out[:, :C_] = w
-            out[:, C_] = self.sd["%s.%s.bias" % (p, nm)].double()
-            return out
-
-        def consts(p):
-            k = ("gramconst", p)
-            if k not in self._packed:
-                wout = self.sd[p + ".conv_out.weight"].double().reshape(C_, -1)
-                A = (wout @ aug(p, "g")).float()                                         # C x Ca
-                Bt = (aug(p, "theta").t() @ aug(p, "phi")).float()                       # B^T: Ca x Ca
-                self._packed[k] = (self._wmat(p + ".gramA", A),
-                                   e.pack_conv([(Bt.reshape(Ca, Ca, 1, 1), torch.ones(Ca), torch.zeros(Ca))], Ca))
-            return self._packed[k]
-        Xr, Xt, dense = {}, {}, []
+        consts = lambda p: self._gl_consts(p, C_)
+        Xr = self._gl_dense(xs, jobs, xq, Ns, Np)
+        Xt = {}
         for (b, q) in jobs:
-            x, n = xs[q], Ns[q]
-            m = e.matrix(Np, Ca)
-            m.buf.view(tdt)[: Np * m.sw].view(Np, m.sw)[:n, C_] = 1.0
             t = e.matrix(Ca, Np)
-            t.buf.view(tdt)[C_ * t.sw: C_ * t.sw + n] = 1.0
-            Xr[b, q], Xt[b, q] = m, t
-            dense.append(TView(m.buf, 0, 1, x.h, x.w, C_, x.h * x.w * m.sw, x.w * m.sw, m.sw, m.dtype))
-        e.copy_many([xq[j] for j in jobs], dense)
+            t.buf.view(tdt)[C_ * t.sw: C_ * t.sw + Ns[q]] = 1.0
+            Xt[b, q] = t
         e.transpose_many([xq[j] for j in jobs], [Xt[j] for j in jobs])
         G = {j: e.matrix(Ca, Ca) for j in jobs}
         e.conv_many([Xt[j] for j in jobs], [e.as_weight(Xt[b, q], alpha=1.0 / Ns[q]) for (b, q) in jobs], 1, 0, "none",

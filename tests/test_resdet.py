@@ -613,7 +613,7 @@ def test_gl_fusion_config_builds_and_oracle_composes():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("mode", ["f32", "f16"])
-@pytest.mark.parametrize("assoc", ["re", "dir", "gram"])
+@pytest.mark.parametrize("assoc", ["re", "dir", "gram", "pair"])
 @pytest.mark.parametrize("c,hw,cat", [(64, (12, 16), "linear"), (128, (13, 21), "linear"), (512, (9, 10), "non_linear")])
 def test_gl_fusion_plugin_vs_oracle(engines, mode, assoc, c, hw, cat):
     """x + Patch_Conv_NonLocal_new(x) at ResNet-like widths through the GEMM lowering of the non-local block, both
