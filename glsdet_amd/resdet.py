@@ -165,7 +165,7 @@ class ResDetBuilder:
         xq = {(b, q): xs[q].image(b) for b, q in jobs}
         oq = {(b, q): outs[q].image(b) for b, q in jobs}
         if assoc in ("gram", "pair"):            # the pixel count is a contraction length there: whole 64-byte K steps as well
-            np32 = (max(Ns) + 31) // 32 * 32
+            np32 = (max(Ns) + 31) // 32 * 32          # (64 measured the same)
             return (self._nonlocal_gram if assoc == "gram" else self._nonlocal_pair)(ps, xs, outs, jobs, xq, oq, Ns, np32)
         # theta for every (image, quadrant): a plain conv per quadrant over the whole batch
         theta = [e.tensor(x.n, x.h, x.w, ci) for x in xs]
