@@ -408,12 +408,27 @@ class Engine:
         buf = self.raw(rp * pitch * _ESIZE[dt])
         return TView(buf, 0, 1, 1, rows, c8, rows * pitch, rows * pitch, pitch, dt)
 
-    def as_weight(self, m: TView, alpha: float = 1.0, bias: Optional[torch.Tensor] = None):
+    def bias_vector(self, n: int) -> TView:
+        """fp32 vector of n entries (zero filled, padded to the weight row granule) that a 1-pixel conv of the plan writes
+        and a later conv reads as its per-channel bias (as_weight(bias_dev=)): -> view [1, 1, 1, n]."""
+        cpad = self.lib.glsdet_conv_cout_pad(ceil_to(n, 8))
+        buf = self.raw(cpad * 4)
+        return TView(buf, 0, 1, 1, 1, ceil_to(n, 8), cpad, cpad, cpad, F32)
+
+    def as_weight(self, m: TView, alpha: float = 1.0, bias: Optional[torch.Tensor] = None, bias_dev: Optional[TView] = None):
         """`packed` tuple for Engine.conv whose weight operand is the activation matrix m (Engine.matrix layout):
-        out[pixel][r] = alpha * sum_k x[pixel][k] * m[r][k] (+ bias[r])."""
+        out[pixel][r] = alpha * sum_k x[pixel][k] * m[r][k] (+ bias[r]).  bias: host constant; bias_dev: an fp32 vector an
+        earlier op of the plan writes (Engine.bias_vector)."""
         rows = m.h * m.w
         assert m.n == 1 and m.sw == self.lib.glsdet_conv_kpad(1, 1, m.c, m.dtype), "as_weight needs an Engine.matrix view"
         cpad = self.lib.glsdet_conv_cout_pad(ceil_to(rows, 8))
+        if bias_dev is not None:
+            assert bias is None and bias_dev.dtype == F32 and bias_dev.sw >= cpad, "bias_dev: Engine.bias_vector of >= cout_pad floats"
+            key = ("vec", cpad, float(alpha))
+            if key not in self._vecs:
+                self._vecs[key] = (self.upload(torch.full((cpad,), float(alpha))), self.upload(torch.zeros(cpad)))
+            return (_Ptr(m.buf.data_ptr() + m.off * _ESIZE[m.dtype]), self._vecs[key][0],
+                    _Ptr(bias_dev.buf.data_ptr() + bias_dev.off * _ESIZE[F32]), ceil_to(rows, 8), 1, 1)
         key = ("vec", cpad, float(alpha))
         if key not in self._vecs:
             self._vecs[key] = (self.upload(torch.full((cpad,), float(alpha))), self.upload(torch.zeros(cpad)))

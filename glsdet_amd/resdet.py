@@ -116,7 +116,23 @@ class ResDetBuilder:
             self._packed[key] = m
         return self._packed[key]
 
-    def nonlocal_gemm(self, ps: Sequence[str], xs: Sequence[TView], outs: Sequence[TView], assoc: str = "auto"):
+    @staticmethod
+    def gl_assoc(assoc: str, ci: int, C_: int, n: int) -> str:
+        """The association nonlocal_gemm uses for quadrants of n pixels ('auto': the fewest multiplies; GLSDET_GL_ASSOC
+        overrides)."""
+        if assoc != "auto":
+            return assoc
+        Ca = C_ + GL_AUG
+        cost = {"re": 4 * ci * C_ * n + ci * ci * n + C_ * ci * ci, "dir": 2 * n * n * ci + 3 * n * ci * C_,
+                "gram": Ca * Ca * n + C_ * Ca * Ca + C_ * C_ * Ca + n * C_ * C_,
+                "pair": n * Ca * Ca + 2 * n * n * Ca + C_ * n * Ca}
+        if n < 2 * C_:
+            # 'gram' pays two C^3 products and a bias product per window: by the multiply count it ties with 'pair' around
+            # n = C, measured (config 3 as named, 50 x 84 level: C = 1024, n = 1050) it is 1006 us against 927
+            del cost["gram"]
+        return os.environ.get("GLSDET_GL_ASSOC") or min(cost, key=cost.get)
+
+    def nonlocal_gemm(self, ps: Sequence[str], xs: Sequence[TView], outs: Sequence[TView], assoc: str = "auto", fold=None):
         """Non_local_Block (drone/models/new/Non_local_family.py:6-50) at ResNet widths (C = 512...2048), for the
         quadrants `xs` (views with the batch in n) of ONE feature map, written to `outs`:
             out = x + conv_out( (theta^T phi / N) g^T )            (dot product, divide by N, no softmax)
@@ -141,12 +157,8 @@ class ResDetBuilder:
         nimg = xs[0].n
         Ns = [x.h * x.w for x in xs]
         Np = (max(Ns) + 7) // 8 * 8
-        if assoc == "auto":
-            n = max(Ns)
-            cost = {"re": 4 * ci * C_ * n + ci * ci * n + C_ * ci * ci, "dir": 2 * n * n * ci + 3 * n * ci * C_,
-                    "gram": 2 * (C_ + GL_AUG) * (C_ + GL_AUG) * n + 2 * C_ * (C_ + GL_AUG) * (C_ + GL_AUG),
-                    "pair": n * (C_ + GL_AUG) * (C_ + GL_AUG) + 2 * n * n * (C_ + GL_AUG) + C_ * n * (C_ + GL_AUG)}
-            assoc = os.environ.get("GLSDET_GL_ASSOC") or min(cost, key=cost.get)
+        assoc = self.gl_assoc(assoc, ci, C_, max(Ns))
+        assert fold is None or assoc == "gram", "only the 'gram' association takes the channel_conv in"
         w2 = lambda p, nm: self.sd["%s.%s.weight" % (p, nm)].float().reshape(self.sd["%s.%s.weight" % (p, nm)].shape[0], -1)
         bias = lambda p, nm: self.sd["%s.%s.bias" % (p, nm)]
         pk = lambda p, nm: self._pack("%s.%s" % (p, nm), [self._plain_part("%s.%s" % (p, nm))], C_)
@@ -166,7 +178,9 @@ class ResDetBuilder:
         oq = {(b, q): outs[q].image(b) for b, q in jobs}
         if assoc in ("gram", "pair"):            # the pixel count is a contraction length there: whole 64-byte K steps as well
             np32 = (max(Ns) + 31) // 32 * 32          # (64 measured the same)
-            return (self._nonlocal_gram if assoc == "gram" else self._nonlocal_pair)(ps, xs, outs, jobs, xq, oq, Ns, np32)
+            if assoc == "gram":
+                return self._nonlocal_gram(ps, xs, outs, jobs, xq, oq, Ns, np32, fold)
+            return self._nonlocal_pair(ps, xs, outs, jobs, xq, oq, Ns, np32)
         # theta for every (image, quadrant): a plain conv per quadrant over the whole batch
         theta = [e.tensor(x.n, x.h, x.w, ci) for x in xs]
         e.conv_many(list(xs), [pk(p, "theta") for p in ps], 1, 0, "none", theta)
@@ -229,7 +243,8 @@ class ResDetBuilder:
     def _gl_consts(self, p: str, C_: int):
         """Build-time constants of the folded associations of one non-local block (float64 on the host), with
         W' = [W | b | 0...] (ci x C+a):  A = Wout Wg' (C x C+a) as an activation matrix;  B = Wphi'^T Wtheta' ((C+a) x (C+a))
-        as conv weights in both orientations.  -> (A matrix, pack of B^T [out = T B], pack of B [out = X' (Wtheta'^T Wphi')])"""
+        as conv weights in both orientations.  -> (A matrix, pack of B^T [out = T B], pack of B [out = X' (Wtheta'^T Wphi')],
+        B^T as an activation matrix, pack of the first C rows of B^T [out = T B[:, :C]])"""
         e = self.e
         Ca = C_ + GL_AUG
         k = ("glconst", p)
@@ -244,9 +259,12 @@ class ResDetBuilder:
             A = (wout @ aug("g")).float()                                            # C x Ca
             B = (aug("phi").t() @ aug("theta")).float()                              # Ca x Ca
             one, zero = torch.ones(Ca), torch.zeros(Ca)
+            Bt = B.t().contiguous()
             self._packed[k] = (self._wmat(p + ".glA", A),
-                               e.pack_conv([(B.t().contiguous().reshape(Ca, Ca, 1, 1), one, zero)], Ca),
-                               e.pack_conv([(B.contiguous().reshape(Ca, Ca, 1, 1), one, zero)], Ca))
+                               e.pack_conv([(Bt.reshape(Ca, Ca, 1, 1), one, zero)], Ca),
+                               e.pack_conv([(B.contiguous().reshape(Ca, Ca, 1, 1), one, zero)], Ca),
+                               self._wmat(p + ".glBt", Bt),                                      # B^T as an activation matrix
+                               e.pack_conv([(Bt[:C_].reshape(C_, Ca, 1, 1), torch.ones(C_), torch.zeros(C_))], Ca))   # Q'[:, :C] = T B[:, :C]
         return self._packed[k]
 
     def _gl_dense(self, xs, jobs, xq, Ns, Np):
@@ -288,19 +306,24 @@ class ResDetBuilder:
                     [oq[j] for j in jobs], [xq[j] for j in jobs])
         return list(outs)
 
-    def _nonlocal_gram(self, ps, xs, outs, jobs, xq, oq, Ns, Np):
-        """The 'gram' association of nonlocal_gemm (see there).  Per (image, quadrant): two copies of the window (row-major
-        X' [N x C+a] and transposed X'^T [C+a x N], both with the constant-one channel C preset at build time), then
-            G' = X'^T X' / N  ((C+a) x (C+a), contraction over the pixels),   T = A G',   Q' = T B,
-            out = x + X' Q'^T + bout
+    def _nonlocal_gram(self, ps, xs, outs, jobs, xq, oq, Ns, Np, fold=None):
+        """The 'gram' association of nonlocal_gemm (see there).  Per (image, quadrant): the transposed copy X'^T [C+a x N] of the
+        window (the constant-one channel C preset at build time), then
+            G' = X'^T X' / N  ((C+a) x (C+a), contraction over the pixels),   T = A G'  (C x C+a),
+            Qm = T B[:, :C]  (C x C),   d = T B[:, C] + bout  (fp32 vector),   out = x + x Qm^T + d
         with the constants A = Wout [Wg | bg] (C x C+a) and B = [Wphi | bphi]^T [Wtheta | btheta] ((C+a) x (C+a)) folded
-        on the host in float64."""
+        on the host in float64: the per-pixel product contracts over exactly C channels of the window where it lies (no
+        row-major copy), its bias is a vector a 1-pixel product of the plan writes.
+        fold = (key, Wc [C x C], bc [C]): gl_fusion's linear channel_conv and its residual taken in as well,
+            x + Wc (x + x Qm^T + d) + bc = x + x Qm2^T + d2,   Qm2 = Wc Qm + Wc,   d2 = Wc (T B[:, C] + bout) + bc
+        -- one more C^3 product per window instead of a C x C product per pixel of the map."""
         e = self.e
         C_ = xs[0].c
         Ca = C_ + GL_AUG
         tdt = torch.float16 if e.dt == 0 else torch.float32
+        rows = lambda m, r0, r1: TView(m.buf, m.off + r0 * m.sw, 1, 1, r1 - r0, m.c, (r1 - r0) * m.sw, (r1 - r0) * m.sw, m.sw, m.dtype)
         consts = lambda p: self._gl_consts(p, C_)
-        Xr = self._gl_dense(xs, jobs, xq, Ns, Np)
+        bout = lambda p: self.sd[p + ".conv_out.bias"]
         Xt = {}
         for (b, q) in jobs:
             t = e.matrix(Ca, Np)
@@ -312,16 +335,31 @@ class ResDetBuilder:
                     [G[j] for j in jobs])
         T = {j: e.matrix(C_, Ca) for j in jobs}
         e.conv_many([consts(ps[q])[0] for (b, q) in jobs], [e.as_weight(G[j]) for j in jobs], 1, 0, "none", [T[j] for j in jobs])
-        Q = {j: e.matrix(C_, Ca) for j in jobs}
-        e.conv_many([T[j] for j in jobs], [consts(ps[q])[1] for (b, q) in jobs], 1, 0, "none", [Q[j] for j in jobs])
-        bias = lambda p: self.sd[p + ".conv_out.bias"]
-        xa = [TView(Xr[b, q].buf, 0, 1, xs[q].h, xs[q].w, Ca, xs[q].h * xs[q].w * Xr[b, q].sw, xs[q].w * Xr[b, q].sw, Xr[b, q].sw,
-                    Xr[b, q].dtype) for (b, q) in jobs]
-        e.conv_many(xa, [e.as_weight(Q[b, q], bias=bias(ps[q])) for (b, q) in jobs], 1, 0, "none",
+        Qm = {j: e.matrix(C_, C_) for j in jobs}
+        d = {j: e.bias_vector(C_) for j in jobs}
+        if fold is None:
+            e.conv_many([T[j] for j in jobs], [consts(ps[q])[4] for (b, q) in jobs], 1, 0, "none", [Qm[j] for j in jobs])
+            e.conv_many([rows(consts(ps[q])[3], C_, C_ + 1) for (b, q) in jobs],
+                        [e.as_weight(T[b, q], bias=bout(ps[q])) for (b, q) in jobs], 1, 0, "none", [d[j] for j in jobs])
+        else:
+            key, Wc, bc = fold
+            WcM = self._wmat(key + ".WcM", Wc.float())
+            # Q'^T (rows 0..C: the C columns of Qm and the bias column) = B^T T^T
+            QT = {j: e.matrix(C_ + 8, C_) for j in jobs}
+            e.conv_many([rows(consts(ps[q])[3], 0, C_ + 8) for (b, q) in jobs], [e.as_weight(T[j]) for j in jobs], 1, 0, "none",
+                        [QT[j] for j in jobs])
+            e.conv_many([WcM for _ in jobs], [e.as_weight(rows(QT[j], 0, C_)) for j in jobs], 1, 0, "none",
+                        [Qm[j] for j in jobs], [WcM for _ in jobs])
+            pkd = {}
+            for q, p in enumerate(ps):
+                b2 = Wc.double() @ bout(p).double() + bc.double()
+                pkd[q] = self._pack(key + ".d2.%d" % q, [(Wc.float().reshape(C_, C_, 1, 1), torch.ones(C_), b2.float())], C_)
+            e.conv_many([rows(QT[j], C_, C_ + 1) for j in jobs], [pkd[q] for (b, q) in jobs], 1, 0, "none", [d[j] for j in jobs])
+        e.conv_many([xq[j] for j in jobs], [e.as_weight(Qm[j], bias_dev=d[j]) for j in jobs], 1, 0, "none",
                     [oq[j] for j in jobs], [xq[j] for j in jobs])
         return list(outs)
 
-    def gl_fusion(self, p: str, x: TView, assoc: str = "auto") -> TView:
+    def gl_fusion(self, p: str, x: TView, assoc: str = "auto", fold="auto") -> TView:
         """x + Patch_Conv_NonLocal_new(x)  (drone/models/new/yolox10.py:262-266 applied to a ResNet stage output;
         Non_local_family.py:208-252): quadrant non-local blocks at the input resolution, re-stitch (free: the
         blocks write their windows of one buffer), channel_conv, residual."""
@@ -330,7 +368,18 @@ class ResDetBuilder:
         st = e.tensor(x.n, x.h, x.w, x.c)
         wins = lambda t: [t.window(0, hh, 0, hw), t.window(hh, t.h, 0, hw), t.window(0, hh, hw, t.w), t.window(hh, t.h, hw, t.w)]
         names = ["%s.feat_patchconv_%s_nonlocal" % (p, q) for q in ("lt", "lb", "rt", "rb")]
-        self.nonlocal_gemm(names, wins(x), wins(st), assoc)
+        # the linear channel_conv (+ x) rides in the per-window matrices of the 'gram' association where a C^3 product per
+        # window is cheaper than a C x C product per pixel (fold: True / False / "auto")
+        n_max = (x.h - hh) * (x.w - hw)
+        a = self.gl_assoc(assoc, self.sd[names[0] + ".theta.weight"].shape[0], x.c, n_max)
+        linear = p + ".channel_conv.weight" in self.sd
+        if a == "gram" and linear and (fold is True or (fold == "auto" and n_max >= 2 * x.c)):
+            wc = self.sd[p + ".channel_conv.weight"]
+            bc = self.sd.get(p + ".channel_conv.bias")
+            self.nonlocal_gemm(names, wins(x), wins(st), "gram",
+                               fold=(p, wc.reshape(x.c, -1), torch.zeros(x.c) if bc is None else bc))
+            return st
+        self.nonlocal_gemm(names, wins(x), wins(st), a)
         if p + ".channel_conv.weight" in self.sd:                       # channel_cat == 'linear': 1x1 conv + bias
             pkc = self._pack(p + ".channel_conv", [self._plain_part(p + ".channel_conv")], st.c)
             return e.conv(st, pkc, 1, 0, "none", res=x)

@@ -613,11 +613,11 @@ def test_gl_fusion_config_builds_and_oracle_composes():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("mode", ["f32", "f16"])
-@pytest.mark.parametrize("assoc", ["re", "dir", "gram", "pair"])
+@pytest.mark.parametrize("assoc", ["re", "dir", "gram", "gram+fold", "pair"])
 @pytest.mark.parametrize("c,hw,cat", [(64, (12, 16), "linear"), (128, (13, 21), "linear"), (512, (9, 10), "non_linear")])
 def test_gl_fusion_plugin_vs_oracle(engines, mode, assoc, c, hw, cat):
-    """x + Patch_Conv_NonLocal_new(x) at ResNet-like widths through the GEMM lowering of the non-local block, both
-    associations of its products, odd quadrant sizes, both channel_cat options."""
+    """x + Patch_Conv_NonLocal_new(x) at ResNet-like widths through the GEMM lowering of the non-local block, every
+    association of its products (and the channel_conv folded into 'gram'), odd quadrant sizes, both channel_cat options."""
     from glsdet_amd.resdet import ResDetBuilder
     from tests.test_hip_ops import _to_view
     eng = engines[mode]
@@ -626,7 +626,9 @@ def test_gl_fusion_plugin_vs_oracle(engines, mode, assoc, c, hw, cat):
         sd["g.channel_conv.bn.running_var"] = sd["g.channel_conv.bn.running_var"] + 1.0
     x = O.synth_input((2, c, hw[0], hw[1]), 11)
     want = _r(x, mode) + O.patch_conv_nonlocal_new(sd, "g", _r(x, mode))
-    out = ResDetBuilder(eng, sd).gl_fusion("g", _to_view(eng, x), assoc)
+    if assoc == "gram+fold" and cat != "linear":
+        pytest.skip("only the linear channel_conv folds into the per-window matrices")
+    out = ResDetBuilder(eng, sd).gl_fusion("g", _to_view(eng, x), assoc.split("+")[0], fold=assoc.endswith("+fold"))
     torch.cuda.synchronize()
     err = _err(out.to_nchw().cpu(), want)
     print("gl_fusion c=%d %s %s %s: %.2e" % (c, hw, assoc, mode, err))
