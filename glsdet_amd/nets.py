@@ -538,10 +538,28 @@ class NetBuilder:
         k = self.sd[p + ".conv.weight"].shape[-1]
         return self.plain(p + ".conv", x, pad=k // 2, out=out)
 
+    def stem_of_identity(self, stem: str, ident: str, x: TView) -> TView:
+        """stems[k](Identity_Conv(x)) as ONE conv.  The identity conv is a plain k x k conv + bias (Identity_Conv.py:27-84) and
+        at P5 its only reader is the head stem's 1x1 BaseConv (yolo_patch_nonlocal_plus.py:245-247 -> base/yolox.py:60): nothing
+        non-linear lies between the two, so W[o, i] = sum_m W1[o, m] Wid[m, i] (float64 on the host) is a k x k conv straight
+        to the stem's width and the identity conv's bias rides through the BN fold.  Same function, a quarter of the identity
+        conv's multiplies at P5 (512 -> 128 instead of 512 -> 512 -> 128) and one launch fewer; P3 / P4 keep theirs (their
+        identity convs also feed the stride-2 convs of the bottom-up path, whose zero padding a composed conv cannot express)."""
+        w1, s1, b1 = self._bn_part(stem)
+        wid, bid = self.sd[ident + ".conv.weight"].double(), self.sd[ident + ".conv.bias"].double()
+        W1 = w1.double().reshape(w1.shape[0], -1)
+        w = torch.einsum("om,mikl->oikl", W1, wid).float()
+        b = (b1.double() + s1.double() * (W1 @ bid)).float()
+        pk = self._pack(stem + "*" + ident, [(w, s1, b)], x.c)
+        y = self.e.conv(x, pk, 1, wid.shape[-1] // 2, "silu")
+        self._rec(stem, y, 0, w.shape[0])
+        return y
+
     # ------------------------------------------------------------------ necks
-    def pafpn(self, p: str, img: torch.Tensor, gl: bool) -> List[TView]:
+    def pafpn(self, p: str, img: torch.Tensor, gl: bool, fold_p5: bool = False) -> List[TView]:
         """YOLOPAFPN (base/yolox.py:170-234) or its GL-fusion variant
-        (block/non_local/yolo_patch_nonlocal_plus.py:180-247) when gl=True."""
+        (block/non_local/yolo_patch_nonlocal_plus.py:180-247) when gl=True.  fold_p5: the caller's head is yolox_head,
+        which may take P5_Identity into its stem (stem_of_identity); the third output is then C3_n4's."""
         sd = self.sd
         c3 = self.conv_out_channels(p + ".backbone.dark3.1.conv3")
         c4 = self.conv_out_channels(p + ".backbone.dark4.1.conv3")
@@ -573,8 +591,13 @@ class NetBuilder:
             P4o = self.identity_conv(p + ".P4_Identity", P4o)
         self.cba(p + ".bu_conv1", P4o, 2, out=cat_n4.channels(0, c4))
         P5o = self.csp(p + ".C3_n4", cat_n4, False)
+        self._p5_identity = None
         if gl:
-            P5o = self.identity_conv(p + ".P5_Identity", P5o)
+            # (a trace holds every stored tensor, P5_Identity's output among them: tracing keeps the two-launch form)
+            if fold_p5 and self.trace is None and not os.environ.get("GLSDET_NO_HEAD_FOLD"):
+                self._p5_identity = p + ".P5_Identity"
+            else:
+                P5o = self.identity_conv(p + ".P5_Identity", P5o)
         self.features = f
         return [P3, P4o, P5o]
 
@@ -598,7 +621,11 @@ class NetBuilder:
         L = len(feats)
         nc = self.sd["%s.cls_preds.0.weight" % p].shape[0]
         f = self.conv_out_channels("%s.stems.0" % p)
-        self.stems = [self.cba("%s.stems.%d" % (p, k), x) for k, x in enumerate(feats)]
+        ident = getattr(self, "_p5_identity", None)
+        if ident is not None and (L != 3 or self.is_depthwise("%s.stems.2" % p)):
+            raise ValueError("pafpn(fold_p5=True) left P5_Identity to a head that cannot take it in")
+        self.stems = [self.stem_of_identity("%s.stems.%d" % (p, k), ident, x) if (ident is not None and k == 2)
+                      else self.cba("%s.stems.%d" % (p, k), x) for k, x in enumerate(feats)]
         T = [self.cba(["%s.cls_convs.%d.0" % (p, k), "%s.reg_convs.%d.0" % (p, k)], s) for k, s in enumerate(self.stems)]
         U = [self.e.tensor(x.n, x.h, x.w, 2 * f) for x in feats]
         pairs = lambda ks: (["%s.%s_convs.%d.1" % (p, t, k) for k in ks for t in ("cls", "reg")],
@@ -659,7 +686,8 @@ def build_forward(kind: str, eng: Engine, sd, img: torch.Tensor, trace: Optional
     b.trace = trace
     if kind not in ("base", "gl", "cross"):
         raise ValueError("unknown detector kind %r" % kind)
-    feats = b.pafpn("backbone", img, gl=(kind == "gl"))
+    fold = kind == "gl" and not b.is_depthwise("head.stems.2")
+    feats = b.pafpn("backbone", img, gl=(kind == "gl"), fold_p5=fold)
     if kind == "cross":
         outs = b.cross_scale_head("head", [b.features["dark2"]] + feats)
     else:

@@ -313,6 +313,37 @@ def test_missing_library_fails_loudly(monkeypatch):
         _lib.load()
 
 
+@pytest.mark.parametrize("mode", ["f32", "f16"])
+def test_p5_identity_folded_into_the_head_stem(golden, shapes, monkeypatch, mode):
+    """stems[2](P5_Identity(x)) as ONE 3x3 conv to the stem's width (NetBuilder.stem_of_identity: W = W1 . Wid on the host)
+    against the two launches: same logits up to the rounding of the intermediate that no longer exists (f32: accumulation
+    order; f16: the identity conv's stored output), both against the REFERENCE's logits, and exactly one op fewer."""
+    from glsdet_amd.detector import HipDetector
+    meta, sd, x, outs, _ = model_case(golden, shapes, "gl_s_seed0")
+    got, nops = {}, {}
+    for fold in (False, True):
+        if fold:
+            monkeypatch.delenv("GLSDET_NO_HEAD_FOLD", raising=False)
+        else:
+            monkeypatch.setenv("GLSDET_NO_HEAD_FOLD", "1")
+        det = HipDetector("gl", sd, dtype=mode)
+        got[fold] = [g.cpu() for g in det.forward_raw(x.cuda())]
+        c = det.compile(x.shape[0], x.shape[2], x.shape[3], dict(conf_thres=0.3, nms_thres=0.5))
+        nops[fold] = c.plan.num_ops
+    scale = max(float(w.abs().max()) for w in outs)
+    diff = max(float((a - b).abs().max()) for a, b in zip(got[False], got[True]))
+    errs = {f: max(float((g - w).abs().max()) for g, w in zip(got[f], outs)) for f in (False, True)}
+    print("P5 fold %s: folded-vs-unfolded %.2e, vs reference unfolded %.2e folded %.2e (max |logit| %.2f)"
+          % (mode, diff, errs[False], errs[True], scale))
+    assert nops[True] == nops[False] - 1, nops
+    if mode == "f32":
+        assert diff <= 1e-4 * scale
+    else:
+        assert diff <= 2e-2 * scale and errs[True] <= max(1.25 * errs[False], 0.10 * scale)
+    # the fold touches level 2 only: the other levels see the identical plan
+    assert torch.equal(got[False][0], got[True][0]) and torch.equal(got[False][1], got[True][1])
+
+
 def test_autotuned_plan_matches_default(golden, shapes):
     """build-time autotune only picks among equivalent kernels: same logits (bitwise for the
     fp16 path up to accumulation order -> compare with the per-op fp16 tolerance)"""
