@@ -437,12 +437,7 @@ __global__ __launch_bounds__(NTHR) void conv_igemm_kernel(const ConvArgs a) {
 // per-quadrant GEMMs of the large-channel non-local block) as ONE
 // launch: each is too small to fill 256 CUs on its own.  The argument blocks travel in the kernarg
 // segment; a workgroup finds its problem from the prefix of tile counts (wave-uniform).
-#define GLS_MULTI 8       // 8 x sizeof(ConvArgs) = 2.2 KB of the 4 KB kernarg segment
-struct ConvArgsN {
-  ConvArgs p[GLS_MULTI];
-  int start[GLS_MULTI + 1];
-  int n;
-};
+// (ConvArgsN: conv_common.h)
 template <typename T, typename TO, int CO_T, int PX_T, int KB, int WCO, bool UT>
 __global__ __launch_bounds__(256) void conv_igemm_multi_kernel(const ConvArgsN m) {
   int g = 0;
@@ -778,6 +773,11 @@ static int build_conv_multi_op(const glsdet_conv_desc* d, int32_t n, int hint, O
         a.pad != b.pad || a.Cin != b.Cin || a.Cout != b.Cout)
       GLS_FAIL(GLSDET_E_ARG, "conv2d_multi: descriptor %d is not of the shape class of descriptor 0", i);
   }
+  if (hint >= 8 && hint <= 11) {          // the grouped ring kernel (conv_halo.hip); no silent fall-back: the tuner asks per hint
+    if (conv_halo_multi_try(m, d[0].x.dtype, d[0].y.dtype, hint, &op))
+      GLS_FAIL(GLSDET_E_ARG, "conv2d_multi: the grouped halo kernel (hint %d) does not apply to this shape class", hint);
+    return 0;
+  }
   int co_t, px_t, kb;
   ConvArgs probe = m.p[0];
   probe.M = (int)(Mtot > 0x7fffffffL ? 0x7fffffffL : Mtot);
@@ -873,11 +873,13 @@ extern "C" int glsdet_conv2d_multi_tune(const glsdet_conv_desc* d, int32_t n, vo
   if (!d || !best_hint) GLS_FAIL(GLSDET_E_ARG, "conv2d_multi_tune: null argument");
   hipStream_t st = (hipStream_t)stream;
   const int hints[] = {(128 << 16) | 128, (64 << 16) | 128, (64 << 16) | 64, (64 << 16) | 64 | 0x8000,
-                       (64 << 16) | 128 | 0x8000, (128 << 16) | 128 | 0x8000};
+                       (64 << 16) | 128 | 0x8000, (128 << 16) | 128 | 0x8000, 8, 9, 10, 11};
   std::vector<OpRecord> ops;
   std::vector<int> ids;
+  const bool no_ring = getenv("GLSDET_NO_RING_MULTI") != nullptr;       // A/B switch for measurements
   for (int h : hints) {
     OpRecord op;
+    if (no_ring && h >= 8 && h <= 11) continue;
     if (build_conv_multi_op(d, n, h, op)) continue;
     ops.push_back(std::move(op));
     ids.push_back(h);

@@ -498,7 +498,21 @@ __device__ __forceinline__ void halo_store_and_chain(unsigned char* smem, const 
 }
 
 // host-side dispatch of the halo kernel (conv_halo.hip); returns 1 if it does not apply
+// several problems of one shape class in the kernarg segment (conv_igemm_multi_kernel, conv_halo_ring_multi_kernel)
+#define GLS_MULTI 8       // 8 x sizeof(ConvArgs) = 2.2 KB of the 4 KB kernarg segment
+struct ConvArgsN {
+  ConvArgs p[GLS_MULTI];
+  int start[GLS_MULTI + 1];
+  int n;
+};
+struct HaloArgsN {
+  ConvArgs p[GLS_MULTI];
+  int start[GLS_MULTI + 1];
+  int tx[GLS_MULTI], ty[GLS_MULTI];      // 8 x 16 tiles per row / column of each problem
+  int n;
+};
 int conv_halo_try(const ConvArgs& a, int xdt, int ydt, int hint, OpRecord* op);
+int conv_halo_multi_try(const ConvArgsN& m, int xdt, int ydt, int hint, OpRecord* op);
 // fused Bottleneck front (conv_bneck.hip); hint 0 / 1 = 128- / 64-byte channel chunks; returns 1 if it does not apply
 int conv_bneck_try(const BneckArgs& b, int dt, int hint, OpRecord* op);
 // weight-stationary persistent 1x1 kernel (conv1x1.hip), tile_hint 3; returns 1 if it does not apply

@@ -255,7 +255,7 @@ __host__ __device__ constexpr int halo_ring_sb_off(bool wide) {
 }
 
 template <typename T, typename TO, int CO_T, int KS, int RING, int KB = 128, int STR = 1, bool CH = false, bool GN = false>
-__global__ __launch_bounds__(256) void conv_halo_ring_kernel(const ConvArgs a, const int tiles_x, const int tiles_y) {
+__device__ __forceinline__ void conv_halo_ring_body(const ConvArgs& a, const int tiles_x, const int tiles_y, const int tile) {
   constexpr int TH = 8, TW = 16, WCO = 2;
   constexpr int RS = KB + 16;
   constexpr int CPRW = KB / 16;                    // 16-byte chunks per row
@@ -281,12 +281,6 @@ __global__ __launch_bounds__(256) void conv_halo_ring_kernel(const ConvArgs a, c
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  int tile;
-  {
-    const int nwg = gridDim.x, bid = blockIdx.x;
-    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, local = bid >> 3;
-    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
-  }
   int rest = gls_div(tile, a.nco_mul, a.nco_sh);
   const int co0 = (tile - rest * a.n_co_tiles) * CO_T;
   const int r1 = gls_div(rest, a.tx_mul, a.tx_sh);
@@ -464,6 +458,27 @@ __global__ __launch_bounds__(256) void conv_halo_ring_kernel(const ConvArgs a, c
   }
   __syncthreads();
   halo_store_and_chain<T, TO, CO_T, PITCH, CH, GN>(smem, a, img, ty0, tx0, co0, tid);
+}
+
+template <typename T, typename TO, int CO_T, int KS, int RING, int KB = 128, int STR = 1, bool CH = false, bool GN = false>
+__global__ __launch_bounds__(256) void conv_halo_ring_kernel(const ConvArgs a, const int tiles_x, const int tiles_y) {
+  const int nwg = gridDim.x, bid = blockIdx.x;
+  const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, local = bid >> 3;       // XCD-aware tile order
+  conv_halo_ring_body<T, TO, CO_T, KS, RING, KB, STR, CH, GN>(a, tiles_x, tiles_y,
+                                                               (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local);
+}
+
+// Several independent 3x3 convs of one shape class (the quadrant convs of Patch_Conv / Patch_Conv_NonLocal and their
+// l / r / t / b convs: each alone is a fraction of a round of workgroups) as ONE launch of the ring kernel; the
+// argument blocks travel in the kernarg segment as for conv_igemm_multi_kernel (conv.hip), a workgroup finds its problem
+// from the prefix of tile counts.
+template <typename T, typename TO, int CO_T, int KS, int RING, int KB, int STR>
+__global__ __launch_bounds__(256) void conv_halo_ring_multi_kernel(const HaloArgsN m) {
+  int g = 0;
+#pragma unroll
+  for (int i = 1; i < GLS_MULTI; ++i)
+    if (i < m.n && (int)blockIdx.x >= m.start[i]) g = i;
+  conv_halo_ring_body<T, TO, CO_T, KS, RING, KB, STR, false, false>(m.p[g], m.tx[g], m.ty[g], (int)blockIdx.x - m.start[g]);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -724,6 +739,75 @@ static int launch_halo_ring(const ConvArgs& a, hipStream_t st) {
   if (grid <= 0 || grid > 0x7fffffffL) GLS_FAIL(GLSDET_E_ARG, "conv2d(halo ring): grid %ld out of range", grid);
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, st, b, tiles_x, tiles_y);
   GLS_HIP(hipGetLastError());
+  return 0;
+}
+
+template <typename T, typename TO, int CO_T, int RING, int KB, int STR>
+static int launch_halo_ring_multi(const ConvArgsN& m0, hipStream_t st) {
+  constexpr int KS = 3;
+  bool any_res = false;
+  for (int i = 0; i < m0.n; ++i) any_res = any_res || m0.p[i].res != nullptr;
+  constexpr int ldsw = halo_ring_sb_off<T, TO, CO_T, KS, RING, KB, STR>(true) + CO_T * 8;
+  const int lds = halo_ring_sb_off<T, TO, CO_T, KS, RING, KB, STR>(sizeof(TO) == 2 && any_res) + CO_T * 8;
+  auto kern = conv_halo_ring_multi_kernel<T, TO, CO_T, KS, RING, KB, STR>;
+  static bool attr_set = false;
+  if (!attr_set && ldsw > 64 * 1024) {
+    GLS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, ldsw));
+    attr_set = true;
+  }
+  HaloArgsN m = {};
+  m.n = m0.n;
+  long grid = 0;
+  for (int i = 0; i < m.n; ++i) {
+    ConvArgs& b = m.p[i];
+    b = m0.p[i];
+    b.n_co_tiles = (b.Cout + CO_T - 1) / CO_T;
+    m.tx[i] = (b.Wo + 15) / 16;
+    m.ty[i] = (b.Ho + 7) / 8;
+    gls_fastdiv(b.n_co_tiles, &b.nco_mul, &b.nco_sh);
+    gls_fastdiv(m.tx[i], &b.tx_mul, &b.tx_sh);
+    gls_fastdiv(m.ty[i], &b.ty_mul, &b.ty_sh);
+    m.start[i] = (int)grid;
+    grid += (long)b.n_co_tiles * m.tx[i] * m.ty[i] * b.N;
+  }
+  for (int i = m.n; i <= GLS_MULTI; ++i) m.start[i] = (int)grid;
+  if (grid <= 0 || grid > 0x7fffffffL) GLS_FAIL(GLSDET_E_ARG, "conv2d_multi(halo ring): grid %ld out of range", grid);
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, st, m);
+  GLS_HIP(hipGetLastError());
+  return 0;
+}
+
+// The grouped form of the ring kernel for glsdet_conv2d_multi: hints 8 / 9 (128-byte channel chunks, 64- / 128-row cout
+// tiles; stride 1) and 10 / 11 (64-byte chunks; stride 1 and 2), 3x3 only, no chained / GroupNorm forms.
+// Returns 1 when it does not apply, 0 when `op` (name + launch) was filled in.
+int conv_halo_multi_try(const ConvArgsN& m, int xdt, int ydt, int hint, OpRecord* op) {
+  if (hint < 8 || hint > 11 || xdt != ydt) return 1;
+  const int es = dtype_size(xdt);
+  const bool k64 = hint >= 10;
+  const ConvArgs& a0 = m.p[0];
+  for (int i = 0; i < m.n; ++i) {
+    const ConvArgs& a = m.p[i];
+    if (a.w2 || a.gn_part || a.R != 3 || a.S != 3 || a.pad != 1 || (a.stride != 1 && a.stride != 2)) return 1;
+    if (a.stride != a0.stride || a.Cin != a0.Cin || a.Cout != a0.Cout) return 1;
+    if ((a.Cin * es) % (k64 ? 64 : 128)) return 1;
+  }
+  if (a0.stride == 2 && !k64) return 1;                 // the de-interleaved-patch form exists for 64-byte chunks
+  if ((hint == 9 || hint == 11) && a0.cout_pad <= 64) return 1;
+  const int co_t = (hint == 9 || hint == 11) ? 128 : 64;
+  const int str = a0.stride;
+  char nm[112];
+  snprintf(nm, sizeof nm, "conv_halo_ring%s%s_multi[%d]<%s,%dx8x16> 3x3 s%d cin%d cout%d", k64 ? "_k64" : "", str == 2 ? "_s2" : "", m.n,
+           xdt ? "f32" : "f16", co_t, str, a0.Cin, a0.Cout);
+  op->name = nm;
+  op->launch = [m, co_t, xdt, k64, str](hipStream_t st) -> int {
+#define GLS_HM(T_)                                                                                                  \
+    if (str == 2) return co_t == 128 ? launch_halo_ring_multi<T_, T_, 128, 4, 64, 2>(m, st) : launch_halo_ring_multi<T_, T_, 64, 4, 64, 2>(m, st); \
+    if (k64) return co_t == 128 ? launch_halo_ring_multi<T_, T_, 128, 4, 64, 1>(m, st) : launch_halo_ring_multi<T_, T_, 64, 4, 64, 1>(m, st);      \
+    return co_t == 128 ? launch_halo_ring_multi<T_, T_, 128, 3, 128, 1>(m, st) : launch_halo_ring_multi<T_, T_, 64, 3, 128, 1>(m, st);
+    if (xdt == GLSDET_F16) { GLS_HM(f16) }
+    GLS_HM(float)
+#undef GLS_HM
+  };
   return 0;
 }
 

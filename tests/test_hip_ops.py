@@ -395,6 +395,24 @@ def test_conv2d_multi_equals_separate_convs(engines, mode, case):
         torch.cuda.synchronize()
         for o, ref in zip(outs, refs):
             _cmp(o.to_nchw(cout), ref, TOL[mode], "conv multi hint %x" % hint)
+    # the grouped ring kernel (conv_halo_ring_multi_kernel): 3x3 only, whole 128- (hints 8 / 9) or 64-byte (10 / 11) channel
+    # chunks, stride 2 with 64-byte chunks only, 128-row cout tiles (9 / 11) for cout > 64; everything else is refused
+    from glsdet_amd._lib import GlsdetError
+    es = 2 if mode == "f16" else 4
+    ran = 0
+    for hint in (8, 9, 10, 11):
+        applies = k == 3 and (cin * es) % (64 if hint >= 10 else 128) == 0 and (stride == 1 or hint >= 10) and \
+            (hint in (8, 10) or cout > 64)
+        if not applies:
+            with pytest.raises(GlsdetError):
+                eng.conv_multi(xs, packs, stride, k // 2, act, ress=ress, tile_hint=hint)
+            continue
+        outs = eng.conv_multi(xs, packs, stride, k // 2, act, ress=ress, tile_hint=hint)
+        torch.cuda.synchronize()
+        for o, ref in zip(outs, refs):
+            _cmp(o.to_nchw(cout), ref, TOL[mode], "conv multi (grouped ring kernel) hint %d" % hint)
+        ran += 1
+    assert ran >= (1 if k == 3 and cin >= 32 else 0)
 
 
 @pytest.mark.parametrize("mode", ["f32", "f16"])
