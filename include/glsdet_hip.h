@@ -95,7 +95,8 @@ int     glsdet_conv2d(const glsdet_conv_desc* d, void* stream);
  * dtypes; extents, strides, weights, residuals may differ) as one launch of the generic kernel:
  * the four quadrant convs of Patch_Conv (drone/models/block/non_local/Identity_Conv.py:298-301),
  * the cls / reg tower convs of one head level (base/yolox.py:62-75).  Each alone is too small
- * to fill the chip.  tile_hint of d[0] applies (0 = auto).  Results are those of n glsdet_conv2d.
+ * to fill the chip.  tile_hint of d[0] applies (0 = auto; 8..11 = the grouped LDS-DMA ring kernel for 3x3 problems, meaning
+ * as for glsdet_conv2d, refused with GLSDET_E_ARG where it does not apply).  Results are those of n glsdet_conv2d.
  * `w` may point at an ACTIVATION matrix (rows of x.c elements at a pitch of glsdet_conv_kpad elements, zero padded):
  * the batched products of the non-local block at ResNet widths are such 1x1 "convs" with per-image weights. */
 int     glsdet_conv2d_multi(const glsdet_conv_desc* d, int32_t n, void* stream);
