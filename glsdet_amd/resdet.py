@@ -37,6 +37,15 @@ GN_EPS = 1e-5
 STAGE_BLOCKS = {50: (3, 4, 6, 3), 101: (3, 4, 23, 3)}
 
 
+class GlDeferred:
+    """x + channel_conv(st) of a GL plug-in level whose linear channel_conv has not been applied yet: the only reader is the
+    FPN lateral 1x1 conv (no norm, no activation), which takes it in (ResDetBuilder.fpn)."""
+    __slots__ = ("p", "x", "st")
+
+    def __init__(self, p: str, x: TView, st: TView):
+        self.p, self.x, self.st = p, x, st
+
+
 class ResDetBuilder:
     def __init__(self, eng: Engine, sd: Dict[str, torch.Tensor]):
         self.e = eng
@@ -359,7 +368,7 @@ class ResDetBuilder:
                     [oq[j] for j in jobs], [xq[j] for j in jobs])
         return list(outs)
 
-    def gl_fusion(self, p: str, x: TView, assoc: str = "auto", fold="auto") -> TView:
+    def gl_fusion(self, p: str, x: TView, assoc: str = "auto", fold="auto", defer: bool = False):
         """x + Patch_Conv_NonLocal_new(x)  (drone/models/new/yolox10.py:262-266 applied to a ResNet stage output;
         Non_local_family.py:208-252): quadrant non-local blocks at the input resolution, re-stitch (free: the
         blocks write their windows of one buffer), channel_conv, residual."""
@@ -380,6 +389,8 @@ class ResDetBuilder:
                                fold=(p, wc.reshape(x.c, -1), torch.zeros(x.c) if bc is None else bc))
             return st
         self.nonlocal_gemm(names, wins(x), wins(st), a)
+        if defer and linear:                 # the caller is the FPN: its lateral conv composes with the channel_conv
+            return GlDeferred(p, x, st)
         if p + ".channel_conv.weight" in self.sd:                       # channel_cat == 'linear': 1x1 conv + bias
             pkc = self._pack(p + ".channel_conv", [self._plain_part(p + ".channel_conv")], st.c)
             return e.conv(st, pkc, 1, 0, "none", res=x)
@@ -387,6 +398,28 @@ class ResDetBuilder:
                        self.sd[p + ".channel_conv.bn.running_mean"], self.sd[p + ".channel_conv.bn.running_var"], 1e-3)
         pkc = self._pack(p + ".channel_conv", [(self.sd[p + ".channel_conv.conv.weight"], s, b)], st.c)
         return e.conv(st, pkc, 1, 1, "silu", res=x)                     # BaseConv 3x3 + BN(1e-3) + SiLU, then + x
+
+    def gl_materialise(self, d: GlDeferred) -> TView:
+        """x + channel_conv(st) as a stored tensor (gl_fusion's own last step)."""
+        pkc = self._pack(d.p + ".channel_conv", [self._plain_part(d.p + ".channel_conv")], d.st.c)
+        return self.e.conv(d.st, pkc, 1, 0, "none", res=d.x)
+
+    def _lateral_of_deferred(self, name: str, d: GlDeferred) -> TView:
+        """lateral(x + Wc st + bc) = Wl x + (Wl Wc) st + (Wl bc + bl): two 1x1 convs to the FPN width instead of a C x C
+        product per pixel followed by one (fpn.py:165-168 on Non_local_family.py:247-250; nothing non-linear lies between
+        the two and the lateral conv is the plug-in output's only reader).  At C = 1024 / 2048 that is 0.5 / 1.0 instead of
+        1.3 / 4.7 MMAC per pixel."""
+        e = self.e
+        wl, _, bl = self._plain_part(name)
+        C_ = d.x.c
+        Wl = wl.double().reshape(wl.shape[0], -1)
+        Wc = self.sd[d.p + ".channel_conv.weight"].double().reshape(C_, -1)
+        bc = self.sd.get(d.p + ".channel_conv.bias")
+        bc = torch.zeros(C_, dtype=torch.float64) if bc is None else bc.double()
+        one, zero = torch.ones(wl.shape[0]), torch.zeros(wl.shape[0])
+        t = e.conv(d.x, self._pack(name + "@x", [(wl.float(), one, (bl.double() + Wl @ bc).float())], C_), 1, 0, "none")
+        w2 = (Wl @ Wc).float().reshape(wl.shape[0], C_, 1, 1)
+        return e.conv(d.st, self._pack(name + "@st", [(w2, one, zero)], C_), 1, 0, "none", res=t)
 
     # ------------------------------------------------------------------ neck
     def fpn(self, p: str, inputs: Sequence[TView], start_level: int = 0, num_outs: int = 5,
@@ -397,7 +430,15 @@ class ResDetBuilder:
             raise NotImplementedError("FPN relu_before_extra_convs is not lowered")
         n_lat = len(inputs) - start_level
         conv = lambda name, x, stride, pad: e.conv(x, self._pack(name, [self._plain_part(name)], x.c), stride, pad, "none")
-        lat = [conv("%s.lateral_convs.%d.conv" % (p, i), inputs[i + start_level], 1, 0) for i in range(n_lat)]
+        inputs = list(inputs)
+        mode = ("on_input" if add_extra_convs is True else add_extra_convs) if num_outs > n_lat else None
+        if mode == "on_input" and isinstance(inputs[-1], GlDeferred):       # the extra level reads C5 itself
+            inputs[-1] = self.gl_materialise(inputs[-1])
+        for i in range(start_level):                                         # levels the FPN does not read at all
+            inputs[i] = None
+        lat = [self._lateral_of_deferred("%s.lateral_convs.%d.conv" % (p, i), inputs[i + start_level])
+               if isinstance(inputs[i + start_level], GlDeferred)
+               else conv("%s.lateral_convs.%d.conv" % (p, i), inputs[i + start_level], 1, 0) for i in range(n_lat)]
         for i in range(n_lat - 1, 0, -1):
             e.upsample_add(lat[i], lat[i - 1])
         outs = [conv("%s.fpn_convs.%d.conv" % (p, i), lat[i], 1, 1) for i in range(n_lat)]
@@ -540,7 +581,8 @@ class HipGflDetector:
         if levels is None:
             levels = [i for i in range(len(stages)) if "neck.gl_fusion.%d.feat_patchconv_lt_nonlocal.theta.weight" % i in self.sd]
         for i in levels:                       # GLFusionFPN: the plug-in sits on the FPN inputs (C3..C5), before the laterals
-            stages[i] = b.gl_fusion("neck.gl_fusion.%d" % i, stages[i], c["gl_assoc"])
+            stages[i] = b.gl_fusion("neck.gl_fusion.%d" % i, stages[i], c["gl_assoc"],
+                                    defer=i >= c["start_level"] and not os.environ.get("GLSDET_NO_LATERAL_FOLD"))
         feats = b.fpn("neck", stages, c["start_level"], c["num_outs"],
                       c["add_extra_convs"], c["relu_before_extra_convs"])
         if self.kind == "gfl":
