@@ -37,6 +37,14 @@ GN_EPS = 1e-5
 STAGE_BLOCKS = {50: (3, 4, 6, 3), 101: (3, 4, 23, 3)}
 
 
+class GlPending:
+    """A GL plug-in level not emitted yet: the FPN decides how (ResDetBuilder.fpn -> gl_lateral / gl_fusion)."""
+    __slots__ = ("p", "x", "assoc")
+
+    def __init__(self, p: str, x: TView, assoc: str):
+        self.p, self.x, self.assoc = p, x, assoc
+
+
 class GlDeferred:
     """x + channel_conv(st) of a GL plug-in level whose linear channel_conv has not been applied yet: the only reader is the
     FPN lateral 1x1 conv (no norm, no activation), which takes it in (ResDetBuilder.fpn)."""
@@ -141,7 +149,7 @@ class ResDetBuilder:
             del cost["gram"]
         return os.environ.get("GLSDET_GL_ASSOC") or min(cost, key=cost.get)
 
-    def nonlocal_gemm(self, ps: Sequence[str], xs: Sequence[TView], outs: Sequence[TView], assoc: str = "auto", fold=None):
+    def nonlocal_gemm(self, ps: Sequence[str], xs: Sequence[TView], outs: Sequence[TView], assoc: str = "auto", post=None):
         """Non_local_Block (drone/models/new/Non_local_family.py:6-50) at ResNet widths (C = 512...2048), for the
         quadrants `xs` (views with the batch in n) of ONE feature map, written to `outs`:
             out = x + conv_out( (theta^T phi / N) g^T )            (dot product, divide by N, no softmax)
@@ -167,7 +175,8 @@ class ResDetBuilder:
         Ns = [x.h * x.w for x in xs]
         Np = (max(Ns) + 7) // 8 * 8
         assoc = self.gl_assoc(assoc, ci, C_, max(Ns))
-        assert fold is None or assoc == "gram", "only the 'gram' association takes the channel_conv in"
+        assert post is None or assoc == "gram" or (assoc == "pair" and not post["res_x"]), \
+            "linear maps behind the block ride in the per-window matrices of 'gram' (any) and 'pair' (to another width) only"
         w2 = lambda p, nm: self.sd["%s.%s.weight" % (p, nm)].float().reshape(self.sd["%s.%s.weight" % (p, nm)].shape[0], -1)
         bias = lambda p, nm: self.sd["%s.%s.bias" % (p, nm)]
         pk = lambda p, nm: self._pack("%s.%s" % (p, nm), [self._plain_part("%s.%s" % (p, nm))], C_)
@@ -188,8 +197,8 @@ class ResDetBuilder:
         if assoc in ("gram", "pair"):            # the pixel count is a contraction length there: whole 64-byte K steps as well
             np32 = (max(Ns) + 31) // 32 * 32          # (64 measured the same)
             if assoc == "gram":
-                return self._nonlocal_gram(ps, xs, outs, jobs, xq, oq, Ns, np32, fold)
-            return self._nonlocal_pair(ps, xs, outs, jobs, xq, oq, Ns, np32)
+                return self._nonlocal_gram(ps, xs, outs, jobs, xq, oq, Ns, np32, post)
+            return self._nonlocal_pair(ps, xs, outs, jobs, xq, oq, Ns, np32, post)
         # theta for every (image, quadrant): a plain conv per quadrant over the whole batch
         theta = [e.tensor(x.n, x.h, x.w, ci) for x in xs]
         e.conv_many(list(xs), [pk(p, "theta") for p in ps], 1, 0, "none", theta)
@@ -249,6 +258,33 @@ class ResDetBuilder:
         e.conv_many(yv, [pk(ps[q], "conv_out") for (b, q) in jobs], 1, 0, "none", [oq[j] for j in jobs], [xq[j] for j in jobs])
         return list(outs)
 
+    def _gl_aug(self, p: str, nm: str, C_: int) -> torch.Tensor:
+        """[W | b | 0...]  (rows x C+a, float64) of the 1x1 conv p.nm."""
+        w = self.sd["%s.%s.weight" % (p, nm)].double().reshape(self.sd["%s.%s.weight" % (p, nm)].shape[0], -1)
+        out = torch.zeros(w.shape[0], C_ + GL_AUG, dtype=torch.float64)
+        out[:, :C_] = w
+        out[:, C_] = self.sd["%s.%s.bias" % (p, nm)].double()
+        return out
+
+    def _gl_post(self, p: str, ps, x: TView, wins, lateral: Optional[str] = None):
+        """The linear maps behind the four non-local blocks of plug-in p, composed on the host (float64):
+        gl_fusion's own linear channel_conv and residual,  z = x + Wc (x + NL(x)) + bc,  and -- lateral = name of the FPN
+        lateral conv that alone reads z -- that conv as well,  Wl z + bl.  With NL(x) = (per-window linear map of x') + bout:
+            result = Wr x + Wp NL0(x) + bias_q          (NL0 = NL without bout; Wr x includes the residuals)
+            channel_conv only:  Wp = Wc,     Wr = I + Wc       (applied as `+ x` and Wc: res_x),  bias_q = Wc bout_q + bc
+            with the lateral:   Wp = Wl Wc,  Wr = Wl (I + Wc),                                    bias_q = Wl (Wc bout_q + bc) + bl"""
+        C_ = x.c
+        Wc = self.sd[p + ".channel_conv.weight"].double().reshape(C_, -1)
+        bc = self.sd.get(p + ".channel_conv.bias")
+        bc = torch.zeros(C_, dtype=torch.float64) if bc is None else bc.double()
+        bout = lambda q: self.sd[ps[q] + ".conv_out.bias"].double()
+        if lateral is None:
+            return dict(key=p + "@cc", Wp=Wc, Wr=Wc, res_x=True, bias=lambda q: Wc @ bout(q) + bc, x=x, wins=wins)
+        wl, _, bl = self._plain_part(lateral)
+        Wl = wl.double().reshape(wl.shape[0], -1)
+        return dict(key=p + "@" + lateral, Wp=Wl @ Wc, Wr=Wl + Wl @ Wc, res_x=False,
+                    bias=lambda q: Wl @ (Wc @ bout(q) + bc) + bl.double(), x=x, wins=wins)
+
     def _gl_consts(self, p: str, C_: int):
         """Build-time constants of the folded associations of one non-local block (float64 on the host), with
         W' = [W | b | 0...] (ci x C+a):  A = Wout Wg' (C x C+a) as an activation matrix;  B = Wphi'^T Wtheta' ((C+a) x (C+a))
@@ -258,12 +294,7 @@ class ResDetBuilder:
         Ca = C_ + GL_AUG
         k = ("glconst", p)
         if k not in self._packed:
-            def aug(nm):
-                w = self.sd["%s.%s.weight" % (p, nm)].double().reshape(self.sd["%s.%s.weight" % (p, nm)].shape[0], -1)
-                out = torch.zeros(w.shape[0], Ca, dtype=torch.float64)
-                out[:, :C_] = w
-                out[:, C_] = self.sd["%s.%s.bias" % (p, nm)].double()
-                return out
+            aug = lambda nm: self._gl_aug(p, nm, C_)
             wout = self.sd[p + ".conv_out.weight"].double().reshape(C_, -1)
             A = (wout @ aug("g")).float()                                            # C x Ca
             B = (aug("phi").t() @ aug("theta")).float()                              # Ca x Ca
@@ -291,10 +322,12 @@ class ResDetBuilder:
         e.copy_many([xq[j] for j in jobs], dense)
         return Xr
 
-    def _nonlocal_pair(self, ps, xs, outs, jobs, xq, oq, Ns, Np):
+    def _nonlocal_pair(self, ps, xs, outs, jobs, xq, oq, Ns, Np, post=None):
         """The 'pair' association of nonlocal_gemm (see there).  Per (image, quadrant), X' = the window with a ones channel:
             U = X' (Wtheta'^T Wphi')   (N x C+a)        S = U X'^T / N   (N x N: theta_i . phi_j / N)
-            V^T = (Wout Wg') X'^T      (C x N)          out = x + S V + bout"""
+            V^T = (Wout Wg') X'^T      (C x N)          out = x + S V + bout
+        post (see _gl_post; to another width R only): the linear maps behind the block applied to V instead of to the pixels,
+            V2^T = (Wp Wout Wg') X'^T  (R x N)          out = Wr x + S V2 + bias_q     (Wr x: ONE 1x1 conv over the whole map)."""
         e = self.e
         C_ = xs[0].c
         Ca = C_ + GL_AUG
@@ -306,16 +339,32 @@ class ResDetBuilder:
         S = {(b, q): e.matrix(Ns[q], Np) for (b, q) in jobs}
         e.conv_many([act(U[j], Ns[j[1]]) for j in jobs], [e.as_weight(Xr[b, q], alpha=1.0 / Ns[q]) for (b, q) in jobs], 1, 0, "none",
                     [S[j] for j in jobs])
-        VT = {j: e.matrix(C_, Np) for j in jobs}
-        e.conv_many([self._gl_consts(ps[q], C_)[0] for (b, q) in jobs], [e.as_weight(Xr[j]) for j in jobs], 1, 0, "none",
-                    [VT[j] for j in jobs])
         sv = [TView(S[b, q].buf, 0, 1, xs[q].h, xs[q].w, S[b, q].c, xs[q].h * xs[q].w * S[b, q].sw, xs[q].w * S[b, q].sw, S[b, q].sw,
                     S[b, q].dtype) for (b, q) in jobs]
-        e.conv_many(sv, [e.as_weight(VT[b, q], bias=self.sd[ps[q] + ".conv_out.bias"]) for (b, q) in jobs], 1, 0, "none",
-                    [oq[j] for j in jobs], [xq[j] for j in jobs])
+        if post is None:
+            VT = {j: e.matrix(C_, Np) for j in jobs}
+            e.conv_many([self._gl_consts(ps[q], C_)[0] for (b, q) in jobs], [e.as_weight(Xr[j]) for j in jobs], 1, 0, "none",
+                        [VT[j] for j in jobs])
+            e.conv_many(sv, [e.as_weight(VT[b, q], bias=self.sd[ps[q] + ".conv_out.bias"]) for (b, q) in jobs], 1, 0, "none",
+                        [oq[j] for j in jobs], [xq[j] for j in jobs])
+            return list(outs)
+        R = post["Wp"].shape[0]
+        one, zero = torch.ones(R), torch.zeros(R)
+        # Wr x over the whole map (the quadrant windows of t are the residual operands below)
+        t = e.conv(post["x"], self._pack(post["key"] + "@x", [(post["Wr"].float().reshape(R, C_, 1, 1), one, zero)], C_), 1, 0, "none")
+        tq = post["wins"](t)
+        A2 = {}
+        for q, p in enumerate(ps):
+            wout = self.sd[p + ".conv_out.weight"].double().reshape(C_, -1)
+            A2[q] = self._wmat("%s.A2.%d" % (post["key"], q), (post["Wp"] @ wout @ self._gl_aug(p, "g", C_)).float())     # R x Ca
+        VT = {j: e.matrix(R, Np) for j in jobs}
+        e.conv_many([A2[q] for (b, q) in jobs], [e.as_weight(Xr[j]) for j in jobs], 1, 0, "none", [VT[j] for j in jobs])
+        bq = {q: post["bias"](q).float() for q in range(len(ps))}          # (as_weight keeps them alive: it keys a bias by address)
+        e.conv_many(sv, [e.as_weight(VT[b, q], bias=bq[q]) for (b, q) in jobs], 1, 0, "none",
+                    [oq[j] for j in jobs], [tq[q].image(b) for (b, q) in jobs])
         return list(outs)
 
-    def _nonlocal_gram(self, ps, xs, outs, jobs, xq, oq, Ns, Np, fold=None):
+    def _nonlocal_gram(self, ps, xs, outs, jobs, xq, oq, Ns, Np, post=None):
         """The 'gram' association of nonlocal_gemm (see there).  Per (image, quadrant): the transposed copy X'^T [C+a x N] of the
         window (the constant-one channel C preset at build time), then
             G' = X'^T X' / N  ((C+a) x (C+a), contraction over the pixels),   T = A G'  (C x C+a),
@@ -323,9 +372,9 @@ class ResDetBuilder:
         with the constants A = Wout [Wg | bg] (C x C+a) and B = [Wphi | bphi]^T [Wtheta | btheta] ((C+a) x (C+a)) folded
         on the host in float64: the per-pixel product contracts over exactly C channels of the window where it lies (no
         row-major copy), its bias is a vector a 1-pixel product of the plan writes.
-        fold = (key, Wc [C x C], bc [C]): gl_fusion's linear channel_conv and its residual taken in as well,
-            x + Wc (x + x Qm^T + d) + bc = x + x Qm2^T + d2,   Qm2 = Wc Qm + Wc,   d2 = Wc (T B[:, C] + bout) + bc
-        -- one more C^3 product per window instead of a C x C product per pixel of the map."""
+        post (see _gl_post): the linear maps behind the block taken into the per-window matrices,
+            Qm2 = Wp Qm + Wr  (R x C),   d2 = Wp T B[:, C] + bias_q,   out = [x +] x Qm2^T + d2       (R = C or the FPN width)
+        -- one more R x C x C product per window instead of C x C (and R x C) products per pixel of the map."""
         e = self.e
         C_ = xs[0].c
         Ca = C_ + GL_AUG
@@ -344,28 +393,29 @@ class ResDetBuilder:
                     [G[j] for j in jobs])
         T = {j: e.matrix(C_, Ca) for j in jobs}
         e.conv_many([consts(ps[q])[0] for (b, q) in jobs], [e.as_weight(G[j]) for j in jobs], 1, 0, "none", [T[j] for j in jobs])
-        Qm = {j: e.matrix(C_, C_) for j in jobs}
-        d = {j: e.bias_vector(C_) for j in jobs}
-        if fold is None:
+        R = C_ if post is None else post["Wp"].shape[0]
+        Qm = {j: e.matrix(R, C_) for j in jobs}
+        d = {j: e.bias_vector(R) for j in jobs}
+        if post is None:
             e.conv_many([T[j] for j in jobs], [consts(ps[q])[4] for (b, q) in jobs], 1, 0, "none", [Qm[j] for j in jobs])
             e.conv_many([rows(consts(ps[q])[3], C_, C_ + 1) for (b, q) in jobs],
                         [e.as_weight(T[b, q], bias=bout(ps[q])) for (b, q) in jobs], 1, 0, "none", [d[j] for j in jobs])
         else:
-            key, Wc, bc = fold
-            WcM = self._wmat(key + ".WcM", Wc.float())
+            key = post["key"]
+            WpM = self._wmat(key + ".WpM", post["Wp"].float())
+            WrM = self._wmat(key + ".WrM", post["Wr"].float())
             # Q'^T (rows 0..C: the C columns of Qm and the bias column) = B^T T^T
             QT = {j: e.matrix(C_ + 8, C_) for j in jobs}
             e.conv_many([rows(consts(ps[q])[3], 0, C_ + 8) for (b, q) in jobs], [e.as_weight(T[j]) for j in jobs], 1, 0, "none",
                         [QT[j] for j in jobs])
-            e.conv_many([WcM for _ in jobs], [e.as_weight(rows(QT[j], 0, C_)) for j in jobs], 1, 0, "none",
-                        [Qm[j] for j in jobs], [WcM for _ in jobs])
-            pkd = {}
-            for q, p in enumerate(ps):
-                b2 = Wc.double() @ bout(p).double() + bc.double()
-                pkd[q] = self._pack(key + ".d2.%d" % q, [(Wc.float().reshape(C_, C_, 1, 1), torch.ones(C_), b2.float())], C_)
+            e.conv_many([WpM for _ in jobs], [e.as_weight(rows(QT[j], 0, C_)) for j in jobs], 1, 0, "none",
+                        [Qm[j] for j in jobs], [WrM for _ in jobs])
+            pkd = {q: self._pack("%s.d2.%d" % (key, q), [(post["Wp"].float().reshape(R, C_, 1, 1), torch.ones(R), post["bias"](q).float())], C_)
+                   for q in range(len(ps))}
             e.conv_many([rows(QT[j], C_, C_ + 1) for j in jobs], [pkd[q] for (b, q) in jobs], 1, 0, "none", [d[j] for j in jobs])
+        res_x = post is None or post["res_x"]
         e.conv_many([xq[j] for j in jobs], [e.as_weight(Qm[j], bias_dev=d[j]) for j in jobs], 1, 0, "none",
-                    [oq[j] for j in jobs], [xq[j] for j in jobs])
+                    [oq[j] for j in jobs], [xq[j] for j in jobs] if res_x else None)
         return list(outs)
 
     def gl_fusion(self, p: str, x: TView, assoc: str = "auto", fold="auto", defer: bool = False):
@@ -383,10 +433,7 @@ class ResDetBuilder:
         a = self.gl_assoc(assoc, self.sd[names[0] + ".theta.weight"].shape[0], x.c, n_max)
         linear = p + ".channel_conv.weight" in self.sd
         if a == "gram" and linear and (fold is True or (fold == "auto" and n_max >= 2 * x.c)):
-            wc = self.sd[p + ".channel_conv.weight"]
-            bc = self.sd.get(p + ".channel_conv.bias")
-            self.nonlocal_gemm(names, wins(x), wins(st), "gram",
-                               fold=(p, wc.reshape(x.c, -1), torch.zeros(x.c) if bc is None else bc))
+            self.nonlocal_gemm(names, wins(x), wins(st), "gram", post=self._gl_post(p, names, x, wins))
             return st
         self.nonlocal_gemm(names, wins(x), wins(st), a)
         if defer and linear:                 # the caller is the FPN: its lateral conv composes with the channel_conv
@@ -398,6 +445,23 @@ class ResDetBuilder:
                        self.sd[p + ".channel_conv.bn.running_mean"], self.sd[p + ".channel_conv.bn.running_var"], 1e-3)
         pkc = self._pack(p + ".channel_conv", [(self.sd[p + ".channel_conv.conv.weight"], s, b)], st.c)
         return e.conv(st, pkc, 1, 1, "silu", res=x)                     # BaseConv 3x3 + BN(1e-3) + SiLU, then + x
+
+    def gl_lateral(self, p: str, x: TView, lateral: str, assoc: str = "auto") -> TView:
+        """lateral_conv(x + Patch_Conv_NonLocal_new(x)) for a plug-in level whose output only the FPN lateral conv reads
+        (GLFusionFPN), linear channel_conv: the whole tail -- conv_out bias, channel_conv, both residuals, the lateral conv --
+        rides in the per-window matrices, and the level's first stored tensor after the backbone is the lateral itself at the
+        FPN width.  'gram': one C -> F product per pixel; 'pair': V at width F instead of C (F / C of its multiplies and of
+        the S V product) and ONE C -> F conv of x over the map.  'dir' / 're': the stored form, then _lateral_of_deferred."""
+        e = self.e
+        hh, hw = x.h // 2, x.w // 2
+        wins = lambda t: [t.window(0, hh, 0, hw), t.window(hh, t.h, 0, hw), t.window(0, hh, hw, t.w), t.window(hh, t.h, hw, t.w)]
+        names = ["%s.feat_patchconv_%s_nonlocal" % (p, q) for q in ("lt", "lb", "rt", "rb")]
+        a = self.gl_assoc(assoc, self.sd[names[0] + ".theta.weight"].shape[0], x.c, (x.h - hh) * (x.w - hw))
+        if a not in ("gram", "pair"):
+            return self._lateral_of_deferred(lateral, self.gl_fusion(p, x, a, fold=False, defer=True))
+        out = e.tensor(x.n, x.h, x.w, self.sd[lateral + ".weight"].shape[0])
+        self.nonlocal_gemm(names, wins(x), wins(out), a, post=self._gl_post(p, names, x, wins, lateral))
+        return out
 
     def gl_materialise(self, d: GlDeferred) -> TView:
         """x + channel_conv(st) as a stored tensor (gl_fusion's own last step)."""
@@ -432,13 +496,28 @@ class ResDetBuilder:
         conv = lambda name, x, stride, pad: e.conv(x, self._pack(name, [self._plain_part(name)], x.c), stride, pad, "none")
         inputs = list(inputs)
         mode = ("on_input" if add_extra_convs is True else add_extra_convs) if num_outs > n_lat else None
-        if mode == "on_input" and isinstance(inputs[-1], GlDeferred):       # the extra level reads C5 itself
-            inputs[-1] = self.gl_materialise(inputs[-1])
-        for i in range(start_level):                                         # levels the FPN does not read at all
-            inputs[i] = None
-        lat = [self._lateral_of_deferred("%s.lateral_convs.%d.conv" % (p, i), inputs[i + start_level])
-               if isinstance(inputs[i + start_level], GlDeferred)
-               else conv("%s.lateral_convs.%d.conv" % (p, i), inputs[i + start_level], 1, 0) for i in range(n_lat)]
+        # A/B switch for measurements: how much of the plug-in's linear tail rides in its per-window matrices
+        #   "window" (default): all of it, gl_lateral;  "deferred": channel_conv composed with the lateral conv, per pixel;
+        #   "stored": the plug-in output as a tensor, then the lateral conv
+        tail = "stored" if os.environ.get("GLSDET_NO_LATERAL_FOLD") else os.environ.get("GLSDET_GL_TAIL", "window")
+        for i, inp in enumerate(inputs):
+            if isinstance(inp, GlPending):
+                last = i == len(inputs) - 1
+                if i < start_level:
+                    inputs[i] = None                                         # a level the FPN does not read at all
+                elif (mode == "on_input" and last) or (inp.p + ".channel_conv.weight") not in self.sd or tail == "stored":
+                    inputs[i] = self.gl_fusion(inp.p, inp.x, inp.assoc)      # stored: the extra level reads C5 itself / BaseConv channel_cat
+                elif tail == "deferred":
+                    inputs[i] = self.gl_fusion(inp.p, inp.x, inp.assoc, defer=True)
+        lat = []
+        for i in range(n_lat):
+            inp, name = inputs[i + start_level], "%s.lateral_convs.%d.conv" % (p, i)
+            if isinstance(inp, GlPending):
+                lat.append(self.gl_lateral(inp.p, inp.x, name, inp.assoc))
+            elif isinstance(inp, GlDeferred):
+                lat.append(self._lateral_of_deferred(name, inp))
+            else:
+                lat.append(conv(name, inp, 1, 0))
         for i in range(n_lat - 1, 0, -1):
             e.upsample_add(lat[i], lat[i - 1])
         outs = [conv("%s.fpn_convs.%d.conv" % (p, i), lat[i], 1, 1) for i in range(n_lat)]
@@ -581,8 +660,7 @@ class HipGflDetector:
         if levels is None:
             levels = [i for i in range(len(stages)) if "neck.gl_fusion.%d.feat_patchconv_lt_nonlocal.theta.weight" % i in self.sd]
         for i in levels:                       # GLFusionFPN: the plug-in sits on the FPN inputs (C3..C5), before the laterals
-            stages[i] = b.gl_fusion("neck.gl_fusion.%d" % i, stages[i], c["gl_assoc"],
-                                    defer=i >= c["start_level"] and not os.environ.get("GLSDET_NO_LATERAL_FOLD"))
+            stages[i] = GlPending("neck.gl_fusion.%d" % i, stages[i], c["gl_assoc"])
         feats = b.fpn("neck", stages, c["start_level"], c["num_outs"],
                       c["add_extra_convs"], c["relu_before_extra_convs"])
         if self.kind == "gfl":

@@ -638,24 +638,25 @@ def test_gl_fusion_plugin_vs_oracle(engines, mode, assoc, c, hw, cat):
 @pytest.mark.gpu
 @pytest.mark.parametrize("mode", ["f32", "f16"])
 def test_gl_channel_conv_folded_into_the_fpn_lateral(monkeypatch, mode):
-    """lateral(x + channel_conv(st)) as two 1x1 convs to the FPN width (ResDetBuilder._lateral_of_deferred) against the
-    stored plug-in output followed by the lateral conv: same raw head outputs up to the rounding of the tensor that is no
-    longer stored; `add_extra_convs='on_input'` (the extra level reads C5 itself) materialises it again."""
+    """The linear tail of the plug-in (conv_out bias, channel_conv, residuals, FPN lateral conv) in its three forms -- stored
+    plug-in output + lateral conv; two 1x1 convs to the FPN width (_lateral_of_deferred); all of it in the per-window
+    matrices (gl_lateral, 'pair' and 'gram') -- same raw head outputs up to the rounding of the tensors that are no longer
+    stored; `add_extra_convs='on_input'` (the extra level reads C5 itself) stores it again."""
     from glsdet_amd.resdet import HipGflDetector
     x = O.synth_input((1, 3, 128, 160), 7)
     sd = calibrated_resdet_sd("mpdet", 1, x, gl_fusion=True)
     outs = {}
-    for fold in (False, True):
-        if fold:
-            monkeypatch.delenv("GLSDET_NO_LATERAL_FOLD", raising=False)
-        else:
-            monkeypatch.setenv("GLSDET_NO_LATERAL_FOLD", "1")
-        gc, gr = HipGflDetector("mpdet", sd, dtype=mode).forward_raw(x.cuda())
-        outs[fold] = [t.cpu() for t in gc + gr]
-    scale = max(float(t.abs().max()) for t in outs[False])
-    diff = max(float((a - b).abs().max()) for a, b in zip(outs[False], outs[True]))
-    print("lateral fold %s: folded-vs-stored %.2e of max |logit| %.2f" % (mode, diff / scale, scale))
-    assert diff <= (2e-4 if mode == "f32" else 2e-2) * scale
+    for tail in ("stored", "deferred", "window", "window-gram"):
+        monkeypatch.setenv("GLSDET_GL_TAIL", tail.split("-")[0])
+        cfg = dict(gl_assoc="gram") if tail.endswith("gram") else {}       # (the small maps of this input pick 'pair' on their own)
+        gc, gr = HipGflDetector("mpdet", sd, dtype=mode, **cfg).forward_raw(x.cuda())
+        outs[tail] = [t.cpu() for t in gc + gr]
+    scale = max(float(t.abs().max()) for t in outs["stored"])
+    for tail in ("deferred", "window", "window-gram"):
+        diff = max(float((a - b).abs().max()) for a, b in zip(outs["stored"], outs[tail]))
+        print("plug-in tail %s %s: vs stored %.2e of max |logit| %.2f" % (tail, mode, diff / scale, scale))
+        assert diff <= (3e-4 if mode == "f32" else 2e-2) * scale
+    monkeypatch.delenv("GLSDET_GL_TAIL", raising=False)
     a = HipGflDetector("mpdet", sd, dtype="f32", add_extra_convs="on_input").forward_raw(x.cuda())
     monkeypatch.setenv("GLSDET_NO_LATERAL_FOLD", "1")
     b = HipGflDetector("mpdet", sd, dtype="f32", add_extra_convs="on_input").forward_raw(x.cuda())
