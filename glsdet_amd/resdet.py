@@ -134,18 +134,20 @@ class ResDetBuilder:
         return self._packed[key]
 
     @staticmethod
-    def gl_assoc(assoc: str, ci: int, C_: int, n: int) -> str:
+    def gl_assoc(assoc: str, ci: int, C_: int, n: int, R: Optional[int] = None) -> str:
         """The association nonlocal_gemm uses for quadrants of n pixels ('auto': the fewest multiplies; GLSDET_GL_ASSOC
-        overrides)."""
+        overrides).  R: width of the linear maps taken in behind the block (gl_lateral: the FPN width), None = none."""
         if assoc != "auto":
             return assoc
         Ca = C_ + GL_AUG
-        cost = {"re": 4 * ci * C_ * n + ci * ci * n + C_ * ci * ci, "dir": 2 * n * n * ci + 3 * n * ci * C_,
-                "gram": Ca * Ca * n + C_ * Ca * Ca + C_ * C_ * Ca + n * C_ * C_,
-                "pair": n * Ca * Ca + 2 * n * n * Ca + C_ * n * Ca}
-        if n < 2 * C_:
-            # 'gram' pays two C^3 products and a bias product per window: by the multiply count it ties with 'pair' around
-            # n = C, measured (config 3 as named, 50 x 84 level: C = 1024, n = 1050) it is 1006 us against 927
+        Ro = C_ if R is None else R
+        cost = {"gram": Ca * Ca * n + Ro * Ca * Ca + Ro * C_ * Ca + n * C_ * Ro,
+                "pair": n * Ca * Ca + n * n * Ca + Ro * n * Ca + n * n * Ro + (n * C_ * Ro if R is not None else 0)}
+        if R is None:
+            cost.update({"re": 4 * ci * C_ * n + ci * ci * n + C_ * ci * ci, "dir": 2 * n * n * ci + 3 * n * ci * C_})
+        if Ro == C_ and n < 2 * C_:
+            # at full width 'gram' pays two C^3 products and a bias product per window: by the multiply count it ties with
+            # 'pair' around n = C, measured (config 3 as named, 50 x 84 level: C = 1024, n = 1050) it is 1006 us against 927
             del cost["gram"]
         return os.environ.get("GLSDET_GL_ASSOC") or min(cost, key=cost.get)
 
@@ -372,9 +374,10 @@ class ResDetBuilder:
         with the constants A = Wout [Wg | bg] (C x C+a) and B = [Wphi | bphi]^T [Wtheta | btheta] ((C+a) x (C+a)) folded
         on the host in float64: the per-pixel product contracts over exactly C channels of the window where it lies (no
         row-major copy), its bias is a vector a 1-pixel product of the plan writes.
-        post (see _gl_post): the linear maps behind the block taken into the per-window matrices,
-            Qm2 = Wp Qm + Wr  (R x C),   d2 = Wp T B[:, C] + bias_q,   out = [x +] x Qm2^T + d2       (R = C or the FPN width)
-        -- one more R x C x C product per window instead of C x C (and R x C) products per pixel of the map."""
+        post (see _gl_post): the linear maps behind the block taken into the per-window matrices from the front,
+            T2 = (Wp A) G'  (R x C+a),   Qm2 = T2 B[:, :C] + Wr,   d2 = T2 B[:, C] + bias_q,   out = [x +] x Qm2^T + d2
+        (R = C or the FPN width): the same three small products, at the OUTPUT width, instead of C x C (and R x C) products per
+        pixel of the map."""
         e = self.e
         C_ = xs[0].c
         Ca = C_ + GL_AUG
@@ -391,28 +394,26 @@ class ResDetBuilder:
         G = {j: e.matrix(Ca, Ca) for j in jobs}
         e.conv_many([Xt[j] for j in jobs], [e.as_weight(Xt[b, q], alpha=1.0 / Ns[q]) for (b, q) in jobs], 1, 0, "none",
                     [G[j] for j in jobs])
-        T = {j: e.matrix(C_, Ca) for j in jobs}
-        e.conv_many([consts(ps[q])[0] for (b, q) in jobs], [e.as_weight(G[j]) for j in jobs], 1, 0, "none", [T[j] for j in jobs])
         R = C_ if post is None else post["Wp"].shape[0]
+        if post is not None:
+            # the linear maps behind the block go in FRONT: A2 = Wp A (R x C+a, a constant), so T2 = A2 G' is already at the
+            # output width, Qm2 = T2 B[:, :C] + Wr and d2 = T2 B[:, C] + bias_q -- the same three products as without them
+            A2 = {}
+            for q, p in enumerate(ps):
+                wout = self.sd[p + ".conv_out.weight"].double().reshape(C_, -1)
+                A2[q] = self._wmat("%s.gA2.%d" % (post["key"], q), (post["Wp"] @ wout @ self._gl_aug(p, "g", C_)).float())
+            WrM = self._wmat(post["key"] + ".WrM", post["Wr"].float())
+            bq = {q: post["bias"](q).float() for q in range(len(ps))}
+        T = {j: e.matrix(R, Ca) for j in jobs}
+        e.conv_many([(consts(ps[q])[0] if post is None else A2[q]) for (b, q) in jobs], [e.as_weight(G[j]) for j in jobs], 1, 0, "none",
+                    [T[j] for j in jobs])
         Qm = {j: e.matrix(R, C_) for j in jobs}
         d = {j: e.bias_vector(R) for j in jobs}
-        if post is None:
-            e.conv_many([T[j] for j in jobs], [consts(ps[q])[4] for (b, q) in jobs], 1, 0, "none", [Qm[j] for j in jobs])
-            e.conv_many([rows(consts(ps[q])[3], C_, C_ + 1) for (b, q) in jobs],
-                        [e.as_weight(T[b, q], bias=bout(ps[q])) for (b, q) in jobs], 1, 0, "none", [d[j] for j in jobs])
-        else:
-            key = post["key"]
-            WpM = self._wmat(key + ".WpM", post["Wp"].float())
-            WrM = self._wmat(key + ".WrM", post["Wr"].float())
-            # Q'^T (rows 0..C: the C columns of Qm and the bias column) = B^T T^T
-            QT = {j: e.matrix(C_ + 8, C_) for j in jobs}
-            e.conv_many([rows(consts(ps[q])[3], 0, C_ + 8) for (b, q) in jobs], [e.as_weight(T[j]) for j in jobs], 1, 0, "none",
-                        [QT[j] for j in jobs])
-            e.conv_many([WpM for _ in jobs], [e.as_weight(rows(QT[j], 0, C_)) for j in jobs], 1, 0, "none",
-                        [Qm[j] for j in jobs], [WrM for _ in jobs])
-            pkd = {q: self._pack("%s.d2.%d" % (key, q), [(post["Wp"].float().reshape(R, C_, 1, 1), torch.ones(R), post["bias"](q).float())], C_)
-                   for q in range(len(ps))}
-            e.conv_many([rows(QT[j], C_, C_ + 1) for j in jobs], [pkd[q] for (b, q) in jobs], 1, 0, "none", [d[j] for j in jobs])
+        e.conv_many([T[j] for j in jobs], [consts(ps[q])[4] for (b, q) in jobs], 1, 0, "none", [Qm[j] for j in jobs],
+                    None if post is None else [WrM for _ in jobs])
+        e.conv_many([rows(consts(ps[q])[3], C_, C_ + 1) for (b, q) in jobs],
+                    [e.as_weight(T[b, q], bias=(bout(ps[q]) if post is None else bq[q])) for (b, q) in jobs], 1, 0, "none",
+                    [d[j] for j in jobs])
         res_x = post is None or post["res_x"]
         e.conv_many([xq[j] for j in jobs], [e.as_weight(Qm[j], bias_dev=d[j]) for j in jobs], 1, 0, "none",
                     [oq[j] for j in jobs], [xq[j] for j in jobs] if res_x else None)
@@ -456,7 +457,8 @@ class ResDetBuilder:
         hh, hw = x.h // 2, x.w // 2
         wins = lambda t: [t.window(0, hh, 0, hw), t.window(hh, t.h, 0, hw), t.window(0, hh, hw, t.w), t.window(hh, t.h, hw, t.w)]
         names = ["%s.feat_patchconv_%s_nonlocal" % (p, q) for q in ("lt", "lb", "rt", "rb")]
-        a = self.gl_assoc(assoc, self.sd[names[0] + ".theta.weight"].shape[0], x.c, (x.h - hh) * (x.w - hw))
+        a = self.gl_assoc(assoc, self.sd[names[0] + ".theta.weight"].shape[0], x.c, (x.h - hh) * (x.w - hw),
+                          R=self.sd[lateral + ".weight"].shape[0])
         if a not in ("gram", "pair"):
             return self._lateral_of_deferred(lateral, self.gl_fusion(p, x, a, fold=False, defer=True))
         out = e.tensor(x.n, x.h, x.w, self.sd[lateral + ".weight"].shape[0])
