@@ -36,6 +36,7 @@ class NetBuilder:
         self.e = eng
         self.sd = {k: v.detach().cpu() for k, v in sd.items()}
         self._packed = {}
+        self._override = {}     # BaseConv name -> (w, scale, bias) replacing the state_dict's (compose_1x1_input)
         self.trace = None       # tests: dict name -> NCHW fp32 snapshot of every stored tensor (eager emission only)
 
     def _rec(self, name: str, v: TView, c0: int = 0, c1: Optional[int] = None):
@@ -47,6 +48,8 @@ class NetBuilder:
 
     # ------------------------------------------------------------------ weights
     def _bn_part(self, p: str):
+        if p in self._override:            # a BaseConv whose weights were composed with the linear conv in front of it
+            return self._override[p]
         s, b = fold_bn(self.sd[p + ".bn.weight"], self.sd[p + ".bn.bias"],
                        self.sd[p + ".bn.running_mean"], self.sd[p + ".bn.running_var"], BN_EPS)
         return self.sd[p + ".conv.weight"], s, b
@@ -320,8 +323,23 @@ class NetBuilder:
             self._rec(p + ".conv_out", y)
         return ys
 
-    def patch_conv(self, p: str, x: TView, stride: int, with_nonlocal: bool, out: Optional[TView] = None) -> TView:
-        """Patch_Conv / Patch_Conv_NonLocal (Identity_Conv.py:267-387)."""
+    def compose_1x1_input(self, consumer: str, c0: int, c1: int, lin: str):
+        """The 1x1 BaseConv `consumer` reads channels [c0, c1) of its (concatenated) input from the linear 1x1 conv `lin`
+        (weight + bias, nothing in between): replace them by lin's OWN input channels, W' = [W[:, :c0] | W[:, c0:c1] Wlin |
+        W[:, c1:]] and the bias through the BN fold -- lin is then never launched (float64 on the host, exact)."""
+        w, s, b = self._bn_part(consumer)
+        wl = self.sd[lin + ".weight"].double().reshape(self.sd[lin + ".weight"].shape[0], -1)
+        bl = self.sd[lin + ".bias"].double()
+        W = w.double().reshape(w.shape[0], -1)
+        assert W.shape[1] >= c1 and c1 - c0 == wl.shape[0]
+        Wn = torch.cat([W[:, :c0], W[:, c0:c1] @ wl, W[:, c1:]], 1)
+        bn = b.double() + s.double() * (W[:, c0:c1] @ bl)
+        self._override[consumer] = (Wn.float().reshape(w.shape[0], -1, 1, 1), s, bn.float())
+
+    def patch_conv(self, p: str, x: TView, stride: int, with_nonlocal: bool, out: Optional[TView] = None,
+                   z_out: Optional[TView] = None) -> TView:
+        """Patch_Conv / Patch_Conv_NonLocal (Identity_Conv.py:267-387).  z_out: write the [lr | tb] tensor there and stop
+        before the linear channel_conv (the caller composed it with its readers: compose_1x1_input)."""
         mid = self.conv_out_channels(p + ".feat_patchconv_lt")
         hh, hw = x.h // 2, x.w // 2               # int(H/2): floor split
         osz = lambda v: (v + 2 - 3) // stride + 1
@@ -339,7 +357,7 @@ class NetBuilder:
             self.nonlocal_blocks(["%s.feat_patchconv_%s_nonlocal" % (p, nm) for nm in names],
                                  [quads[nm][1] for nm in names])
         H, W = ht + hb, wl + wr
-        Z = self.e.tensor(x.n, H, W, 2 * mid)
+        Z = self.e.tensor(x.n, H, W, 2 * mid) if z_out is None else z_out
         lr, tb = Z.channels(0, mid), Z.channels(mid, 2 * mid)
         self.cba_group([p + ".feat_patchconv_l", p + ".feat_patchconv_r"],
                        [Q.window(0, H, 0, wl), Q.window(0, H, wl, W)],
@@ -347,6 +365,8 @@ class NetBuilder:
         self.cba_group([p + ".feat_patchconv_t", p + ".feat_patchconv_b"],
                        [Q.window(0, ht, 0, W), Q.window(ht, H, 0, W)],
                        outs=[tb.window(0, ht, 0, W), tb.window(ht, H, 0, W)])
+        if z_out is not None:
+            return Z
         if self.has(p + ".channel_conv.weight"):
             return self.plain(p + ".channel_conv", Z, out=out)
         return self.cba(p + ".channel_conv", Z, out=out)
@@ -567,7 +587,13 @@ class NetBuilder:
         h3, w3, h4, w4, h5, w5 = H // 8, W // 8, H // 16, W // 16, H // 32, W // 32
         e = self.e
         extra = 1 if gl else 0
-        cat_p4 = e.tensor(n, h4, w4, (2 + extra) * c4)      # [up(P5) | feat2 | (feat1_patch)]
+        # Patch_conv_feat1's linear channel_conv (2 mid -> c4) is read by C3_p4.conv1 / conv2 only (1x1 BaseConvs on the concat):
+        # composed with them, the concat holds the block's [lr | tb] tensor instead and the channel_conv is never launched
+        pc1 = p + ".Patch_conv_feat1"
+        zc = 2 * self.conv_out_channels(pc1 + ".feat_patchconv_lt") if gl else 0
+        fold1 = gl and self.trace is None and not os.environ.get("GLSDET_NO_PATCH_FOLD") and self.has(pc1 + ".channel_conv.bias") \
+            and zc < c4 and not self.is_depthwise(p + ".C3_p4.conv1")
+        cat_p4 = e.tensor(n, h4, w4, 2 * c4 + (zc if fold1 else extra * c4))      # [up(P5) | feat2 | (feat1_patch)]
         cat_p3 = e.tensor(n, h3, w3, 2 * c3)                # [up(P4) | feat1]
         cat_n3 = e.tensor(n, h4, w4, (2 + extra) * c3)      # [down(P3) | P4 | (feat2_patch)]
         cat_n4 = e.tensor(n, h5, w5, 2 * c4)                # [down(P4) | P5]
@@ -575,7 +601,12 @@ class NetBuilder:
                                                  "dark4": cat_p4.channels(c4, 2 * c4)})
         feat1, feat2, feat3 = f["dark3"], f["dark4"], f["dark5"]
         if gl:
-            self.patch_conv(p + ".Patch_conv_feat1", feat1, 2, True, out=cat_p4.channels(2 * c4, 3 * c4))
+            if fold1:
+                for cv in ("conv1", "conv2"):
+                    self.compose_1x1_input("%s.C3_p4.%s" % (p, cv), 2 * c4, 3 * c4, pc1 + ".channel_conv")
+                self.patch_conv(pc1, feat1, 2, True, z_out=cat_p4.channels(2 * c4, 2 * c4 + zc))
+            else:
+                self.patch_conv(pc1, feat1, 2, True, out=cat_p4.channels(2 * c4, 3 * c4))
             self.patch_conv(p + ".Patch_conv_feat2", feat2, 1, False, out=cat_n3.channels(2 * c3, 3 * c3))
         P5 = self.cba(p + ".lateral_conv0", feat3, out=cat_n4.channels(c4, 2 * c4))
         e.resample(P5, 2, out=cat_p4.channels(0, c4))

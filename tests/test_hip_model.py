@@ -344,6 +344,35 @@ def test_p5_identity_folded_into_the_head_stem(golden, shapes, monkeypatch, mode
     assert torch.equal(got[False][0], got[True][0]) and torch.equal(got[False][1], got[True][1])
 
 
+@pytest.mark.parametrize("mode", ["f32", "f16"])
+@pytest.mark.parametrize("tag", ["gl_s_seed0", "gl_tiny_seed0"])
+def test_patch_channel_conv_composed_with_its_readers(golden, shapes, monkeypatch, mode, tag):
+    """Patch_conv_feat1.channel_conv (linear 1x1) composed with C3_p4.conv1 / conv2, the 1x1 BaseConvs that alone read it
+    through the concat (NetBuilder.compose_1x1_input): same logits as the launched form, against the REFERENCE's logits, one
+    op fewer."""
+    from glsdet_amd.detector import HipDetector
+    meta, sd, x, outs, _ = model_case(golden, shapes, tag)
+    got, nops = {}, {}
+    for fold in (False, True):
+        if fold:
+            monkeypatch.delenv("GLSDET_NO_PATCH_FOLD", raising=False)
+        else:
+            monkeypatch.setenv("GLSDET_NO_PATCH_FOLD", "1")
+        det = HipDetector("gl", sd, dtype=mode)
+        got[fold] = [g.cpu() for g in det.forward_raw(x.cuda())]
+        nops[fold] = det.compile(x.shape[0], x.shape[2], x.shape[3], dict(conf_thres=0.3, nms_thres=0.5)).plan.num_ops
+    scale = max(float(w.abs().max()) for w in outs)
+    diff = max(float((a - b).abs().max()) for a, b in zip(got[False], got[True]))
+    errs = {f: max(float((g - w).abs().max()) for g, w in zip(got[f], outs)) for f in (False, True)}
+    print("patch fold %s %s: folded-vs-launched %.2e, vs reference launched %.2e folded %.2e (max |logit| %.2f)"
+          % (tag, mode, diff, errs[False], errs[True], scale))
+    assert nops[True] == nops[False] - 1, nops
+    if mode == "f32":
+        assert diff <= 1e-4 * scale
+    else:
+        assert diff <= 3e-2 * scale and errs[True] <= max(1.25 * errs[False], 0.10 * scale)
+
+
 def test_autotuned_plan_matches_default(golden, shapes):
     """build-time autotune only picks among equivalent kernels: same logits (bitwise for the
     fp16 path up to accumulation order -> compare with the per-op fp16 tolerance)"""
