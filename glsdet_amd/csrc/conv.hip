@@ -731,6 +731,10 @@ static int build_conv_op(const glsdet_conv_desc* d, int hint, OpRecord& op, cons
     GLS_FAIL(GLSDET_E_ARG, "conv2d: the weight-stationary 1x1 kernel does not apply to this problem");
   }
   if (hint == 6 || hint == 7) GLS_FAIL(GLSDET_E_ARG, "conv2d: tile_hint 6 / 7 (persistent LDS-DMA halo kernel) no longer exist");
+  if (hint >= 16 && hint < 64) {            // persistent LDS-DMA GEMM kernel for 1x1 convs (conv_gemm.hip), variant hint - 16
+    if (conv_gemm_try(a, xdt, ydt, hint, &op) == 0) return 0;
+    GLS_FAIL(GLSDET_E_ARG, "conv2d: the persistent 1x1 kernel (variant %d) does not apply to this problem", hint - 16);
+  }
   if (conv_halo_try(a, xdt, ydt, hint, &op) == 0) return 0;
   if (hint == 2 || hint == 4 || hint == 5 || (hint >= 8 && hint <= 13)) GLS_FAIL(GLSDET_E_ARG, "conv2d: the halo kernel does not apply to this problem");
 
@@ -1030,7 +1034,7 @@ static int conv_tune(const glsdet_conv_desc* d, const glsdet_conv_chain* c, void
   if (!d || !best_hint) GLS_FAIL(GLSDET_E_ARG, "conv2d_tune: null argument");
   hipStream_t st = (hipStream_t)stream;
   // (6 / 7, the persistent LDS-DMA halo kernel, is not offered: slower than 8 / 9 on every layer measured)
-  const int hints[] = {2, 4, 5, 8, 9, 10, 11, 12, 13, 3, (128 << 16) | 128, (64 << 16) | 128, (64 << 16) | 64, (32 << 16) | 128,
+  const int hints[] = {2, 4, 5, 8, 9, 10, 11, 12, 13, 3, 16, 20, 22, 24, 25, 29, (128 << 16) | 128, (64 << 16) | 128, (64 << 16) | 64, (32 << 16) | 128,
                        (64 << 16) | 64 | 0x8000, (64 << 16) | 128 | 0x8000, (128 << 16) | 128 | 0x8000, (128 << 16),
                        (128 << 16) | 0x8000};
   std::vector<OpRecord> ops;

@@ -517,5 +517,7 @@ int conv_halo_multi_try(const ConvArgsN& m, int xdt, int ydt, int hint, OpRecord
 int conv_bneck_try(const BneckArgs& b, int dt, int hint, OpRecord* op);
 // weight-stationary persistent 1x1 kernel (conv1x1.hip), tile_hint 3; returns 1 if it does not apply
 int conv1x1_ws_try(const ConvArgs& a, int xdt, int ydt, OpRecord* op);
+// persistent LDS-DMA GEMM kernel for 1x1 convs (conv_gemm.hip), tile_hint 16 + variant; returns 1 if it does not apply
+int conv_gemm_try(const ConvArgs& a, int xdt, int ydt, int hint, OpRecord* op);
 
 }  // namespace glsdet

@@ -1,0 +1,690 @@
+// 1x1 convolution (stride 1, no padding) = GEMM over pixels, as a PERSISTENT LDS-DMA stream.
+//
+// Reference: every 1x1 BaseConv / nn.Conv2d of the path -- drone/models/base/baseConv.py:6-19 (conv + BN + act),
+// drone/models/base/darknet.py:66-112 (CSPLayer conv1 | conv2 / conv3, Bottleneck conv1), the theta | phi | g projections of
+// Identity_Conv.py:126-173, the ResNet Bottleneck's conv1 / conv3 (ufp/mmdet/models/backbones/resnet.py:263-303).
+//
+// Why a kernel of its own (round 3): on the flat-pixel kernel (conv.hip) these layers ran at 8 % of the MFMA peak -- a
+// 64x64 tile issues ~690 instructions for its 16 MFMAs per wave (tile decode, im2col addressing, register-staged
+// operands, an LDS-transposed epilogue with 35 % bank conflicts), every K step is a dependent round trip, and a launch
+// is one or two rounds of such short-lived workgroups (profiles/r02_pmc).  Here
+//   * a workgroup is persistent: kernel arguments, buffer descriptors, its cout tile's weight row addresses and
+//     scale | bias are set up ONCE; it then walks pixel tiles (pixel tile = PX_T consecutive output pixels);
+//   * both operands travel global -> LDS by DMA (`buffer_load ... lds`, no staging registers, no ds_write) in K panels of
+//     KB bytes through a ring of NS stages that runs ACROSS tile boundaries: the panels of the next tile are in flight
+//     while this one is multiplied and stored.  Waits are counted by hand (`s_waitcnt vmcnt(N)` + raw `s_barrier`, one
+//     per stage); rows are unpadded (a DMA writes 1 KiB of consecutive LDS) with the XOR swizzle of conv_halo.hip's ring
+//     on the source side and in the fragment reads (conflict free for the 16-lane groups of ds_read_b128);
+//   * WRES variants keep the whole [CO_T x K] weight tile resident in LDS (K <= 512 bytes) and stream pixels only;
+//   * the epilogue never touches LDS and has no barrier: scale / bias / activation on the accumulator, fp16 pairs packed,
+//     ONE v_permlane32_swap per dword so that a lane holds the 8 consecutive output channels (16 bytes) of its pixel, one
+//     global_store_dwordx4 per 16 bytes.  A residual tile comes in by DMA as well (each lane's slot = the chunk it adds),
+//     so that no register waits on memory across the loop and the compiler never drains the ring with a vmcnt(0).
+// Work split: the workgroups of a launch are dealt to the XCDs round-robin (blockIdx % 8); XCD x owns the pixel tiles
+// == x (mod 8) and runs all cout tiles of a pixel tile side by side, so the pixel rows they share are fetched into that
+// XCD's L2 once.
+#include <stdlib.h>
+
+#include "conv_common.h"
+
+namespace glsdet {
+
+template <int N>
+__device__ __forceinline__ void gemm_wait_barrier() {
+  asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void gemm_wait_vm() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// lanes 32..63 of a <-> lanes 0..31 of b.  Inline asm in the fp32 (residual) path: with the builtin hipcc (ROCm 7.2) kept ONE
+// of the four swaps of an unrolled per-element loop (found by the fuzz test: channel 0 of every chunk right, 1..7 wrong);
+// the s_nops cover the VALU -> permlane-swap hazards the compiler's recogniser does not see through inline asm
+__device__ __forceinline__ void lane32_swap(float& a, float& b) {
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+}
+
+// s_waitcnt vmcnt(BASE + k * UNIT) [+ s_barrier], k = 0 .. KMAX (wave-uniform, immediates only on this ISA)
+template <int BASE, int UNIT, int KMAX, bool BARRIER>
+__device__ __forceinline__ void gemm_wait_k(int k) {
+  if constexpr (KMAX == 0) {
+    if constexpr (BARRIER) gemm_wait_barrier<BASE>();
+    else gemm_wait_vm<BASE>();
+  } else {
+    if (k >= KMAX) {
+      if constexpr (BARRIER) gemm_wait_barrier<BASE + KMAX * UNIT>();
+      else gemm_wait_vm<BASE + KMAX * UNIT>();
+    } else {
+      gemm_wait_k<BASE, UNIT, KMAX - 1, BARRIER>(k);
+    }
+  }
+}
+
+struct GemmGeom {
+  int n_px_tiles;      // ceil(M / PX_T)
+  int np;              // K panels of KB bytes
+  int nwalk;           // pixel-tile walkers per XCD and cout tile
+};
+
+template <typename TO>
+__host__ __device__ constexpr int gemm_res_bytes(int co_t, int px_t) { return co_t * px_t * (int)sizeof(TO); }
+
+template <typename T, typename TO, int CO_T, int PX_T, int NS, int KB, bool WRES>
+__global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvArgs a, const GemmGeom gm) {
+  constexpr int ES = (int)sizeof(T), VEC = 16 / ES;
+  constexpr int WCO = CO_T >= 64 ? 2 : 1, WPX = 4 / WCO;
+  constexpr int WT_CO = CO_T / WCO, WT_PX = PX_T / WPX;
+  constexpr int TM = WT_CO / 32, TN = WT_PX / 32;
+  constexpr int CPRW = KB / 16;                    // 16-byte chunks per row
+  constexpr int RPL = 256 / KB;                    // rows per 256 bytes of LDS
+  constexpr int RPI = 64 / CPRW;                   // rows one DMA instruction fills
+  constexpr int NIW = CO_T / (4 * RPI), NIX = PX_T / (4 * RPI);
+  constexpr int NI = (WRES ? 0 : NIW) + NIX;       // DMA instructions per wave and stage
+  constexpr int W_ST = CO_T * KB, X_ST = PX_T * KB, STAGE = (WRES ? 0 : W_ST) + X_ST;
+  constexpr int NKK = KB / 32;                     // MFMA k steps per panel
+  constexpr int OV = 16 / (int)sizeof(TO);         // output channels per 16-byte chunk
+  constexpr int NR = TM * TN * (32 / (2 * OV));    // residual chunks (= DMA instructions) per wave and tile
+  static_assert(TM >= 1 && TN >= 1 && NIW >= 1 && NIX >= 1 && NS >= 3, "tile shape");
+  static_assert(CO_T % (4 * RPI) == 0 && PX_T % (4 * RPI) == 0, "whole DMA pieces");
+  constexpr int NST = TM * TN * (32 / OV);         // 16-byte stores per lane and tile (always issued: out-of-range lanes store out of range)
+  constexpr int KEND_ = (63 - NI * (NS - 2)) / NST;                        // store groups a six-bit vmcnt can still allow for
+  constexpr int KEND = KEND_ < NS - 1 ? KEND_ : NS - 1;
+  static_assert(NI * (NS - 2) <= 63 && KEND >= 0 && NI * (NS - 1) <= 63, "vmcnt is six bits");
+
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int np = gm.np;
+
+  // ---- this workgroup: cout tile, walker, XCD class
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7, local = bid >> 3;
+  const int walker = gls_div(local, a.nco_mul, a.nco_sh);
+  const int co0 = (local - walker * a.n_co_tiles) * CO_T;
+  const int first_tile = walker * 8 + xcd, tile_step = 8 * gm.nwalk;
+  if (first_tile >= gm.n_px_tiles) return;                       // (uniform: before any barrier)
+  const int my_tiles = (gm.n_px_tiles - 1 - first_tile) / tile_step + 1;
+  const int total = my_tiles * np;
+
+  unsigned char* sW = smem + NS * STAGE;                         // WRES: [np][CO_T][KB]
+  unsigned char* sSB = sW + (WRES ? np * W_ST : 0);              // scale | bias of the cout tile
+  unsigned char* sR = sSB + CO_T * 8;                            // residual tile (DMA), wave-private slots
+
+  const auto xrs = gls_make_rsrc(a.x_lo, a.x_bytes);
+  const auto wrs = gls_make_rsrc(a.w, a.w_bytes);
+
+  f32x4 sb_s = {0.f, 0.f, 0.f, 0.f}, sb_b = {0.f, 0.f, 0.f, 0.f};
+  if (tid < CO_T / 4 && co0 + tid * 4 < a.cout_pad) {
+    sb_s = *reinterpret_cast<const f32x4*>(a.scale + co0 + tid * 4);
+    sb_b = *reinterpret_cast<const f32x4*>(a.bias + co0 + tid * 4);
+  }
+
+  // ---- DMA lane geometry: instruction q of this wave fills rows RPI * (wave + 4 q) .. + RPI - 1; lane -> (row, slot);
+  // the slot holds source chunk slot ^ swz(row), swz(row) = (row / RPL) % CPRW (independent of q)
+  const int r_in = lane / CPRW, c_in = lane % CPRW;
+  const int ch = c_in ^ (((RPI * wave + r_in) / RPL) & (CPRW - 1));
+  const int kbytes = a.Cin * ES;
+  const bool ragged = (kbytes % KB) != 0;                        // the last panel is partly beyond the input channels
+  const bool lane_tail_ok = ch * 16 + (np - 1) * KB < kbytes;
+  unsigned wd[NIW];
+#pragma unroll
+  for (int q = 0; q < NIW; ++q) {
+    const int row = RPI * (wave + 4 * q) + r_in;
+    wd[q] = (co0 + row) < a.cout_pad ? (unsigned)(((co0 + row) * a.kpad + ch * VEC) * ES) : GLS_OOB;
+  }
+  const int HoWo = a.Ho * a.Wo;
+  // element offset of output pixel p in a view (x has the output's pixel geometry: 1x1, stride 1, no padding)
+  auto pix = [&](int p, long sn, long sh, long sw, int lin) __attribute__((always_inline)) -> long {
+    if (lin) return (long)p * sw;
+    const int n = gls_div(p, a.howo_mul, a.howo_sh), rem = p - n * HoWo;
+    const int ho = gls_div(rem, a.wo_mul, a.wo_sh), wo = rem - ho * a.Wo;
+    return (long)n * sn + (long)ho * sh + (long)wo * sw;
+  };
+
+  // ---- issue side: runs NS - 1 stages ahead of the compute side, across tile boundaries
+  int it_i = 0, it_p = 0, it_slot = 0;
+  bool it_live = true;
+  unsigned it_x[NIX];
+  auto set_issue_tile = [&]() __attribute__((always_inline)) {
+    const int ptile = first_tile + it_i * tile_step;
+#pragma unroll
+    for (int q = 0; q < NIX; ++q) {
+      const int p = ptile * PX_T + RPI * (wave + 4 * q) + r_in;
+      it_x[q] = p < a.M ? a.x_off + (unsigned)((pix(p, a.x_sn, a.x_sh, a.x_sw, a.x_lin) + ch * VEC) * (long)ES) : GLS_OOB;
+    }
+  };
+  auto issue = [&]() __attribute__((always_inline)) {
+    unsigned char* dst = smem + it_slot * STAGE + wave * 1024;
+    const unsigned pb = it_live ? (unsigned)(it_p * KB) : GLS_OOB;           // scalar; beyond the end: zero fills
+    if constexpr (!WRES) {
+#pragma unroll
+      for (int q = 0; q < NIW; ++q)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lds_ptr)(dst + q * 4096), 16, (int)(wd[q] + pb), 0, 0, 0);
+    }
+    unsigned char* dx = dst + (WRES ? 0 : W_ST);
+    const bool tail = ragged && it_p == np - 1;
+#pragma unroll
+    for (int q = 0; q < NIX; ++q) {
+      unsigned o = it_x[q] + pb;
+      if (tail && !lane_tail_ok) o = GLS_OOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_ptr)(dx + q * 4096), 16, (int)o, 0, 0, 0);
+    }
+    it_slot = it_slot + 1 == NS ? 0 : it_slot + 1;
+    if (++it_p == np) {
+      it_p = 0;
+      if (++it_i < my_tiles) set_issue_tile();
+      else it_live = false;
+    }
+  };
+
+  // ---- compute side
+  const int wco = wave % WCO, wpx = wave / WCO;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int a_row = (wco * WT_CO + l31) * KB, b_row = (wpx * WT_PX + l31) * KB;
+  int f_sw[NKK];
+#pragma unroll
+  for (int kk = 0; kk < NKK; ++kk) f_sw[kk] = ((2 * kk + lh) ^ ((l31 / RPL) & (CPRW - 1))) << 4;
+  const int nkk_last = ((kbytes - (np - 1) * KB) + 31) / 32;     // k steps of the last panel that hold input channels
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+  // ---- prologue: resident weights, the first NS - 1 stages, scale | bias parked in LDS
+  if constexpr (WRES) {
+    for (int pn = 0; pn < np; ++pn) {
+#pragma unroll
+      for (int q = 0; q < NIW; ++q)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lds_ptr)(sW + pn * W_ST + wave * 1024 + q * 4096), 16,
+                                                 (int)(wd[q] + (unsigned)(pn * KB)), 0, 0, 0);
+    }
+  }
+  set_issue_tile();
+#pragma unroll
+  for (int s = 0; s < NS - 1; ++s) issue();
+  if (tid < CO_T / 4) {
+    *reinterpret_cast<f32x4*>(sSB + tid * 16) = sb_s;
+    *reinterpret_cast<f32x4*>(sSB + CO_T * 4 + tid * 16) = sb_b;
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             // the first barrier below publishes them
+
+  const unsigned char* res_lo = a.res;
+  const bool has_res = a.res != nullptr;
+  // residual view as a buffer: the descriptor spans from the view's base to the end of what a 32-bit offset reaches
+  const auto rrs = gls_make_rsrc(a.res ? a.res : a.x_lo, 0x7fffffffu);
+  const auto yrs = gls_make_rsrc(a.y, 0x7fffffffu);
+  (void)res_lo;
+  // vmcnt counts EVERY vector-memory operation of the wave in issue order -- the operand DMAs, the residual DMAs and the
+  // epilogue's stores.  To wait for stage t and for nothing younger, the wait allows (NS - 2) stages of DMAs plus the store
+  // groups of the tiles that ended in the last NS - 1 iterations: `ends` is a shift register of "this iteration ended a
+  // tile" bits.  (The stores are buffer stores that every lane always issues, so the count is exact; residual DMAs in the
+  // window are not added: the wait is then stricter than needed, never weaker.)
+  unsigned ends = 0;
+
+  int c_p = 0, c_i = 0, c_slot = 0;
+  for (int t = 0; t < total; ++t) {
+    // stage t has landed in every wave; every wave is done with stage t - 1
+    gemm_wait_k<NI * (NS - 2), NST, KEND, true>(__builtin_popcount(ends & ((1u << (NS - 1)) - 1u)));
+    ends <<= 1;
+    const int ptile = first_tile + c_i * tile_step;
+    if (has_res && c_p == 0) {
+      // residual chunks of this tile -> wave-private LDS slots (lane L of instruction k reads back slot k * 1024 + L * 16)
+      unsigned char* rdst = sR + wave * (NR * 1024);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int p = ptile * PX_T + wpx * WT_PX + j * 32 + l31;
+          const long ro = p < a.M ? pix(p, a.r_sn, a.r_sh, a.r_sw, a.r_lin) : -1;
+#pragma unroll
+          for (int h = 0; h < 32 / (2 * OV); ++h) {
+            const int co = co0 + wco * WT_CO + i * 32 + h * 2 * OV + lh * OV;
+            const unsigned o = (ro >= 0 && co < a.Cout) ? (unsigned)((ro + co) * (long)sizeof(TO)) : GLS_OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rrs, (lds_ptr)(rdst + ((i * TN + j) * (32 / (2 * OV)) + h) * 1024), 16, (int)o, 0, 0, 0);
+          }
+        }
+    }
+    issue();                                       // stage t + NS - 1 -> the slot stage t - 1 just left
+    {
+      const unsigned char* sa = WRES ? sW + c_p * W_ST : smem + c_slot * STAGE;
+      const unsigned char* sb = smem + c_slot * STAGE + (WRES ? 0 : W_ST);
+      const int nkk = c_p == np - 1 ? nkk_last : NKK;
+#pragma unroll
+      for (int kk = 0; kk < NKK; ++kk) {
+        if (kk < nkk) {
+          u32x4 af[TM], bf[TN];
+#pragma unroll
+          for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const u32x4*>(sa + a_row + i * 32 * KB + f_sw[kk]);
+#pragma unroll
+          for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const u32x4*>(sb + b_row + j * 32 * KB + f_sw[kk]);
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) MMA<T>::run(af[i], bf[j], acc[i][j]);
+        }
+      }
+    }
+    c_slot = c_slot + 1 == NS ? 0 : c_slot + 1;
+    if (++c_p == np) {
+      // ---- epilogue of this tile, straight from the accumulators (no LDS staging, no barrier)
+      c_p = 0;
+      ++c_i;
+      long yo[TN];
+      bool pok[TN];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int p = ptile * PX_T + wpx * WT_PX + j * 32 + l31;
+        pok[j] = p < a.M;
+        yo[j] = pok[j] ? pix(p, a.y_sn, a.y_sh, a.y_sw, a.y_lin) : 0;
+      }
+      ends |= 1u;
+      if (has_res && np < NS) {                    // the residual DMAs are older than exactly np stages of operand DMAs
+        gemm_wait_k<NI, NI, NS - 2, false>(np - 1);
+      }
+      const unsigned char* rsrc = sR + wave * (NR * 1024) + lane * 16;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        if constexpr (sizeof(TO) == 2) {
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const int cl0 = wco * WT_CO + i * 32 + 16 * h + 4 * lh;          // channel of group 2h; group 2h + 1: + 8
+            const f32x4 s0 = *reinterpret_cast<const f32x4*>(sSB + cl0 * 4), b0 = *reinterpret_cast<const f32x4*>(sSB + CO_T * 4 + cl0 * 4);
+            const f32x4 s1 = *reinterpret_cast<const f32x4*>(sSB + (cl0 + 8) * 4), b1 = *reinterpret_cast<const f32x4*>(sSB + CO_T * 4 + (cl0 + 8) * 4);
+            const int co = co0 + wco * WT_CO + i * 32 + 16 * h + 8 * lh;      // this lane's 8 channels after the swap
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+              const f32x4 x0 = {acc[i][j][8 * h], acc[i][j][8 * h + 1], acc[i][j][8 * h + 2], acc[i][j][8 * h + 3]};
+              const f32x4 x1 = {acc[i][j][8 * h + 4], acc[i][j][8 * h + 5], acc[i][j][8 * h + 6], acc[i][j][8 * h + 7]};
+              const f32x4 y0 = scale_bias_act4<T>(x0, s0, b0, a.act), y1 = scale_bias_act4<T>(x1, s1, b1, a.act);
+              u32x4 v;
+              if (has_res) {                       // fp32 halves swapped, residual added in fp32, ONE rounding
+                float l0 = y0[0], l1 = y0[1], l2 = y0[2], l3 = y0[3], h0 = y1[0], h1 = y1[1], h2 = y1[2], h3 = y1[3];
+                lane32_swap(l0, h0);
+                lane32_swap(l1, h1);
+                lane32_swap(l2, h2);
+                lane32_swap(l3, h3);
+                const f32x4 lo = {l0, l1, l2, l3}, hi = {h0, h1, h2, h3};
+                const u32x4 rv = *reinterpret_cast<const u32x4*>(rsrc + ((i * TN + j) * 2 + h) * 1024);
+                v = add_chunk_wide(lo, hi, rv, a.act_post);
+              } else {
+                const f16x4 e4 = {(f16)y0[0], (f16)y0[1], (f16)y0[2], (f16)y0[3]}, o4 = {(f16)y1[0], (f16)y1[1], (f16)y1[2], (f16)y1[3]};
+                typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+                const u32x2 eu = __builtin_bit_cast(u32x2, e4), ou = __builtin_bit_cast(u32x2, o4);
+                const auto s0w = __builtin_amdgcn_permlane32_swap(eu[0], ou[0], false, false);
+                const auto s1w = __builtin_amdgcn_permlane32_swap(eu[1], ou[1], false, false);
+                v = u32x4{s0w[0], s1w[0], s0w[1], s1w[1]};
+              }
+              __builtin_amdgcn_raw_buffer_store_b128(v, yrs, (int)((pok[j] && co < a.Cout) ? (unsigned)((yo[j] + co) * 2) : GLS_OOB), 0, 0);
+            }
+          }
+        } else {
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int cl = wco * WT_CO + i * 32 + 8 * g + 4 * lh;
+            const f32x4 sc = *reinterpret_cast<const f32x4*>(sSB + cl * 4), bi = *reinterpret_cast<const f32x4*>(sSB + CO_T * 4 + cl * 4);
+            const int co = co0 + cl;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+              const f32x4 xv = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+              f32x4 yv = scale_bias_act4<T>(xv, sc, bi, a.act);
+              u32x4 v = __builtin_bit_cast(u32x4, yv);
+              if (has_res) v = add_chunk(v, *reinterpret_cast<const u32x4*>(rsrc + ((i * TN + j) * 4 + g) * 1024), (float*)nullptr, a.act_post);
+              __builtin_amdgcn_raw_buffer_store_b128(v, yrs, (int)((pok[j] && co < a.Cout) ? (unsigned)((yo[j] + co) * 4) : GLS_OOB), 0, 0);
+            }
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+      }
+    }
+  }
+  gemm_wait_vm<0>();                               // the zero fills issued beyond the last stage land before the LDS is released
+}
+
+template <typename T, typename TO, int CO_T, int PX_T, int NS, int KB, bool WRES>
+static int launch_gemm(const ConvArgs& a, hipStream_t st, bool dry) {
+  constexpr int ES = (int)sizeof(T);
+  const int kbytes = a.Cin * ES;
+  GemmGeom gm;
+  gm.np = (kbytes + KB - 1) / KB;
+  gm.n_px_tiles = (a.M + PX_T - 1) / PX_T;
+  constexpr int STAGE = ((WRES ? 0 : CO_T) + PX_T) * KB;
+  if (WRES && gm.np * CO_T * KB > 48 * 1024) return 1;                     // resident weight tile: at most 48 KiB
+  const int lds = NS * STAGE + (WRES ? gm.np * CO_T * KB : 0) + CO_T * 8 + (a.res ? gemm_res_bytes<TO>(CO_T, PX_T) : 0);
+  if (lds > 160 * 1024) return 1;
+  ConvArgs b = a;
+  b.n_co_tiles = (a.cout_pad + CO_T - 1) / CO_T;
+  if ((b.n_co_tiles - 1) * CO_T >= a.Cout) b.n_co_tiles = (a.Cout + CO_T - 1) / CO_T;
+  gls_fastdiv(b.n_co_tiles, &b.nco_mul, &b.nco_sh);
+  // residual offsets are 32-bit byte offsets from the view's base
+  if (a.res) {
+    const long span = ((long)(a.N - 1) * a.r_sn + (long)(a.Ho - 1) * a.r_sh + (long)(a.Wo - 1) * a.r_sw + a.Cout) * (long)sizeof(TO);
+    if (span >= 0x7fffffffL || a.r_sn < 0 || a.r_sh < 0 || a.r_sw < 0) return 1;
+  }
+  {
+    const long span = ((long)(a.N - 1) * a.y_sn + (long)(a.Ho - 1) * a.y_sh + (long)(a.Wo - 1) * a.y_sw + a.Cout) * (long)sizeof(TO);
+    if (span >= 0x7fffffffL || a.y_sn < 0 || a.y_sh < 0 || a.y_sw < 0) return 1;
+  }
+  if (dry) return 0;
+  int per_cu = (160 * 1024) / (lds + 512);
+  if (per_cu > 6) per_cu = 6;
+  static const int per_cu_env = getenv("GLSDET_GEMM_PER_CU") ? atoi(getenv("GLSDET_GEMM_PER_CU")) : 0;
+  if (per_cu_env > 0 && per_cu_env < per_cu) per_cu = per_cu_env;
+  int slots_per_xcd = 32 * per_cu;
+  if (const char* e = getenv("GLSDET_GEMM_SLOTS_PER_XCD")) {              // tests: few walkers, so that small problems walk several tiles
+    const int v = atoi(e);
+    if (v > 0 && v < slots_per_xcd) slots_per_xcd = v;
+  }
+  const int tiles_per_xcd = (gm.n_px_tiles + 7) / 8;
+  int nwalk = slots_per_xcd / b.n_co_tiles;
+  if (nwalk < 1) nwalk = 1;
+  if (nwalk > tiles_per_xcd) nwalk = tiles_per_xcd;
+  const int rounds = (tiles_per_xcd + nwalk - 1) / nwalk;
+  nwalk = (tiles_per_xcd + rounds - 1) / rounds;
+  gm.nwalk = nwalk;
+  const long grid = 8L * b.n_co_tiles * nwalk;
+  auto kern = conv_gemm_kernel<T, TO, CO_T, PX_T, NS, KB, WRES>;
+  static int attr_lds = 64 * 1024;
+  if (lds > attr_lds) {
+    GLS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_lds = 160 * 1024;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, st, b, gm);
+  GLS_HIP(hipGetLastError());
+  return 0;
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// "Single shot" form for short K (Cin * sizeof(T) <= 512 bytes: every 1x1 layer of YOLOX-s up to 256 input channels).
+// What the measurements of the persistent ring above showed (profiles/r03_*, tools/conv_variants.py gls1x1): on these
+// layers a deep ring per workgroup buys nothing -- what hides latency is MANY resident workgroups, and 64 KiB of ring per
+// workgroup leaves two of them per CU.  So: one tile per workgroup, the whole K of both operands requested at once by DMA
+// (16-32 KiB of LDS -> five to eight workgroups per CU), ONE wait + ONE barrier, the MFMAs, and the register epilogue of
+// the kernel above (no LDS staging, no second barrier).  Scale / bias come straight into registers (requested first, used
+// last).  ~200 instructions per wave instead of the flat-pixel kernel's ~690 for the same 16 MFMAs.
+template <typename T, typename TO, int CO_T, int PX_T>
+__global__ __launch_bounds__(256) void conv_gemm1_kernel(const ConvArgs a, const int np) {
+  constexpr int ES = (int)sizeof(T), VEC = 16 / ES, KB = 128;
+  constexpr int WCO = CO_T >= 64 ? 2 : 1, WPX = 4 / WCO;
+  constexpr int WT_CO = CO_T / WCO, WT_PX = PX_T / WPX;
+  constexpr int TM = WT_CO / 32, TN = WT_PX / 32;
+  constexpr int NIW = CO_T / 32, NIX = PX_T / 32;
+  constexpr int W_ST = CO_T * KB, X_ST = PX_T * KB;
+  constexpr int OV = 16 / (int)sizeof(TO);
+  constexpr int NR = TM * TN * (32 / (2 * OV));
+  static_assert(TM == 1 && TN >= 1, "one 32-row cout block per wave: its scale | bias live in registers");
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wco = wave % WCO, wpx = wave / WCO;
+  const int l31 = lane & 31, lh = lane >> 5;
+
+  int tile;                                      // XCD-aware order, cout tile fastest (conv.hip)
+  {
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, local = bid >> 3;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+  }
+  const int ptile = gls_div(tile, a.nco_mul, a.nco_sh);
+  const int co0 = (tile - ptile * a.n_co_tiles) * CO_T;
+  const int px0 = ptile * PX_T;
+
+  // scale | bias of this lane's 16 channels: requested first
+  f32x4 scv[4], biv[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const int co = co0 + wco * WT_CO + 8 * g + 4 * lh;
+    scv[g] = biv[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (co < a.cout_pad) {
+      scv[g] = *reinterpret_cast<const f32x4*>(a.scale + co);
+      biv[g] = *reinterpret_cast<const f32x4*>(a.bias + co);
+    }
+  }
+  unsigned char* sW = smem;                       // [np][CO_T][KB]
+  unsigned char* sX = smem + np * W_ST;           // [np][PX_T][KB]
+  unsigned char* sR = sX + np * X_ST;             // residual chunks, wave-private slots
+  const auto xrs = gls_make_rsrc(a.x_lo, a.x_bytes);
+  const auto wrs = gls_make_rsrc(a.w, a.w_bytes);
+  const int r_in = lane >> 3, c_in = lane & 7;
+  const int ch = c_in ^ ((4 * (wave & 1) + (r_in >> 1)) & 7);
+  const int kbytes = a.Cin * ES;
+  const int HoWo = a.Ho * a.Wo;
+  auto pix = [&](int p, long sn, long sh, long sw, int lin) __attribute__((always_inline)) -> long {
+    if (lin) return (long)p * sw;
+    const int n = gls_div(p, a.howo_mul, a.howo_sh), rem = p - n * HoWo;
+    const int ho = gls_div(rem, a.wo_mul, a.wo_sh), wo = rem - ho * a.Wo;
+    return (long)n * sn + (long)ho * sh + (long)wo * sw;
+  };
+  unsigned wd[NIW], xd[NIX];
+#pragma unroll
+  for (int q = 0; q < NIW; ++q) {
+    const int row = 8 * (wave + 4 * q) + r_in;
+    wd[q] = (co0 + row) < a.cout_pad ? (unsigned)(((co0 + row) * a.kpad + ch * VEC) * ES) : GLS_OOB;
+  }
+#pragma unroll
+  for (int q = 0; q < NIX; ++q) {
+    const int p = px0 + 8 * (wave + 4 * q) + r_in;
+    xd[q] = p < a.M ? a.x_off + (unsigned)((pix(p, a.x_sn, a.x_sh, a.x_sw, a.x_lin) + ch * VEC) * (long)ES) : GLS_OOB;
+  }
+  for (int pn = 0; pn < np; ++pn) {
+    const unsigned pb = (unsigned)(pn * KB);
+    // a chunk beyond the input channels (the last panel of a ragged K) reads zeros: the packed weights hold zeros there,
+    // but 0 x (whatever follows the pixel's channels in memory) must not become a NaN
+    const bool dead = (int)(ch * 16 + pb) >= kbytes;
+    if (!(a.dbg & 4)) {
+#pragma unroll
+    for (int q = 0; q < NIX; ++q)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_ptr)(sX + pn * X_ST + wave * 1024 + q * 4096), 16, (int)(dead ? GLS_OOB : xd[q] + pb), 0, 0, 0);
+    }
+#pragma unroll
+    for (int q = 0; q < NIW; ++q)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lds_ptr)(sW + pn * W_ST + wave * 1024 + q * 4096), 16, (int)(wd[q] + pb), 0, 0, 0);
+  }
+  const bool has_res = a.res != nullptr;
+  long yo[TN];
+  bool pok[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int p = px0 + wpx * WT_PX + j * 32 + l31;
+    pok[j] = p < a.M;
+    yo[j] = pok[j] ? pix(p, a.y_sn, a.y_sh, a.y_sw, a.y_lin) : 0;
+  }
+  if (has_res) {
+    const auto rrs = gls_make_rsrc(a.res, 0x7fffffffu);
+    unsigned char* rdst = sR + wave * (NR * 1024);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int p = px0 + wpx * WT_PX + j * 32 + l31;
+      const long ro = p < a.M ? pix(p, a.r_sn, a.r_sh, a.r_sw, a.r_lin) : -1;
+#pragma unroll
+      for (int h = 0; h < 32 / (2 * OV); ++h) {
+        const int co = co0 + wco * WT_CO + h * 2 * OV + lh * OV;
+        const unsigned o = (ro >= 0 && co < a.Cout) ? (unsigned)((ro + co) * (long)sizeof(TO)) : GLS_OOB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rrs, (lds_ptr)(rdst + (j * (32 / (2 * OV)) + h) * 1024), 16, (int)o, 0, 0, 0);
+      }
+    }
+  }
+  f32x16 acc[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[j][e] = 0.0f;
+  const int a_row = (wco * WT_CO + l31) * KB, b_row = (wpx * WT_PX + l31) * KB;
+  int f_sw[4];
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) f_sw[kk] = ((2 * kk + lh) ^ ((l31 >> 1) & 7)) << 4;
+  gemm_wait_barrier<0>();                          // everything this workgroup will ever read has landed
+  const int nsteps = (kbytes + 31) / 32;           // 32-byte k steps that hold input channels
+  for (int pn = 0; pn < np; ++pn) {
+    const unsigned char* sa = sW + pn * W_ST + a_row;
+    const unsigned char* sb = sX + pn * X_ST + b_row;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      if (pn * 4 + kk < nsteps && !(a.dbg & 2)) {
+        const u32x4 af = *reinterpret_cast<const u32x4*>(sa + f_sw[kk]);
+        u32x4 bf[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const u32x4*>(sb + j * 32 * KB + f_sw[kk]);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) MMA<T>::run(af, bf[j], acc[j]);
+      }
+    }
+  }
+  // ---- epilogue from the accumulators
+  const unsigned char* rsrc = sR + wave * (NR * 1024) + lane * 16;
+  if constexpr (sizeof(TO) == 2) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int co = co0 + wco * WT_CO + 16 * h + 8 * lh;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const f32x4 x0 = {acc[j][8 * h], acc[j][8 * h + 1], acc[j][8 * h + 2], acc[j][8 * h + 3]};
+        const f32x4 x1 = {acc[j][8 * h + 4], acc[j][8 * h + 5], acc[j][8 * h + 6], acc[j][8 * h + 7]};
+        const f32x4 y0 = scale_bias_act4<T>(x0, scv[2 * h], biv[2 * h], a.act), y1 = scale_bias_act4<T>(x1, scv[2 * h + 1], biv[2 * h + 1], a.act);
+        u32x4 v;
+        if (has_res) {
+          float l0 = y0[0], l1 = y0[1], l2 = y0[2], l3 = y0[3], h0 = y1[0], h1 = y1[1], h2 = y1[2], h3 = y1[3];
+          lane32_swap(l0, h0);
+          lane32_swap(l1, h1);
+          lane32_swap(l2, h2);
+          lane32_swap(l3, h3);
+          const f32x4 lo = {l0, l1, l2, l3}, hi = {h0, h1, h2, h3};
+          v = add_chunk_wide(lo, hi, *reinterpret_cast<const u32x4*>(rsrc + (j * 2 + h) * 1024), a.act_post);
+        } else {
+          const f16x4 e4 = {(f16)y0[0], (f16)y0[1], (f16)y0[2], (f16)y0[3]}, o4 = {(f16)y1[0], (f16)y1[1], (f16)y1[2], (f16)y1[3]};
+          typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+          const u32x2 eu = __builtin_bit_cast(u32x2, e4), ou = __builtin_bit_cast(u32x2, o4);
+          const auto s0w = __builtin_amdgcn_permlane32_swap(eu[0], ou[0], false, false);
+          const auto s1w = __builtin_amdgcn_permlane32_swap(eu[1], ou[1], false, false);
+          v = u32x4{s0w[0], s1w[0], s0w[1], s1w[1]};
+        }
+        if (pok[j] && co < a.Cout && (!(a.dbg & 1) || v[0] == 0x12345u)) *reinterpret_cast<u32x4*>(a.y + (yo[j] + co) * 2) = v;
+      }
+    }
+  } else {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int co = co0 + wco * WT_CO + 8 * g + 4 * lh;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const f32x4 xv = {acc[j][4 * g], acc[j][4 * g + 1], acc[j][4 * g + 2], acc[j][4 * g + 3]};
+        const f32x4 yv = scale_bias_act4<T>(xv, scv[g], biv[g], a.act);
+        u32x4 v = __builtin_bit_cast(u32x4, yv);
+        if (has_res) v = add_chunk(v, *reinterpret_cast<const u32x4*>(rsrc + (j * 4 + g) * 1024), (float*)nullptr, a.act_post);
+        if (pok[j] && co < a.Cout) *reinterpret_cast<u32x4*>(a.y + (yo[j] + co) * 4) = v;
+      }
+    }
+  }
+}
+
+template <typename T, typename TO, int CO_T, int PX_T>
+static int launch_gemm1(const ConvArgs& a, hipStream_t st, bool dry) {
+  constexpr int ES = (int)sizeof(T);
+  const int kbytes = a.Cin * ES;
+  const int np = (kbytes + 127) / 128;
+  if (np > 4) return 1;                                                    // K <= 512 bytes: everything at once
+  const int lds = np * (CO_T + PX_T) * 128 + (a.res ? gemm_res_bytes<TO>(CO_T, PX_T) : 0);
+  if (a.res) {
+    const long span = ((long)(a.N - 1) * a.r_sn + (long)(a.Ho - 1) * a.r_sh + (long)(a.Wo - 1) * a.r_sw + a.Cout) * (long)sizeof(TO);
+    if (span >= 0x7fffffffL || a.r_sn < 0 || a.r_sh < 0 || a.r_sw < 0) return 1;
+  }
+  if (dry) return 0;
+  ConvArgs b = a;
+  if (const char* e = getenv("GLSDET_GEMM_DBG")) b.dbg = atoi(e);          // timing knock-outs (results are then invalid)
+  b.n_co_tiles = (a.cout_pad + CO_T - 1) / CO_T;
+  if ((b.n_co_tiles - 1) * CO_T >= a.Cout) b.n_co_tiles = (a.Cout + CO_T - 1) / CO_T;
+  gls_fastdiv(b.n_co_tiles, &b.nco_mul, &b.nco_sh);
+  const long grid = (long)b.n_co_tiles * ((a.M + PX_T - 1) / PX_T);
+  if (grid <= 0 || grid > 0x7fffffffL) return 1;
+  auto kern = conv_gemm1_kernel<T, TO, CO_T, PX_T>;
+  static int attr_lds = 64 * 1024;
+  if (lds > attr_lds) {
+    GLS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_lds = 160 * 1024;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, st, b, np);
+  GLS_HIP(hipGetLastError());
+  return 0;
+}
+
+// variant table: tile_hint 16 + index
+struct GemmVariant { int co_t, px_t, ns, kb; bool wres; };
+static const GemmVariant GEMM_VARIANTS[] = {
+    {64, 64, 4, 128, false},     // 16
+    {128, 64, 3, 128, false},    // 17
+    {64, 128, 3, 128, false},    // 18
+    {128, 128, 3, 128, false},   // 19
+    {128, 128, 4, 64, false},    // 20
+    {32, 128, 3, 128, false},    // 21
+    {64, 128, 3, 128, true},     // 22
+    {128, 64, 4, 128, true},     // 23
+    {64, 64, 4, 128, true},      // 24
+    {32, 128, 4, 128, true},     // 25
+    {128, 128, 3, 128, true},    // 26
+    {64, 64, 6, 64, false},      // 27
+    {128, 64, 4, 64, false},     // 28
+    {64, 64, 0, 128, false},     // 29  single shot (ns 0)
+    {64, 128, 0, 128, false},    // 30  single shot
+    {32, 128, 0, 128, false},    // 31  single shot
+};
+constexpr int N_GEMM_VARIANTS = (int)(sizeof(GEMM_VARIANTS) / sizeof(GEMM_VARIANTS[0]));
+
+template <typename T, typename TO>
+static int gemm_dispatch(const ConvArgs& a, int v, hipStream_t st, bool dry) {
+  switch (v) {
+    case 0: return launch_gemm<T, TO, 64, 64, 4, 128, false>(a, st, dry);
+    case 1: return launch_gemm<T, TO, 128, 64, 3, 128, false>(a, st, dry);
+    case 2: return launch_gemm<T, TO, 64, 128, 3, 128, false>(a, st, dry);
+    case 3: return launch_gemm<T, TO, 128, 128, 3, 128, false>(a, st, dry);
+    case 4: return launch_gemm<T, TO, 128, 128, 4, 64, false>(a, st, dry);
+    case 5: return launch_gemm<T, TO, 32, 128, 3, 128, false>(a, st, dry);
+    case 6: return launch_gemm<T, TO, 64, 128, 3, 128, true>(a, st, dry);
+    case 7: return launch_gemm<T, TO, 128, 64, 4, 128, true>(a, st, dry);
+    case 8: return launch_gemm<T, TO, 64, 64, 4, 128, true>(a, st, dry);
+    case 9: return launch_gemm<T, TO, 32, 128, 4, 128, true>(a, st, dry);
+    case 10: return launch_gemm<T, TO, 128, 128, 3, 128, true>(a, st, dry);
+    case 11: return launch_gemm<T, TO, 64, 64, 6, 64, false>(a, st, dry);
+    case 12: return launch_gemm<T, TO, 128, 64, 4, 64, false>(a, st, dry);
+    case 13: return launch_gemm1<T, TO, 64, 64>(a, st, dry);
+    case 14: return launch_gemm1<T, TO, 64, 128>(a, st, dry);
+    case 15: return launch_gemm1<T, TO, 32, 128>(a, st, dry);
+  }
+  return 1;
+}
+
+// tile_hint 16 .. 16 + N_GEMM_VARIANTS - 1.  Returns 1 when the variant does not apply to the problem.
+int conv_gemm_try(const ConvArgs& a, int xdt, int ydt, int hint, OpRecord* op) {
+  const int v = hint - 16;
+  if (v < 0 || v >= N_GEMM_VARIANTS) return 1;
+  if (a.R != 1 || a.S != 1 || a.stride != 1 || a.pad != 0 || a.w2 || a.gn_part) return 1;
+  const GemmVariant& gv = GEMM_VARIANTS[v];
+  if (gv.co_t > 32 && a.cout_pad <= gv.co_t / 2) return 1;                 // mostly padding
+  if (gv.co_t == 32 && a.cout_pad > 32) return 1;
+  auto run = [a, v, xdt, ydt](hipStream_t st, bool dry) -> int {
+    if (xdt == GLSDET_F16 && ydt == GLSDET_F16) return gemm_dispatch<f16, f16>(a, v, st, dry);
+    if (xdt == GLSDET_F16 && ydt == GLSDET_F32) return gemm_dispatch<f16, float>(a, v, st, dry);
+    return gemm_dispatch<float, float>(a, v, st, dry);
+  };
+  if (run(nullptr, true)) return 1;
+  char nm[112];
+  if (gv.ns == 0)
+    snprintf(nm, sizeof nm, "conv_gemm1<%s,%s,%dx%d> 1x1 cin%d cout%d", xdt ? "f32" : "f16", ydt ? "f32" : "f16", gv.co_t, gv.px_t, a.Cin, a.Cout);
+  else
+    snprintf(nm, sizeof nm, "conv_gemm<%s,%s,%dx%d,ns%d,kb%d%s> 1x1 cin%d cout%d", xdt ? "f32" : "f16", ydt ? "f32" : "f16", gv.co_t, gv.px_t,
+             gv.ns, gv.kb, gv.wres ? ",wres" : "", a.Cin, a.Cout);
+  op->name = nm;
+  op->launch = [run](hipStream_t st) -> int { return run(st, false); };
+  return 0;
+}
+
+}  // namespace glsdet

@@ -11,7 +11,8 @@ from tests.test_hip_ops import TOL, _cmp, _to_view
 
 pytestmark = pytest.mark.gpu
 
-HINTS = [0, 1, 2, 3, 4, 5, 8, 9, 10, 11, 12, 13, (128 << 16) | 128, (64 << 16) | 128, (64 << 16) | 64, (32 << 16) | 128,
+GEMM_HINTS = list(range(16, 32))       # persistent LDS-DMA 1x1 kernel (conv_gemm.hip), every variant
+HINTS = [0, 1, 2, 3, 4, 5, 8, 9, 10, 11, 12, 13] + GEMM_HINTS + [(128 << 16) | 128, (64 << 16) | 128, (64 << 16) | 64, (32 << 16) | 128,
          (64 << 16) | 64 | 0x8000, (128 << 16) | 128 | 0x8000, (128 << 16), (128 << 16) | 0x8000]
 
 
@@ -119,3 +120,61 @@ def _s2_cases(n, seed):
 @pytest.mark.parametrize("case", _s2_cases(14, 23), ids=lambda c: "n%d_ci%d_co%d_k%d_s%d_%dx%d_%s_r%d_e%d" % c)
 def test_conv2d_random_stride2_problem_halo_family(engines, mode, case):
     _run_case(engines, mode, case, [0, 1, 10, 11, (64 << 16) | 128])
+
+
+def _gemm_cases(n, seed):
+    """1x1 problems for the persistent LDS-DMA kernel: ragged K (Cin not a whole 128-byte panel), one to ten panels, cout
+    tiles with padding rows, pixel counts that end inside a tile, strided views, both residual orders"""
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(n):
+        cin = int(rng.choice([8, 16, 24, 32, 40, 64, 72, 96, 128, 136, 256, 264, 320, 512, 640]))
+        cout = int(rng.choice([8, 16, 40, 64, 96, 128, 136, 192, 256, 264]))
+        h, w = int(rng.integers(1, 60)), int(rng.integers(1, 60))
+        n_img = int(rng.choice([1, 2, 3]))
+        act = str(rng.choice(["silu", "relu", "lrelu", "none", "gelu"]))
+        res = int(rng.choice([0, 0, 1, 2]))
+        embed = bool(rng.integers(0, 2))
+        out.append((n_img, cin, cout, 1, 1, h, w, act, res, embed))
+    return out
+
+
+@pytest.mark.parametrize("slots", [0, 3])
+@pytest.mark.parametrize("mode", ["f16", "f32"])
+@pytest.mark.parametrize("case", _gemm_cases(36, 23), ids=lambda c: "n%d_ci%d_co%d_k%d_s%d_%dx%d_%s_r%d_e%d" % c)
+def test_conv1x1_persistent_dma_kernel_all_variants(engines, monkeypatch, mode, case, slots):
+    """slots = 3: at most three workgroups per XCD (GLSDET_GEMM_SLOTS_PER_XCD), so that every workgroup walks many pixel
+    tiles and the operand ring, the residual DMAs and the epilogues run across tile boundaries"""
+    if slots:
+        monkeypatch.setenv("GLSDET_GEMM_SLOTS_PER_XCD", str(slots))
+    else:
+        monkeypatch.delenv("GLSDET_GEMM_SLOTS_PER_XCD", raising=False)
+    _run_case(engines, mode, case, [1] + GEMM_HINTS)
+
+
+@pytest.mark.parametrize("slots", [0, 2])
+@pytest.mark.parametrize("cin,cout,hw", [(256, 15, (25, 42)), (64, 15, (7, 9)), (136, 40, (33, 31)), (512, 200, (12, 11))])
+def test_conv1x1_persistent_dma_kernel_fp32_output_of_fp16_input(engines, monkeypatch, cin, cout, hw, slots):
+    """the predictor form: fp16 operands, fp32 logits (no rounding of the result), cout padded to 16 / 32"""
+    from glsdet_amd._lib import F32, GlsdetError
+    if slots:
+        monkeypatch.setenv("GLSDET_GEMM_SLOTS_PER_XCD", str(slots))
+    else:
+        monkeypatch.delenv("GLSDET_GEMM_SLOTS_PER_XCD", raising=False)
+    eng = engines["f16"]
+    g = torch.Generator().manual_seed(cin + cout)
+    x = torch.randn(3, cin, hw[0], hw[1], generator=g)
+    wt = torch.randn(cout, cin, 1, 1, generator=g) / np.sqrt(cin)
+    bias = torch.randn(cout, generator=g)
+    ref = F.conv2d(x.half().float(), wt.half().float(), bias)
+    pk = eng.pack_conv([(wt, torch.ones(cout), bias)], cin)
+    ran = 0
+    for hint in GEMM_HINTS:
+        try:
+            out = eng.conv(_to_view(eng, x), pk, 1, 0, "none", out_dtype=F32, tile_hint=hint)
+        except GlsdetError:
+            continue
+        torch.cuda.synchronize()
+        _cmp(out.to_nchw(cout), ref, 1e-3, "hint %d" % hint)
+        ran += 1
+    assert ran >= 2
