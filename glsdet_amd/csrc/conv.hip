@@ -731,12 +731,13 @@ static int build_conv_op(const glsdet_conv_desc* d, int hint, OpRecord& op, cons
     GLS_FAIL(GLSDET_E_ARG, "conv2d: the weight-stationary 1x1 kernel does not apply to this problem");
   }
   if (hint == 6 || hint == 7) GLS_FAIL(GLSDET_E_ARG, "conv2d: tile_hint 6 / 7 (persistent LDS-DMA halo kernel) no longer exist");
-  if (hint >= 16 && hint < 64) {            // persistent LDS-DMA GEMM kernel for 1x1 convs (conv_gemm.hip), variant hint - 16
+  if (hint >= 16 && hint < 64 && !a.w2) {   // persistent LDS-DMA GEMM kernel for 1x1 convs (conv_gemm.hip), variant hint - 16
     if (conv_gemm_try(a, xdt, ydt, hint, &op) == 0) return 0;
     GLS_FAIL(GLSDET_E_ARG, "conv2d: the persistent 1x1 kernel (variant %d) does not apply to this problem", hint - 16);
   }
   if (conv_halo_try(a, xdt, ydt, hint, &op) == 0) return 0;
-  if (hint == 2 || hint == 4 || hint == 5 || (hint >= 8 && hint <= 13)) GLS_FAIL(GLSDET_E_ARG, "conv2d: the halo kernel does not apply to this problem");
+  if (hint == 2 || hint == 4 || hint == 5 || (hint >= 8 && hint <= 13) || (hint >= 0x100 && hint < 0x300))
+    GLS_FAIL(GLSDET_E_ARG, "conv2d: the halo kernel does not apply to this problem");
 
   int co_t, px_t, kb;
   pick_tile(a, dtype_size(x.dtype), hint >= 0x10000 ? hint : 0, &co_t, &px_t, &kb);
@@ -777,7 +778,7 @@ static int build_conv_multi_op(const glsdet_conv_desc* d, int32_t n, int hint, O
         a.pad != b.pad || a.Cin != b.Cin || a.Cout != b.Cout)
       GLS_FAIL(GLSDET_E_ARG, "conv2d_multi: descriptor %d is not of the shape class of descriptor 0", i);
   }
-  if (hint >= 8 && hint <= 11) {          // the grouped ring kernel (conv_halo.hip); no silent fall-back: the tuner asks per hint
+  if ((hint >= 8 && hint <= 11) || (hint >= 0x100 && hint < 0x300)) {          // the grouped ring kernel (conv_halo.hip; bits 8..9: tile geometry); no silent fall-back: the tuner asks per hint
     if (conv_halo_multi_try(m, d[0].x.dtype, d[0].y.dtype, hint, &op))
       GLS_FAIL(GLSDET_E_ARG, "conv2d_multi: the grouped halo kernel (hint %d) does not apply to this shape class", hint);
     return 0;
@@ -881,9 +882,24 @@ extern "C" int glsdet_conv2d_multi_tune(const glsdet_conv_desc* d, int32_t n, vo
   std::vector<OpRecord> ops;
   std::vector<int> ids;
   const bool no_ring = getenv("GLSDET_NO_RING_MULTI") != nullptr;       // A/B switch for measurements
-  for (int h : hints) {
+  std::vector<int> cand(hints, hints + sizeof(hints) / sizeof(hints[0]));
+  if (!getenv("GLSDET_NO_TILE_GEO") && (d[0].stride == 1 || d[0].stride == 2) && d[0].R == 3 && !no_ring) {
+    for (int geo = 1; geo <= 2; ++geo) {             // tile geometries with >= 3 % fewer tiles over the whole group
+      int th, tw;
+      tile_geo_dims(geo, &th, &tw);
+      long t0 = 0, t1 = 0;
+      for (int i = 0; i < n; ++i) {
+        t0 += (long)((d[i].y.h + 7) / 8) * ((d[i].y.w + 15) / 16);
+        t1 += (long)((d[i].y.h + th - 1) / th) * ((d[i].y.w + tw - 1) / tw);
+      }
+      if (t1 * 100 <= t0 * 97)
+        for (int h : {8, 9, 10, 11})
+          if (d[0].stride == 1 || h >= 10) cand.push_back((geo << 8) | h);
+    }
+  }
+  for (int h : cand) {
     OpRecord op;
-    if (no_ring && h >= 8 && h <= 11) continue;
+    if (no_ring && (h & 0xff) >= 8 && (h & 0xff) <= 11 && h < 0x10000) continue;
     if (build_conv_multi_op(d, n, h, op)) continue;
     ops.push_back(std::move(op));
     ids.push_back(h);
@@ -1039,11 +1055,26 @@ static int conv_tune(const glsdet_conv_desc* d, const glsdet_conv_chain* c, void
                        (128 << 16) | 0x8000};
   std::vector<OpRecord> ops;
   std::vector<int> ids;
-  for (int h : hints) {
+  std::vector<int> cand(hints, hints + sizeof(hints) / sizeof(hints[0]));
+  if (!c && (d->stride == 1 || (d->stride == 2 && d->R == 3)) && d->R == d->S && d->R >= 3 && !getenv("GLSDET_NO_TILE_GEO")) {
+    // other tile geometries of the ring kernels (conv_common.h TileGeo): offered where they need >= 3 % fewer tiles
+    const int Ho = d->y.h, Wo = d->y.w;
+    auto tiles = [&](int th, int tw) { return (long)((Ho + th - 1) / th) * ((Wo + tw - 1) / tw); };
+    for (int geo = 1; geo <= 2; ++geo) {
+      int th, tw;
+      tile_geo_dims(geo, &th, &tw);
+      if (tiles(th, tw) * 100 <= tiles(8, 16) * 97)
+        for (int h : {8, 9, 10, 11})
+          if (d->stride == 1 || h >= 10) cand.push_back((geo << 8) | h);
+      tile_geo8_dims(geo, &th, &tw);
+      if (d->stride == 1 && tiles(th, tw) * 100 <= tiles(8, 32) * 97) cand.push_back((geo << 8) | 13);
+    }
+  }
+  for (int h : cand) {
     OpRecord op;
-    if ((h >> 16) == 128 && (h & 0xff) == 0 && (c || d->y.c <= 64)) continue;      // the eight-wave tile: wide layers, no chain
+    if (h >= 0x10000 && (h >> 16) == 128 && (h & 0xff) == 0 && (c || d->y.c <= 64)) continue;      // the eight-wave tile: wide layers, no chain
     if (build_conv_op(d, h, op, c)) continue;          // variant does not apply
-    if ((h >> 16) == 32 && d->y.c > 32) continue;
+    if (h >= 0x10000 && (h >> 16) == 32 && d->y.c > 32) continue;
     ops.push_back(std::move(op));
     ids.push_back(h);
   }

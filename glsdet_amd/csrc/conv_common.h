@@ -224,6 +224,79 @@ __device__ __forceinline__ void pix_to_xy16(int pix, int& oy, int& ox) {
   ox = (oy & 1) ? ((m + ROT) & 15) : m;
 }
 
+// Tile geometries of the pixel-tile kernels (round 3).  A tile is TH x TW output pixels laid row-major onto the 128 (256)
+// MFMA lanes of a workgroup; TH * TW may fall short of the lane count (dead lanes: they multiply pixel 0 again and store
+// nothing).  8 x 16 wastes 28 % of the lanes on a 50 x 84 map and 47 % on a 13 x 21 quadrant; 10 x 12 and 6 x 21 tile those
+// maps with 7-17 % (tile counts: 42 -> 35, 12 -> 10, 4 -> 3 per image).  GEO: 0 = 8 x 16, 1 = 10 x 12, 2 = 6 x 21.
+template <int GEO> struct TileGeo;
+template <> struct TileGeo<0> { static constexpr int TH = 8, TW = 16; };
+template <> struct TileGeo<1> { static constexpr int TH = 10, TW = 12; };
+template <> struct TileGeo<2> { static constexpr int TH = 6, TW = 21; };
+inline void tile_geo_dims(int geo, int* th, int* tw) {
+  *th = geo == 1 ? 10 : (geo == 2 ? 6 : 8);
+  *tw = geo == 1 ? 12 : (geo == 2 ? 21 : 16);
+}
+inline void tile_geo8_dims(int geo, int* th, int* tw) {      // the 8-wave (256-lane) ring kernel: 8 x 32, 10 x 24, 6 x 42
+  *th = geo == 1 ? 10 : (geo == 2 ? 6 : 8);
+  *tw = geo == 1 ? 24 : (geo == 2 ? 42 : 32);
+}
+// tile-local pixel index -> (oy, ox); TW == 16 keeps the row rotation of pix_to_xy16
+template <int TW, int PW>
+__device__ __forceinline__ void pix_to_xy(int pix, int& oy, int& ox) {
+  if constexpr (TW == 16) {
+    pix_to_xy16<PW>(pix, oy, ox);
+  } else {
+    oy = pix / TW;                                  // (constant divisor)
+    ox = pix - oy * TW;
+  }
+}
+
+// Lane <-> pixel assignment of the other tile geometries.  The B fragment of an MFMA block is one ds_read_b128 per lane at
+// patch slot (oy * PW + ox); the LDS serves such a read in groups of 16 lanes ({0-3, 12-15, 20-27} and {4-11, 16-19, 28-31}
+// of each half wave) and a group is conflict free when its 16 slots differ mod 16 (row pitches of 80 / 144 bytes: slot * 5
+// resp. * 9 sixteen-byte columns, a bijection mod 16).  With rows of 12, 21, 24 or 42 pixels laid onto the lanes in row-major
+// order a group straddles patch rows and 43-55 % of the LDS cycles were bank conflicts (rocprofv3, 5x5 256 -> 256 @50x84),
+// which ate the whole gain of the smaller tile count.  So: the patch pitch is made ODD (every row then starts at another
+// slot residue), pixels are dealt to (group, position = slot mod 16) pairs -- the k-th pixel of a residue class goes to
+// group k -- and position m of a group sits on the lane of that group with lane % 16 == m.  pix[q]: row-major pixel index of
+// lane q (q = 32 * block + lane % 32), 0xffff = dead lane.  Built at compile time.
+template <int TH, int TW, int PW, int NL>
+struct GeoMap {
+  unsigned short pix[NL];
+  static constexpr int lane_of(int g, int m) {
+    const int j = g / 2;
+    int l = 0;
+    if ((g & 1) == 0) l = (m < 4 || m >= 12) ? m : 16 + m;
+    else l = (m >= 4 && m < 12) ? m : 16 + m;
+    return j * 32 + l;
+  }
+  constexpr GeoMap() : pix{} {
+    int cnt[16] = {};
+    bool used[NL] = {};
+    int over[NL] = {};
+    int nover = 0;
+    for (int q = 0; q < NL; ++q) pix[q] = 0xffff;
+    for (int p = 0; p < TH * TW; ++p) {
+      const int oy = p / TW, ox = p % TW, s = (oy * PW + ox) & 15;
+      const int g = cnt[s]++;
+      if (g < NL / 16) {
+        const int q = lane_of(g, s);
+        pix[q] = (unsigned short)p;
+        used[q] = true;
+      } else {
+        over[nover++] = p;                          // more than NL / 16 pixels of one residue: a (rare) two-way conflict
+      }
+    }
+    int qf = 0;
+    for (int i = 0; i < nover; ++i) {
+      while (used[qf]) ++qf;
+      pix[qf] = (unsigned short)over[i];
+      used[qf] = true;
+    }
+  }
+};
+template <int TH, int TW, int PW, int NL>
+struct GeoMapHolder { static constexpr GeoMap<TH, TW, PW, NL> map{}; };
 
 // Store phase of the 8 x 16 pixel-tile kernels: the staged tile (rows of ORS bytes in LDS) -> global, 16-byte chunks,
 // optional residual.  A thread's chunks are 256 / OCPR pixels apart -- one or two tile rows -- so its addresses advance
@@ -273,20 +346,21 @@ __device__ __forceinline__ void gn_tile_partials(const ConvArgs& a, int img, int
   }
 }
 
-template <typename TO, int CO_T, int PW, bool GN = false>
+template <typename TO, int CO_T, int PW, bool GN = false, int TH = 8, int TW = 16>
 __device__ __forceinline__ void halo_store_tile(const unsigned char* stile, const ConvArgs& a, int img, int ty0, int tx0, int co0,
                                                 int tid) {
   constexpr int PX_T = 128, ORS = CO_T * (int)sizeof(TO) + 16;
+  constexpr int LIVE = TH * TW;                   // lanes beyond the tile's pixels store nothing
   constexpr int VO = 16 / (int)sizeof(TO);
   constexpr int OCPR = CO_T / VO;                 // chunks per pixel
   constexpr int PXS = 256 / OCPR;                 // pixels between two chunks of one thread (a multiple of 16)
   float gs1 = 0.f, gs2 = 0.f;                     // (GN) sums over this thread's stored chunks
   if (sizeof(TO) == 2 && a.res) {                 // wide staging (fp32 rows): add in fp32, round once
     constexpr int ORSW = CO_T * 4 + 16;
-    for (int q = tid; q < PX_T * OCPR; q += 256) {
+    for (int q = tid; q < LIVE * OCPR; q += 256) {
       const int px_l = q / OCPR, cq = q - px_l * OCPR;
       int oy, ox;
-      pix_to_xy16<PW>(px_l, oy, ox);
+      pix_to_xy<TW, PW>(px_l, oy, ox);
       const int ho = ty0 + oy, wo = tx0 + ox, co = co0 + cq * VO;
       if (ho < a.Ho && wo < a.Wo && co < a.Cout) {
         const f32x4 lo = *reinterpret_cast<const f32x4*>(stile + px_l * ORSW + cq * 32);
@@ -301,11 +375,11 @@ __device__ __forceinline__ void halo_store_tile(const unsigned char* stile, cons
     if constexpr (GN) gn_tile_partials<TO, CO_T>(a, img, ty0, tx0, co0, tid, gs1, gs2);
     return;
   }
-  if constexpr (PXS % 16 != 0) {                  // fp32 output with 128-row tiles: 8 pixels apart, plain form
-    for (int q = tid; q < PX_T * OCPR; q += 256) {
+  if constexpr (PXS % 16 != 0 || TW != 16) {      // fp32 output with 128-row tiles (8 pixels apart) / other tile geometries: plain form
+    for (int q = tid; q < LIVE * OCPR; q += 256) {
       const int px_l = q / OCPR, cq = q - px_l * OCPR;
       int oy, ox;
-      pix_to_xy16<PW>(px_l, oy, ox);
+      pix_to_xy<TW, PW>(px_l, oy, ox);
       const int ho = ty0 + oy, wo = tx0 + ox, co = co0 + cq * VO;
       if (ho < a.Ho && wo < a.Wo && co < a.Cout) {
         u32x4 v = *reinterpret_cast<const u32x4*>(stile + px_l * ORS + cq * 16);
@@ -471,9 +545,14 @@ __device__ __forceinline__ void halo_store_tile_keep(unsigned char* stile, const
 
 // epilogue tail shared by the pixel-tile kernels: store the staged tile, then the chained 1x1 if this workgroup's cout tile
 // holds its input channels
-template <typename T, typename TO, int CO_T, int PW, bool CH, bool GN = false>
+template <typename T, typename TO, int CO_T, int PW, bool CH, bool GN = false, int TH = 8, int TW = 16>
 __device__ __forceinline__ void halo_store_and_chain(unsigned char* smem, const ConvArgs& a, int img, int ty0, int tx0, int co0,
                                                      int tid) {
+  static_assert((TH == 8 && TW == 16) || (!CH && !GN), "chained / GroupNorm forms exist for 8 x 16 tiles only");
+  if constexpr (TW != 16) {
+    halo_store_tile<TO, CO_T, PW, false, TH, TW>(smem, a, img, ty0, tx0, co0, tid);
+    return;
+  }
   if constexpr (GN) {
     halo_store_tile<TO, CO_T, PW, true>(smem, a, img, ty0, tx0, co0, tid);
     return;

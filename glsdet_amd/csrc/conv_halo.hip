@@ -246,24 +246,27 @@ __device__ __forceinline__ void halo_lds_barrier() {
 // (2*oy + r) * PW + ox + (s & 1 ? HALF : s >> 1) -- a per-lane base plus a per-tap constant, exactly as for stride 1.
 // byte offset of the parked scale | bias (CO_T * 8 bytes): behind the staging area AND this launch's epilogue tile
 // (wide = fp32 staging of a residual layer)
-template <typename T, typename TO, int CO_T, int KS, int RING, int KB, int STR>
+template <typename T, typename TO, int CO_T, int KS, int RING, int KB, int STR, int GEO = 0>
 __host__ __device__ constexpr int halo_ring_sb_off(bool wide) {
-  constexpr int PH = 7 * STR + KS, PW = 15 * STR + KS;
+  constexpr int PH = (TileGeo<GEO>::TH - 1) * STR + KS, PW0 = (TileGeo<GEO>::TW - 1) * STR + KS;
+  constexpr int PW = (GEO != 0 && PW0 % 2 == 0) ? PW0 + 1 : PW0;       // odd patch pitch (conv_common.h GeoMap)
   constexpr int stage = RING * CO_T * KB + PH * PW * (KB + 16);
   const int epi = epi_bytes<TO>(CO_T, 128, wide);
   return ((stage > epi ? stage : epi) + 15) / 16 * 16;
 }
 
-template <typename T, typename TO, int CO_T, int KS, int RING, int KB = 128, int STR = 1, bool CH = false, bool GN = false>
+template <typename T, typename TO, int CO_T, int KS, int RING, int KB = 128, int STR = 1, bool CH = false, bool GN = false, int GEO = 0>
 __device__ __forceinline__ void conv_halo_ring_body(const ConvArgs& a, const int tiles_x, const int tiles_y, const int tile) {
-  constexpr int TH = 8, TW = 16, WCO = 2;
+  constexpr int TH = TileGeo<GEO>::TH, TW = TileGeo<GEO>::TW, WCO = 2;
+  static_assert(GEO == 0 || (!CH && !GN), "other tile geometries: no chained / GroupNorm form");
   constexpr int RS = KB + 16;
   constexpr int CPRW = KB / 16;                    // 16-byte chunks per row
   constexpr int RPL = 256 / KB;                    // rows per 256 bytes: the swizzle is f(row) = (row / RPL) % CPRW
   constexpr int VEC = 16 / (int)sizeof(T);
   constexpr int KE = KB / (int)sizeof(T);
-  constexpr int PX_T = TH * TW;
-  constexpr int PH = (TH - 1) * STR + KS, PW = (TW - 1) * STR + KS;
+  constexpr int PX_T = 128;                        // 128 MFMA lanes; dead lanes (GeoMap) multiply pixel 0 again and store nothing
+  constexpr int PH = (TH - 1) * STR + KS, PW0 = (TW - 1) * STR + KS;
+  constexpr int PW = (GEO != 0 && PW0 % 2 == 0) ? PW0 + 1 : PW0;       // odd patch pitch for the other geometries (one spare column)
   constexpr int HALF = (PW + 1) / 2;               // STR 2: even columns occupy slots [0, HALF), odd ones [HALF, PW)
   constexpr int PITCH = STR * PW;                  // slots between two output rows
   static_assert(STR == 1 || (STR == 2 && KS == 3), "stride 2 is built for 3x3");
@@ -290,7 +293,7 @@ __device__ __forceinline__ void conv_halo_ring_body(const ConvArgs& a, const int
 
   // folded-BN scale / bias of the cout tile: requested first, parked in LDS behind the staging / epilogue areas when the
   // first patch has landed anyway (conv.hip: the epilogue then starts without a dependent global round trip)
-  unsigned char* sSB = smem + halo_ring_sb_off<T, TO, CO_T, KS, RING, KB, STR>(sizeof(TO) == 2 && a.res != nullptr);
+  unsigned char* sSB = smem + halo_ring_sb_off<T, TO, CO_T, KS, RING, KB, STR, GEO>(sizeof(TO) == 2 && a.res != nullptr);
   f32x4 sb_s = {0.f, 0.f, 0.f, 0.f}, sb_b = {0.f, 0.f, 0.f, 0.f};
   if (tid < CO_T / 4 && co0 + tid * 4 < a.cout_pad) {
     sb_s = *reinterpret_cast<const f32x4*>(a.scale + co0 + tid * 4);
@@ -377,11 +380,20 @@ __device__ __forceinline__ void conv_halo_ring_body(const ConvArgs& a, const int
 #pragma unroll
   for (int kk = 0; kk < KB / 32; ++kk) a_sw[kk] = ((2 * kk + lh) ^ ((l31 / RPL) & (CPRW - 1))) << 4;
   int b_off[TN];
+  int prow[TN];                                    // row of the staged output tile this lane's pixel goes to (-1: dead lane)
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int pix = wpx * WT_PX + j * 32 + l31;
     int oy, ox;
-    pix_to_xy16<PITCH>(pix, oy, ox);
+    if constexpr (GEO == 0) {
+      pix_to_xy16<PITCH>(pix, oy, ox);
+      prow[j] = pix;
+    } else {
+      const int p = GeoMapHolder<TH, TW, PITCH, 128>::map.pix[pix];       // (stride 2: a tile row is two patch rows further on)
+      prow[j] = p == 0xffff ? -1 : p;
+      oy = p == 0xffff ? 0 : p / TW;
+      ox = p == 0xffff ? 0 : p - oy * TW;
+    }
     b_off[j] = PATCH_OFF + (oy * PITCH + ox) * RS + lh * 16;
   }
 
@@ -448,23 +460,22 @@ __device__ __forceinline__ void conv_halo_ring_body(const ConvArgs& a, const int
       const f32x4 sc = *reinterpret_cast<const f32x4*>(sSB + co_l * 4), bi = *reinterpret_cast<const f32x4*>(sSB + CO_T * 4 + co_l * 4);
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
-        const int px_l = wpx * WT_PX + j * 32 + l31;
         const f32x4 xv = {acc[i][j][4 * gq], acc[i][j][4 * gq + 1], acc[i][j][4 * gq + 2], acc[i][j][4 * gq + 3]};
         const f32x4 yv = scale_bias_act4<T>(xv, sc, bi, a.act);
         const float v[4] = {yv[0], yv[1], yv[2], yv[3]};
-        stage4<TO, CO_T>(smem, px_l, co_l, v, wide);
+        if (GEO == 0 || prow[j] >= 0) stage4<TO, CO_T>(smem, prow[j], co_l, v, wide);      // staged in row-major pixel order
       }
     }
   }
   __syncthreads();
-  halo_store_and_chain<T, TO, CO_T, PITCH, CH, GN>(smem, a, img, ty0, tx0, co0, tid);
+  halo_store_and_chain<T, TO, CO_T, PITCH, CH, GN, TH, TW>(smem, a, img, ty0, tx0, co0, tid);
 }
 
-template <typename T, typename TO, int CO_T, int KS, int RING, int KB = 128, int STR = 1, bool CH = false, bool GN = false>
+template <typename T, typename TO, int CO_T, int KS, int RING, int KB = 128, int STR = 1, bool CH = false, bool GN = false, int GEO = 0>
 __global__ __launch_bounds__(256) void conv_halo_ring_kernel(const ConvArgs a, const int tiles_x, const int tiles_y) {
   const int nwg = gridDim.x, bid = blockIdx.x;
   const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, local = bid >> 3;       // XCD-aware tile order
-  conv_halo_ring_body<T, TO, CO_T, KS, RING, KB, STR, CH, GN>(a, tiles_x, tiles_y,
+  conv_halo_ring_body<T, TO, CO_T, KS, RING, KB, STR, CH, GN, GEO>(a, tiles_x, tiles_y,
                                                                (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local);
 }
 
@@ -472,13 +483,13 @@ __global__ __launch_bounds__(256) void conv_halo_ring_kernel(const ConvArgs a, c
 // l / r / t / b convs: each alone is a fraction of a round of workgroups) as ONE launch of the ring kernel; the
 // argument blocks travel in the kernarg segment as for conv_igemm_multi_kernel (conv.hip), a workgroup finds its problem
 // from the prefix of tile counts.
-template <typename T, typename TO, int CO_T, int KS, int RING, int KB, int STR>
+template <typename T, typename TO, int CO_T, int KS, int RING, int KB, int STR, int GEO = 0>
 __global__ __launch_bounds__(256) void conv_halo_ring_multi_kernel(const HaloArgsN m) {
   int g = 0;
 #pragma unroll
   for (int i = 1; i < GLS_MULTI; ++i)
     if (i < m.n && (int)blockIdx.x >= m.start[i]) g = i;
-  conv_halo_ring_body<T, TO, CO_T, KS, RING, KB, STR, false, false>(m.p[g], m.tx[g], m.ty[g], (int)blockIdx.x - m.start[g]);
+  conv_halo_ring_body<T, TO, CO_T, KS, RING, KB, STR, false, false, GEO>(m.p[g], m.tx[g], m.ty[g], (int)blockIdx.x - m.start[g]);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -487,12 +498,20 @@ __global__ __launch_bounds__(256) void conv_halo_ring_multi_kernel(const HaloArg
 // out 2 (cout) x 4 (pairs of pixel rows), each with the 64 x 64 register tile of the 128-row 4-wave form, so a tap's
 // weight tile (one DMA ring slot) serves twice the pixels.  A 32-lane MFMA block is one full tile row of 32 pixels: no
 // row rotation needed.  No residual / chained / GroupNorm forms.  Measured in DESIGN.md section 3.
-template <typename T, int KS, int RING, int KB>
+// GEO8: 0 = 8 x 32 pixels, 1 = 10 x 24 (240 of the 256 lanes live), 2 = 6 x 42 (252): a 100 x 168 map takes 78 / 70 / 68 tiles
+template <int GEO8> struct TileGeo8;
+template <> struct TileGeo8<0> { static constexpr int TH = 8, TW = 32; };
+template <> struct TileGeo8<1> { static constexpr int TH = 10, TW = 24; };
+template <> struct TileGeo8<2> { static constexpr int TH = 6, TW = 42; };
+
+template <typename T, int KS, int RING, int KB, int GEO8 = 0>
 __global__ __launch_bounds__(512) void conv_halo_ring8_kernel(const ConvArgs a, const int tiles_x, const int tiles_y) {
-  constexpr int TH = 8, TW = 32, CO_T = 128, NWV = 8;
+  constexpr int TH = TileGeo8<GEO8>::TH, TW = TileGeo8<GEO8>::TW, CO_T = 128, NWV = 8;
+  constexpr int LIVE = TH * TW;                    // of 256 MFMA lanes
   constexpr int RS = KB + 16, CPRW = KB / 16, RPL = 256 / KB;
   constexpr int VEC = 16 / (int)sizeof(T), KE = KB / (int)sizeof(T);
-  constexpr int PH = TH - 1 + KS, PW = TW - 1 + KS;
+  constexpr int PH = TH - 1 + KS, PW0 = TW - 1 + KS;
+  constexpr int PW = (GEO8 != 0 && PW0 % 2 == 0) ? PW0 + 1 : PW0;      // odd patch pitch for the other geometries (GeoMap)
   constexpr int NP = (PH * PW * CPRW + 511) / 512;
   constexpr int TM = 2, TN = 2;
   constexpr int A_BYTES = CO_T * KB;
@@ -501,7 +520,7 @@ __global__ __launch_bounds__(512) void conv_halo_ring8_kernel(const ConvArgs a, 
   static_assert(CO_T % (RPI * NWV) == 0 && RING >= 3, "ring geometry");
   constexpr int PATCH_OFF = RING * A_BYTES;
   constexpr int ORS = CO_T * (int)sizeof(T) + 16;
-  constexpr int STAGE = RING * A_BYTES + PH * PW * RS, EPI = TH * TW * ORS;
+  constexpr int STAGE = RING * A_BYTES + PH * PW * RS, EPI = 256 * ORS;
   constexpr int SB_OFF = ((STAGE > EPI ? STAGE : EPI) + 15) / 16 * 16;
 
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
@@ -594,8 +613,16 @@ __global__ __launch_bounds__(512) void conv_halo_ring8_kernel(const ConvArgs a, 
 #pragma unroll
   for (int kk = 0; kk < KB / 32; ++kk) a_sw[kk] = ((2 * kk + lh) ^ ((l31 / RPL) & (CPRW - 1))) << 4;
   int b_off[TN];
+  int prow[TN];                                    // row of the staged output tile (row-major pixel index; -1: dead lane)
 #pragma unroll
-  for (int j = 0; j < TN; ++j) b_off[j] = PATCH_OFF + ((wpx * 2 + j) * PW + l31) * RS + lh * 16;      // tile row wpx * 2 + j, column l31
+  for (int j = 0; j < TN; ++j) {                  // lanes of pixel block wpx * 2 + j (8 x 32: tile row wpx * 2 + j, column l31)
+    const int pix = (wpx * 2 + j) * 32 + l31;
+    int p = pix;
+    if constexpr (GEO8 != 0) p = GeoMapHolder<TH, TW, PW, 256>::map.pix[pix];
+    prow[j] = p == 0xffff ? -1 : p;
+    const int oy = p == 0xffff ? 0 : p / TW, ox = p == 0xffff ? 0 : p - oy * TW;
+    b_off[j] = PATCH_OFF + (oy * PW + ox) * RS + lh * 16;
+  }
 
   load_patch(0);
 #pragma unroll
@@ -652,19 +679,19 @@ __global__ __launch_bounds__(512) void conv_halo_ring8_kernel(const ConvArgs a, 
       const f32x4 sc = *reinterpret_cast<const f32x4*>(sSB + co_l * 4), bi = *reinterpret_cast<const f32x4*>(sSB + CO_T * 4 + co_l * 4);
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
-        const int px_l = (wpx * 2 + j) * 32 + l31;
         const f32x4 xv = {acc[i][j][4 * gq], acc[i][j][4 * gq + 1], acc[i][j][4 * gq + 2], acc[i][j][4 * gq + 3]};
         const f32x4 yv = scale_bias_act4<T>(xv, sc, bi, a.act);
         const float v[4] = {yv[0], yv[1], yv[2], yv[3]};
-        store4(smem + px_l * ORS + co_l * (int)sizeof(T), v, (T*)nullptr);
+        if (GEO8 == 0 || prow[j] >= 0) store4(smem + prow[j] * ORS + co_l * (int)sizeof(T), v, (T*)nullptr);
       }
     }
   }
   __syncthreads();
   constexpr int OCPR = CO_T / VEC;
-  for (int q = tid; q < TH * TW * OCPR; q += 512) {
+  for (int q = tid; q < LIVE * OCPR; q += 512) {
     const int px_l = q / OCPR, cq = q - px_l * OCPR;
-    const int ho = ty0 + (px_l >> 5), wo = tx0 + (px_l & 31), co = co0 + cq * VEC;
+    const int oy = px_l / TW, ox = px_l - oy * TW;
+    const int ho = ty0 + oy, wo = tx0 + ox, co = co0 + cq * VEC;
     if (ho < a.Ho && wo < a.Wo && co < a.Cout) {
       const long yo = (long)img * a.y_sn + (long)ho * a.y_sh + (long)wo * a.y_sw + co;
       *reinterpret_cast<u32x4*>(a.y + yo * (long)sizeof(T)) = *reinterpret_cast<const u32x4*>(smem + px_l * ORS + cq * 16);
@@ -672,13 +699,14 @@ __global__ __launch_bounds__(512) void conv_halo_ring8_kernel(const ConvArgs a, 
   }
 }
 
-template <typename T, int KS, int RING, int KB>
+template <typename T, int KS, int RING, int KB, int GEO8 = 0>
 static int launch_halo_ring8(const ConvArgs& a, hipStream_t st) {
-  constexpr int PH = 7 + KS, PW = 31 + KS, ORS = 128 * (int)sizeof(T) + 16;
+  constexpr int TH = TileGeo8<GEO8>::TH, TW = TileGeo8<GEO8>::TW;
+  constexpr int PH = TH - 1 + KS, PW0 = TW - 1 + KS, PW = (GEO8 != 0 && PW0 % 2 == 0) ? PW0 + 1 : PW0, ORS = 128 * (int)sizeof(T) + 16;
   constexpr int stage = RING * 128 * KB + PH * PW * (KB + 16), epi = 256 * ORS;
   constexpr int lds = ((stage > epi ? stage : epi) + 15) / 16 * 16 + 128 * 8;
   static_assert(lds <= 160 * 1024, "LDS");
-  auto kern = conv_halo_ring8_kernel<T, KS, RING, KB>;
+  auto kern = conv_halo_ring8_kernel<T, KS, RING, KB, GEO8>;
   static bool attr_set = false;
   if (!attr_set) {
     GLS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
@@ -686,7 +714,7 @@ static int launch_halo_ring8(const ConvArgs& a, hipStream_t st) {
   }
   ConvArgs b = a;
   b.n_co_tiles = (a.Cout + 127) / 128;
-  const int tiles_x = (a.Wo + 31) / 32, tiles_y = (a.Ho + 7) / 8;
+  const int tiles_x = (a.Wo + TW - 1) / TW, tiles_y = (a.Ho + TH - 1) / TH;
   gls_fastdiv(b.n_co_tiles, &b.nco_mul, &b.nco_sh);
   gls_fastdiv(tiles_x, &b.tx_mul, &b.tx_sh);
   gls_fastdiv(tiles_y, &b.ty_mul, &b.ty_sh);
@@ -698,20 +726,34 @@ static int launch_halo_ring8(const ConvArgs& a, hipStream_t st) {
 }
 
 template <typename T>
-static int halo_ring8_dispatch(const ConvArgs& a, bool k64, hipStream_t st) {
-  switch (a.R) {
-    case 3: return k64 ? launch_halo_ring8<T, 3, 4, 64>(a, st) : launch_halo_ring8<T, 3, 3, 128>(a, st);
-    case 5: return k64 ? launch_halo_ring8<T, 5, 4, 64>(a, st) : launch_halo_ring8<T, 5, 3, 128>(a, st);
-    case 7: return k64 ? launch_halo_ring8<T, 7, 4, 64>(a, st) : launch_halo_ring8<T, 7, 3, 128>(a, st);
+static int halo_ring8_dispatch(const ConvArgs& a, bool k64, int geo, hipStream_t st) {
+  if (geo == 0) {
+    switch (a.R) {
+      case 3: return k64 ? launch_halo_ring8<T, 3, 4, 64>(a, st) : launch_halo_ring8<T, 3, 3, 128>(a, st);
+      case 5: return k64 ? launch_halo_ring8<T, 5, 4, 64>(a, st) : launch_halo_ring8<T, 5, 3, 128>(a, st);
+      case 7: return k64 ? launch_halo_ring8<T, 7, 4, 64>(a, st) : launch_halo_ring8<T, 7, 3, 128>(a, st);
+    }
+  } else if (k64) {                // the other tile geometries: 64-byte channel chunks only (the form the tuner picks at 100 x 168)
+    switch (a.R * 4 + geo) {
+      case 3 * 4 + 1: return launch_halo_ring8<T, 3, 4, 64, 1>(a, st);
+      case 3 * 4 + 2: return launch_halo_ring8<T, 3, 4, 64, 2>(a, st);
+      case 5 * 4 + 1: return launch_halo_ring8<T, 5, 4, 64, 1>(a, st);
+      case 5 * 4 + 2: return launch_halo_ring8<T, 5, 4, 64, 2>(a, st);
+      case 7 * 4 + 1: return launch_halo_ring8<T, 7, 4, 64, 1>(a, st);
+      case 7 * 4 + 2: return launch_halo_ring8<T, 7, 4, 64, 2>(a, st);
+    }
   }
-  GLS_FAIL(GLSDET_E_ARG, "conv2d(halo ring8): unsupported kernel size %d", a.R);
+  GLS_FAIL(GLSDET_E_ARG, "conv2d(halo ring8): unsupported kernel size %d / geometry %d", a.R, geo);
 }
 
 // (the chained 1x1 exists for 3x3 stride 1 only: a CSP Bottleneck's conv2 -> the next Bottleneck's conv1)
 // and so do the GroupNorm partials (glsdet_conv2d_gnstats: the 3x3 tower convs of GFLHead / MPHead)
-template <typename T, typename TO, int CO_T, int KS, int RING, int KB = 128, int STR = 1, bool CH = false, bool GN = false>
+template <typename T, typename TO, int CO_T, int KS, int RING, int KB = 128, int STR = 1, bool CH = false, bool GN = false, int GEO = 0>
 static int launch_halo_ring(const ConvArgs& a, hipStream_t st) {
-  if constexpr (!CH && !GN && KS == 3 && STR == 1) {
+  if constexpr (GEO != 0) {
+    if (a.w2 || a.gn_part) GLS_FAIL(GLSDET_E_ARG, "conv2d: chained / GroupNorm forms exist for 8 x 16 tiles only");
+  }
+  if constexpr (!CH && !GN && KS == 3 && STR == 1 && GEO == 0) {
     if (a.w2) return launch_halo_ring<T, TO, CO_T, KS, RING, KB, STR, true, false>(a, st);
     if constexpr (sizeof(T) == sizeof(TO)) {
       if (a.gn_part) return launch_halo_ring<T, TO, CO_T, KS, RING, KB, STR, false, true>(a, st);
@@ -719,10 +761,10 @@ static int launch_halo_ring(const ConvArgs& a, hipStream_t st) {
   }
   if (a.w2 && !CH) GLS_FAIL(GLSDET_E_ARG, "conv2d_chain: this halo kernel has no chained form");
   if (a.gn_part && !GN) GLS_FAIL(GLSDET_E_ARG, "conv2d_gnstats: this halo kernel has no statistics form");
-  constexpr int ldsw = halo_ring_sb_off<T, TO, CO_T, KS, RING, KB, STR>(true) + CO_T * 8;
-  int lds = halo_ring_sb_off<T, TO, CO_T, KS, RING, KB, STR>(sizeof(TO) == 2 && a.res != nullptr) + CO_T * 8;
+  constexpr int ldsw = halo_ring_sb_off<T, TO, CO_T, KS, RING, KB, STR, GEO>(true) + CO_T * 8;
+  int lds = halo_ring_sb_off<T, TO, CO_T, KS, RING, KB, STR, GEO>(sizeof(TO) == 2 && a.res != nullptr) + CO_T * 8;
   if (a.w2 && chain_lds_bytes<T>(CO_T, 128, a) > lds) lds = chain_lds_bytes<T>(CO_T, 128, a);
-  auto kern = conv_halo_ring_kernel<T, TO, CO_T, KS, RING, KB, STR, CH, GN>;
+  auto kern = conv_halo_ring_kernel<T, TO, CO_T, KS, RING, KB, STR, CH, GN, GEO>;
   static int attr_lds = 64 * 1024;
   const int want_attr = lds > ldsw ? lds : ldsw;
   if (want_attr > attr_lds) {
@@ -731,7 +773,7 @@ static int launch_halo_ring(const ConvArgs& a, hipStream_t st) {
   }
   ConvArgs b = a;
   b.n_co_tiles = (a.Cout + CO_T - 1) / CO_T;
-  const int tiles_x = (a.Wo + 15) / 16, tiles_y = (a.Ho + 7) / 8;
+  const int tiles_x = (a.Wo + TileGeo<GEO>::TW - 1) / TileGeo<GEO>::TW, tiles_y = (a.Ho + TileGeo<GEO>::TH - 1) / TileGeo<GEO>::TH;
   gls_fastdiv(b.n_co_tiles, &b.nco_mul, &b.nco_sh);
   gls_fastdiv(tiles_x, &b.tx_mul, &b.tx_sh);
   gls_fastdiv(tiles_y, &b.ty_mul, &b.ty_sh);
@@ -742,14 +784,14 @@ static int launch_halo_ring(const ConvArgs& a, hipStream_t st) {
   return 0;
 }
 
-template <typename T, typename TO, int CO_T, int RING, int KB, int STR>
+template <typename T, typename TO, int CO_T, int RING, int KB, int STR, int GEO = 0>
 static int launch_halo_ring_multi(const ConvArgsN& m0, hipStream_t st) {
   constexpr int KS = 3;
   bool any_res = false;
   for (int i = 0; i < m0.n; ++i) any_res = any_res || m0.p[i].res != nullptr;
-  constexpr int ldsw = halo_ring_sb_off<T, TO, CO_T, KS, RING, KB, STR>(true) + CO_T * 8;
-  const int lds = halo_ring_sb_off<T, TO, CO_T, KS, RING, KB, STR>(sizeof(TO) == 2 && any_res) + CO_T * 8;
-  auto kern = conv_halo_ring_multi_kernel<T, TO, CO_T, KS, RING, KB, STR>;
+  constexpr int ldsw = halo_ring_sb_off<T, TO, CO_T, KS, RING, KB, STR, GEO>(true) + CO_T * 8;
+  const int lds = halo_ring_sb_off<T, TO, CO_T, KS, RING, KB, STR, GEO>(sizeof(TO) == 2 && any_res) + CO_T * 8;
+  auto kern = conv_halo_ring_multi_kernel<T, TO, CO_T, KS, RING, KB, STR, GEO>;
   static bool attr_set = false;
   if (!attr_set && ldsw > 64 * 1024) {
     GLS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, ldsw));
@@ -762,8 +804,8 @@ static int launch_halo_ring_multi(const ConvArgsN& m0, hipStream_t st) {
     ConvArgs& b = m.p[i];
     b = m0.p[i];
     b.n_co_tiles = (b.Cout + CO_T - 1) / CO_T;
-    m.tx[i] = (b.Wo + 15) / 16;
-    m.ty[i] = (b.Ho + 7) / 8;
+    m.tx[i] = (b.Wo + TileGeo<GEO>::TW - 1) / TileGeo<GEO>::TW;
+    m.ty[i] = (b.Ho + TileGeo<GEO>::TH - 1) / TileGeo<GEO>::TH;
     gls_fastdiv(b.n_co_tiles, &b.nco_mul, &b.nco_sh);
     gls_fastdiv(m.tx[i], &b.tx_mul, &b.tx_sh);
     gls_fastdiv(m.ty[i], &b.ty_mul, &b.ty_sh);
@@ -780,8 +822,11 @@ static int launch_halo_ring_multi(const ConvArgsN& m0, hipStream_t st) {
 // The grouped form of the ring kernel for glsdet_conv2d_multi: hints 8 / 9 (128-byte channel chunks, 64- / 128-row cout
 // tiles; stride 1) and 10 / 11 (64-byte chunks; stride 1 and 2), 3x3 only, no chained / GroupNorm forms.
 // Returns 1 when it does not apply, 0 when `op` (name + launch) was filled in.
-int conv_halo_multi_try(const ConvArgsN& m, int xdt, int ydt, int hint, OpRecord* op) {
+int conv_halo_multi_try(const ConvArgsN& m, int xdt, int ydt, int hint_in, OpRecord* op) {
+  const int geo = (hint_in >= 0x100 && hint_in < 0x300) ? (hint_in >> 8) : 0;       // tile geometry: 8 x 16 / 10 x 12 / 6 x 21
+  const int hint = geo ? (hint_in & 0xff) : hint_in;
   if (hint < 8 || hint > 11 || xdt != ydt) return 1;
+  if (geo && m.p[0].stride != 1 && !(hint_in & 2)) return 1;         // stride 2: 64-byte chunks (hints 10 / 11)
   const int es = dtype_size(xdt);
   const bool k64 = hint >= 10;
   const ConvArgs& a0 = m.p[0];
@@ -796,19 +841,46 @@ int conv_halo_multi_try(const ConvArgsN& m, int xdt, int ydt, int hint, OpRecord
   const int co_t = (hint == 9 || hint == 11) ? 128 : 64;
   const int str = a0.stride;
   char nm[112];
-  snprintf(nm, sizeof nm, "conv_halo_ring%s%s_multi[%d]<%s,%dx8x16> 3x3 s%d cin%d cout%d", k64 ? "_k64" : "", str == 2 ? "_s2" : "", m.n,
-           xdt ? "f32" : "f16", co_t, str, a0.Cin, a0.Cout);
+  int gth, gtw;
+  tile_geo_dims(geo, &gth, &gtw);
+  snprintf(nm, sizeof nm, "conv_halo_ring%s%s_multi[%d]<%s,%dx%dx%d> 3x3 s%d cin%d cout%d", k64 ? "_k64" : "", str == 2 ? "_s2" : "", m.n,
+           xdt ? "f32" : "f16", co_t, gth, gtw, str, a0.Cin, a0.Cout);
   op->name = nm;
-  op->launch = [m, co_t, xdt, k64, str](hipStream_t st) -> int {
+  op->launch = [m, co_t, xdt, k64, str, geo](hipStream_t st) -> int {
+#define GLS_HMG(T_, G_)                                                                                             \
+    if (geo == G_ && str == 2)                                                                                      \
+      return co_t == 128 ? launch_halo_ring_multi<T_, T_, 128, 4, 64, 2, G_>(m, st) : launch_halo_ring_multi<T_, T_, 64, 4, 64, 2, G_>(m, st); \
+    if (geo == G_) {                                                                                                \
+      if (k64) return co_t == 128 ? launch_halo_ring_multi<T_, T_, 128, 4, 64, 1, G_>(m, st) : launch_halo_ring_multi<T_, T_, 64, 4, 64, 1, G_>(m, st); \
+      return co_t == 128 ? launch_halo_ring_multi<T_, T_, 128, 3, 128, 1, G_>(m, st) : launch_halo_ring_multi<T_, T_, 64, 3, 128, 1, G_>(m, st);        \
+    }
 #define GLS_HM(T_)                                                                                                  \
+    GLS_HMG(T_, 1)                                                                                                  \
+    GLS_HMG(T_, 2)                                                                                                  \
     if (str == 2) return co_t == 128 ? launch_halo_ring_multi<T_, T_, 128, 4, 64, 2>(m, st) : launch_halo_ring_multi<T_, T_, 64, 4, 64, 2>(m, st); \
     if (k64) return co_t == 128 ? launch_halo_ring_multi<T_, T_, 128, 4, 64, 1>(m, st) : launch_halo_ring_multi<T_, T_, 64, 4, 64, 1>(m, st);      \
     return co_t == 128 ? launch_halo_ring_multi<T_, T_, 128, 3, 128, 1>(m, st) : launch_halo_ring_multi<T_, T_, 64, 3, 128, 1>(m, st);
     if (xdt == GLSDET_F16) { GLS_HM(f16) }
     GLS_HM(float)
 #undef GLS_HM
+#undef GLS_HMG
   };
   return 0;
+}
+
+// the other tile geometries (GEO 1 = 10 x 12, 2 = 6 x 21): 128-byte chunks for 3x3 only, 64-byte chunks for 3x3 / 5x5 / 7x7
+template <typename T, typename TO, int CO_T, int GEO>
+static int halo_ring_geo(const ConvArgs& a, bool k64, hipStream_t st) {
+  if (!k64) {
+    if (a.R == 3) return launch_halo_ring<T, TO, CO_T, 3, 3, 128, 1, false, false, GEO>(a, st);
+    GLS_FAIL(GLSDET_E_ARG, "conv2d(halo ring): tile geometry %d with 128-byte chunks exists for 3x3 only", GEO);
+  }
+  switch (a.R) {
+    case 3: return launch_halo_ring<T, TO, CO_T, 3, 4, 64, 1, false, false, GEO>(a, st);
+    case 5: return launch_halo_ring<T, TO, CO_T, 5, 4, 64, 1, false, false, GEO>(a, st);
+    case 7: return launch_halo_ring<T, TO, CO_T, 7, 4, 64, 1, false, false, GEO>(a, st);
+  }
+  GLS_FAIL(GLSDET_E_ARG, "conv2d(halo ring): unsupported kernel size %d", a.R);
 }
 
 template <typename T, typename TO, int CO_T>
@@ -875,18 +947,25 @@ static int halo_ring_k64_by_ks(const ConvArgs& a, hipStream_t st) {
 
 // Returns 1 when the halo kernel does not apply (caller falls back to the generic kernel),
 // 0 when `op` was filled in.
-int conv_halo_try(const ConvArgs& a, int xdt, int ydt, int hint, OpRecord* op) {
+int conv_halo_try(const ConvArgs& a, int xdt, int ydt, int hint_in, OpRecord* op) {
+  // tile geometry in bits 8..9 of a ring hint (8..13): 0x1xx = 10 x 12 (ring8: 10 x 24), 0x2xx = 6 x 21 (ring8: 6 x 42)
+  const int geo = (hint_in >= 0x100 && hint_in < 0x300) ? (hint_in >> 8) : 0;
+  const int hint = geo ? (hint_in & 0xff) : hint_in;
+  if (geo && (hint < 8 || hint > 13)) return 1;
   if (hint == 12 || hint == 13) {      // 8-wave 128 x 256 form of the ring kernel (13: 64-byte channel chunks)
     const int es8 = dtype_size(xdt);
     if (a.w2 || a.res || a.gn_part || xdt != ydt || a.stride != 1 || a.R != a.S || (a.R != 3 && a.R != 5 && a.R != 7) || a.pad != a.R / 2 ||
         a.cout_pad <= 64 || (a.Cin * es8) % (hint == 13 ? 64 : 128))
       return 1;
     const bool k64 = hint == 13;
+    if (geo && !k64) return 1;
+    int gth, gtw;
+    tile_geo8_dims(geo, &gth, &gtw);
     char nm8[96];
-    snprintf(nm8, sizeof nm8, "conv_halo_ring8%s<%s,128x8x32> %dx%d s1 cin%d cout%d", k64 ? "_k64" : "", xdt ? "f32" : "f16", a.R, a.S, a.Cin, a.Cout);
+    snprintf(nm8, sizeof nm8, "conv_halo_ring8%s<%s,128x%dx%d> %dx%d s1 cin%d cout%d", k64 ? "_k64" : "", xdt ? "f32" : "f16", gth, gtw, a.R, a.S, a.Cin, a.Cout);
     op->name = nm8;
-    op->launch = [a, xdt, k64](hipStream_t st) -> int {
-      return xdt == GLSDET_F16 ? halo_ring8_dispatch<f16>(a, k64, st) : halo_ring8_dispatch<float>(a, k64, st);
+    op->launch = [a, xdt, k64, geo](hipStream_t st) -> int {
+      return xdt == GLSDET_F16 ? halo_ring8_dispatch<f16>(a, k64, geo, st) : halo_ring8_dispatch<float>(a, k64, geo, st);
     };
     return 0;
   }
@@ -894,6 +973,7 @@ int conv_halo_try(const ConvArgs& a, int xdt, int ydt, int hint, OpRecord* op) {
   const int es = dtype_size(xdt);
   if (a.w2 && (a.R != 3 || a.stride != 1)) return 1;      // chained 1x1: compiled into the 3x3 stride-1 forms only
   if (a.gn_part && (a.R != 3 || a.stride != 1 || hint < 8 || hint > 11 || a.w2 || a.res)) return 1;   // GN partials: ring forms only
+  if (geo && (a.w2 || a.gn_part)) return 1;
   if (a.stride == 2) {            // 3x3 stride 2: the de-interleaved-patch form of the ring kernel, 64-byte channel chunks
     if (a.R != 3 || a.S != 3 || a.pad != 1 || xdt != ydt || (a.Cin * es) % 64 || (hint != 0 && hint != 10 && hint != 11)) return 1;
     if (hint == 11 && a.cout_pad <= 64) return 1;
@@ -902,9 +982,16 @@ int conv_halo_try(const ConvArgs& a, int xdt, int ydt, int hint, OpRecord* op) {
     const int co_t = (a.cout_pad <= 64 || hint != 11) ? 64 : 128;      // measured: 64-row tiles win unless the tuner says otherwise
     if (a.w2 && a.c2_0 / co_t != (a.c2_0 + a.cin2 - 1) / co_t) return 1;
     char nm[96];
-    snprintf(nm, sizeof nm, "conv_halo_ring_k64_s2<%s,%dx8x16> 3x3 s2 cin%d cout%d%s", xdt ? "f32" : "f16", co_t, a.Cin, a.Cout, a.w2 ? " +1x1" : "");
+    int sth, stw;
+    tile_geo_dims(geo, &sth, &stw);
+    snprintf(nm, sizeof nm, "conv_halo_ring_k64_s2<%s,%dx%dx%d> 3x3 s2 cin%d cout%d%s", xdt ? "f32" : "f16", co_t, sth, stw, a.Cin, a.Cout, a.w2 ? " +1x1" : "");
     op->name = nm;
-    op->launch = [a, co_t, xdt](hipStream_t st) -> int {
+    op->launch = [a, co_t, xdt, geo](hipStream_t st) -> int {
+#define GLS_S2(T_, G_)                                                                                                                  \
+      if (geo == G_) return co_t == 128 ? launch_halo_ring<T_, T_, 128, 3, 4, 64, 2, false, false, G_>(a, st)                               \
+                                        : launch_halo_ring<T_, T_, 64, 3, 4, 64, 2, false, false, G_>(a, st);
+      if (xdt == GLSDET_F16) { GLS_S2(f16, 1) GLS_S2(f16, 2) } else { GLS_S2(float, 1) GLS_S2(float, 2) }
+#undef GLS_S2
       if (xdt == GLSDET_F16) return co_t == 128 ? launch_halo_ring<f16, f16, 128, 3, 4, 64, 2>(a, st) : launch_halo_ring<f16, f16, 64, 3, 4, 64, 2>(a, st);
       return co_t == 128 ? launch_halo_ring<float, float, 128, 3, 4, 64, 2>(a, st) : launch_halo_ring<float, float, 64, 3, 4, 64, 2>(a, st);
     };
@@ -913,6 +1000,7 @@ int conv_halo_try(const ConvArgs& a, int xdt, int ydt, int hint, OpRecord* op) {
   if (a.stride != 1 || a.R != a.S || (a.R != 3 && a.R != 5 && a.R != 7) || a.pad != a.R / 2) return 1;
   if ((a.Cin * es) % ((hint == 10 || hint == 11) ? 64 : 128)) return 1;      // whole channel chunks (hint 10 works on 64-byte chunks)
   if (xdt != ydt) return 1;
+  if (geo && !((hint == 8 || hint == 9) ? a.R == 3 : (hint == 10 || hint == 11))) return 1;
   // wasted MFMA work on partial tiles: prefer the flat-pixel kernel when it is large
   const long tiles = (long)((a.Ho + 7) / 8) * ((a.Wo + 15) / 16);
   const double waste = (double)tiles * 128.0 / ((double)a.Ho * a.Wo);
@@ -925,10 +1013,20 @@ int conv_halo_try(const ConvArgs& a, int xdt, int ydt, int hint, OpRecord* op) {
   if (wpriv && co_t != 128) return 1;
   if (a.w2 && a.c2_0 / co_t != (a.c2_0 + a.cin2 - 1) / co_t) return 1;      // chained 1x1: its input channels in ONE cout tile
   char nm[96];
-  snprintf(nm, sizeof nm, "conv_halo%s<%s,%dx8x16> %dx%d s1 cin%d cout%d%s", wpriv ? "_wp" : (ring ? (ring_k64 ? "_ring_k64" : "_ring") : ""), xdt ? "f32" : "f16", co_t, a.R,
+  int gth, gtw;
+  tile_geo_dims(geo, &gth, &gtw);
+  snprintf(nm, sizeof nm, "conv_halo%s<%s,%dx%dx%d> %dx%d s1 cin%d cout%d%s", wpriv ? "_wp" : (ring ? (ring_k64 ? "_ring_k64" : "_ring") : ""), xdt ? "f32" : "f16", co_t, gth, gtw, a.R,
            a.S, a.Cin, a.Cout, a.w2 ? " +1x1" : "");
   op->name = nm;
-  op->launch = [a, co_t, xdt, wpriv, ring, ring_k64](hipStream_t st) -> int {
+  op->launch = [a, co_t, xdt, wpriv, ring, ring_k64, geo](hipStream_t st) -> int {
+    if (geo == 1) {
+      if (xdt == GLSDET_F16) return co_t == 128 ? halo_ring_geo<f16, f16, 128, 1>(a, ring_k64, st) : halo_ring_geo<f16, f16, 64, 1>(a, ring_k64, st);
+      return co_t == 128 ? halo_ring_geo<float, float, 128, 1>(a, ring_k64, st) : halo_ring_geo<float, float, 64, 1>(a, ring_k64, st);
+    }
+    if (geo == 2) {
+      if (xdt == GLSDET_F16) return co_t == 128 ? halo_ring_geo<f16, f16, 128, 2>(a, ring_k64, st) : halo_ring_geo<f16, f16, 64, 2>(a, ring_k64, st);
+      return co_t == 128 ? halo_ring_geo<float, float, 128, 2>(a, ring_k64, st) : halo_ring_geo<float, float, 64, 2>(a, ring_k64, st);
+    }
     if (ring_k64) {
       if (xdt == GLSDET_F16) return co_t == 128 ? halo_ring_k64_by_ks<f16, f16, 128>(a, st) : halo_ring_k64_by_ks<f16, f16, 64>(a, st);
       return co_t == 128 ? halo_ring_k64_by_ks<float, float, 128>(a, st) : halo_ring_k64_by_ks<float, float, 64>(a, st);

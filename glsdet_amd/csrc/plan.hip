@@ -1,5 +1,6 @@
 // Error text, view validation, and the plan (record -> eager replay / hipGraph replay).
 #include <stdarg.h>
+#include <stdlib.h>
 #include <string.h>
 #include <vector>
 
@@ -91,6 +92,23 @@ static int replay(glsdet_plan* p, hipStream_t st, bool use_branches) {
 namespace glsdet {
 int submit(OpRecord&& op, void* stream) {
   if (g_recording) {
+    // timing experiments (tools/probe/knockout.sh): ops whose name contains one of the comma-separated tokens of
+    // GLSDET_SKIP_OPS are recorded as no-ops -- the results of such a plan are garbage, only its wall clock is of interest
+    if (const char* skip = getenv("GLSDET_SKIP_OPS")) {
+      std::string all(skip);
+      size_t pos = 0;
+      while (pos <= all.size()) {
+        const size_t e = all.find(',', pos);
+        const std::string tok = all.substr(pos, e == std::string::npos ? std::string::npos : e - pos);
+        if (!tok.empty() && op.name.find(tok) != std::string::npos) {
+          op.launch = [](hipStream_t) -> int { return 0; };
+          op.name = "SKIPPED " + op.name;
+          break;
+        }
+        if (e == std::string::npos) break;
+        pos = e + 1;
+      }
+    }
     op.branch = g_branch;
     g_recording->ops.emplace_back(std::move(op));
     return 0;

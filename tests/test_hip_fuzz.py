@@ -11,8 +11,9 @@ from tests.test_hip_ops import TOL, _cmp, _to_view
 
 pytestmark = pytest.mark.gpu
 
-GEMM_HINTS = list(range(16, 32))       # persistent LDS-DMA 1x1 kernel (conv_gemm.hip), every variant
-HINTS = [0, 1, 2, 3, 4, 5, 8, 9, 10, 11, 12, 13] + GEMM_HINTS + [(128 << 16) | 128, (64 << 16) | 128, (64 << 16) | 64, (32 << 16) | 128,
+GEMM_HINTS = list(range(16, 32))
+GEO_HINTS = [(g << 8) | h for g in (1, 2) for h in (8, 9, 10, 11, 13)]       # ring kernels on 10 x 12 / 6 x 21 (10 x 24 / 6 x 42) pixel tiles       # persistent LDS-DMA 1x1 kernel (conv_gemm.hip), every variant
+HINTS = [0, 1, 2, 3, 4, 5, 8, 9, 10, 11, 12, 13] + GEMM_HINTS + GEO_HINTS + [(128 << 16) | 128, (64 << 16) | 128, (64 << 16) | 64, (32 << 16) | 128,
          (64 << 16) | 64 | 0x8000, (128 << 16) | 128 | 0x8000, (128 << 16), (128 << 16) | 0x8000]
 
 
@@ -96,7 +97,7 @@ def _kxk_cases(n, seed):
 @pytest.mark.parametrize("mode", ["f16", "f32"])
 @pytest.mark.parametrize("case", _kxk_cases(16, 11), ids=lambda c: "n%d_ci%d_co%d_k%d_s%d_%dx%d_%s_r%d_e%d" % c)
 def test_conv2d_random_kxk_problem_halo_family(engines, mode, case):
-    _run_case(engines, mode, case, [0, 1, 2, 4, 5, 8, 9, 10, 11, 12, 13])
+    _run_case(engines, mode, case, [0, 1, 2, 4, 5, 8, 9, 10, 11, 12, 13] + GEO_HINTS)
 
 
 def _s2_cases(n, seed):
@@ -119,7 +120,7 @@ def _s2_cases(n, seed):
 @pytest.mark.parametrize("mode", ["f16", "f32"])
 @pytest.mark.parametrize("case", _s2_cases(14, 23), ids=lambda c: "n%d_ci%d_co%d_k%d_s%d_%dx%d_%s_r%d_e%d" % c)
 def test_conv2d_random_stride2_problem_halo_family(engines, mode, case):
-    _run_case(engines, mode, case, [0, 1, 10, 11, (64 << 16) | 128])
+    _run_case(engines, mode, case, [0, 1, 10, 11, (64 << 16) | 128, 0x10a, 0x10b, 0x20a, 0x20b])
 
 
 def _gemm_cases(n, seed):

@@ -34,6 +34,11 @@ GLS_1X1 = [  # the 1x1 layers of YOLOX-s + GL neck at 8 x 800 x 1344 (profiles/r
     (8, 50, 84, 640, 256, 1, 1), (8, 50, 84, 384, 256, 1, 1), (8, 25, 42, 512, 256, 1, 1), (8, 25, 42, 1024, 512, 1, 1),
     (8, 25, 42, 512, 512, 1, 1), (8, 25, 42, 256, 256, 1, 1),
 ]
+QUANT = [  # tile-count quantisation probe: the same layer on maps that need 1.2 / 0.94 / 0.75 rounds of workgroups
+    (8, 100, 168, 128, 128, 7, 1), (8, 80, 168, 128, 128, 7, 1), (8, 64, 168, 128, 128, 7, 1), (8, 104, 192, 128, 128, 7, 1),
+    (8, 50, 84, 256, 256, 5, 1), (8, 48, 80, 256, 256, 5, 1), (8, 40, 80, 256, 256, 5, 1),
+    (8, 100, 168, 128, 256, 3, 1), (8, 80, 160, 128, 256, 3, 1),
+]
 RESNET = [  # ResNet-50 / FPN / head layers at 8 x 800 x 1344
     (8, 50, 84, 1024, 256, 1, 1),
     (8, 50, 84, 256, 1024, 1, 1),
@@ -51,7 +56,9 @@ HINTS = {"auto": 0, "halo": 2, "halowp": 4, "halo64": 5, "dma64": 6, "dma128": 7
          "g64x64": (64 << 16) | 64, "g64x64k64": (64 << 16) | 64 | 0x8000, "g64x128k64": (64 << 16) | 128 | 0x8000, "g32x128": (32 << 16) | 128,
          "g128x128k64": (128 << 16) | 128 | 0x8000, "g128x256": (128 << 16), "g128x256k64": (128 << 16) | 0x8000,
          "p64x64": 16, "p128x64": 17, "p64x128": 18, "p128x128": 19, "p128x128k64": 20, "p32x128": 21, "pw64x128": 22, "pw128x64": 23,
-         "pw64x64": 24, "pw32x128": 25, "pw128x128": 26, "p64x64k64": 27, "p128x64k64": 28, "s64x64": 29, "s64x128": 30, "s32x128": 31}
+         "pw64x64": 24, "pw32x128": 25, "pw128x128": 26, "p64x64k64": 27, "p128x64k64": 28, "s64x64": 29, "s64x128": 30, "s32x128": 31,
+         "ring64g1": 0x108, "ring128g1": 0x109, "ring64k64g1": 0x10a, "ring128k64g1": 0x10b, "ring8k64g1": 0x10d,
+         "ring64g2": 0x208, "ring128g2": 0x209, "ring64k64g2": 0x20a, "ring128k64g2": 0x20b, "ring8k64g2": 0x20d}
 
 
 def main():
@@ -61,6 +68,8 @@ def main():
     shapes = SHAPES
     if args and args[0] == "resnet":
         shapes, args = RESNET, args[1:]
+    elif args and args[0] == "quant":
+        shapes, args = QUANT, args[1:]
     elif args and args[0] == "gls1x1":
         shapes, args = GLS_1X1, args[1:]
     only = args or None

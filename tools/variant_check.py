@@ -27,8 +27,12 @@ HINTS = {"generic": 1, "halo": 2, "halo_wp": 4, "halo_co64": 5, "halo_ring64": 8
          "halo_ring64k64": 10, "halo_ring128k64": 11, "halo_ring8": 12, "halo_ring8k64": 13, "ws1x1": 3, "g128x128": (128 << 16) | 128, "g64x128": (64 << 16) | 128,
          "g64x64": (64 << 16) | 64, "g32x128": (32 << 16) | 128, "g64x64k64": (64 << 16) | 64 | 0x8000,
          "g64x128k64": (64 << 16) | 128 | 0x8000, "g128x128k64": (128 << 16) | 128 | 0x8000, "g128x256": (128 << 16),
-         "g128x256k64": (128 << 16) | 0x8000}
-MULTI = {"m128x128": (128 << 16) | 128, "m64x128": (64 << 16) | 128, "m64x64": (64 << 16) | 64,
+         "g128x256k64": (128 << 16) | 0x8000,
+         "ring64_10x12": 0x108, "ring128_10x12": 0x109, "ring64k64_10x12": 0x10a, "ring128k64_10x12": 0x10b, "ring8k64_10x24": 0x10d,
+         "ring64_6x21": 0x208, "ring128_6x21": 0x209, "ring64k64_6x21": 0x20a, "ring128k64_6x21": 0x20b, "ring8k64_6x42": 0x20d,
+         "gemm_p64x64": 16, "gemm_p128x128k64": 20, "gemm_pw64x128": 22, "gemm_pw64x64": 24, "gemm_pw32x128": 25, "gemm1_64x64": 29}
+MULTI = {"mring64_10x12": 0x108, "mring64k64_10x12": 0x10a, "mring64_6x21": 0x208, "mring64k64_6x21": 0x20a, "mring128k64_6x21": 0x20b,
+         "m128x128": (128 << 16) | 128, "m64x128": (64 << 16) | 128, "m64x64": (64 << 16) | 64,
          "m64x64k64": (64 << 16) | 64 | 0x8000, "m64x128k64": (64 << 16) | 128 | 0x8000, "m128x128k64": (128 << 16) | 128 | 0x8000}
 dev = "cuda:0"
 BAR = {"f32": 5e-5, "f16": 1.2e-3}
