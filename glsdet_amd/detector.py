@@ -2,6 +2,7 @@
 (optionally one hipGraph) per input shape, no Python in the per-layer loop."""
 from __future__ import annotations
 
+import threading
 from typing import Dict, List, Optional, Tuple
 
 import numpy as np
@@ -25,6 +26,7 @@ class HipDetector:
         self.kind, self.dtype, self.device, self.autotune = kind, dtype, device, autotune
         self.sd = {k: v.detach().cpu() for k, v in state_dict.items()}
         self._compiled: Dict[Tuple, _Compiled] = {}
+        self._cache_lock = threading.Lock()       # plan cache: looked up / LRU-touched / evicted by several lanes' threads
         self.num_classes = None
 
     # ------------------------------------------------------------------ compile
@@ -35,9 +37,10 @@ class HipDetector:
         `instance` > 0 builds an independent copy (own buffers, own stream) of the same plan, so
         consecutive batches can be in flight concurrently (see run_async)."""
         key = (n, H, W, tuple(sorted(post.items())) if post else None, use_graph, instance)
-        if key in self._compiled:
-            self._compiled[key] = self._compiled.pop(key)          # most recently used last
-            return self._compiled[key]
+        with self._cache_lock:
+            if key in self._compiled:
+                self._compiled[key] = self._compiled.pop(key)      # most recently used last
+                return self._compiled[key]
         if H % 32 or W % 32:
             raise ValueError("input H and W must be multiples of 32 (got %dx%d)" % (H, W))
         eng = Engine(self.dtype, self.device, autotune=self.autotune)
@@ -73,14 +76,16 @@ class HipDetector:
                 with torch.cuda.stream(c.graph_stream):
                     c.plan.capture(c.graph_stream)
                 c.graph_stream.synchronize()
-        self._compiled[key] = c
+        # (two threads asking for the same key at once both build; the second insert wins, the first plan is dropped: correct, rare)
         # LRU cap on resident plans (each holds its activations, an NMS workspace and, today, its own copy of the packed
         # weights): the UFPMP fine stage compiles one plan per padded mosaic shape and lane -- without a cap HBM grows with
         # every new shape over a data set.  GLSDET_MAX_PLANS (default 24) plans stay; evicted ones are rebuilt on demand.
         import os as _os
         cap = int(_os.environ.get("GLSDET_MAX_PLANS", "24"))
-        while len(self._compiled) > max(1, cap):
-            self._compiled.pop(next(iter(self._compiled)))
+        with self._cache_lock:
+            self._compiled[key] = c
+            while len(self._compiled) > max(1, cap):
+                self._compiled.pop(next(iter(self._compiled)))
         return c
 
     # ------------------------------------------------------------------ run

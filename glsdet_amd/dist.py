@@ -40,6 +40,26 @@ def ranks_agree(flag: bool, mode: str = "all", device="cpu", group=None) -> bool
     return bool(int(t.item()))
 
 
+def share_tuning(src: int = 0, group=None) -> int:
+    """Every rank adopts rank `src`'s kernel-selection table (Engine autotune results, all dtypes), so that all ranks of a
+    job run IDENTICAL kernel variants: tuned independently, near-ties fall differently per GPU and the slowest rank's
+    choice sets the weak-scaling step.  Call it after `src` has built (tuned) its plans and before the others build
+    theirs; ranks != src then find every key in the table and measure nothing.  One object broadcast (a few KB).
+    -> number of entries now in the table.  No process group / one rank: a no-op."""
+    from . import engine
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return sum(len(v) for v in engine._SHARED_TUNED.values())
+    rank = dist.get_rank(group)
+    box = [{dt: [(list(k), v) for k, v in tab.items()] for dt, tab in engine._SHARED_TUNED.items()}] if rank == src else [None]
+    dist.broadcast_object_list(box, src=src, group=group)
+    if rank != src:
+        for dt, items in box[0].items():
+            tab = engine._SHARED_TUNED.setdefault(dt, {})
+            for k, v in items:
+                tab[tuple(k)] = v
+    return sum(len(v) for v in engine._SHARED_TUNED.values())
+
+
 def pack_detections(dets: torch.Tensor, count: torch.Tensor) -> torch.Tensor:
     """dets [n, max_det, 7] + count [>=n] int32 -> [n, max_det+1, 7] fp32 (count in [:, -1, 0])."""
     n, k, f = dets.shape

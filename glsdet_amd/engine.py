@@ -8,6 +8,7 @@ from __future__ import annotations
 import ctypes as C
 import json
 import os
+import threading
 from typing import List, Optional, Sequence, Tuple
 
 import numpy as np
@@ -127,6 +128,7 @@ def _stream_ptr(stream) -> int:
 
 
 _SHARED_TUNED: dict = {}
+_TUNE_IO_LOCK = threading.Lock()       # save_tune_cache: lanes of one process share the table and the cache file
 
 
 class _Ptr:
@@ -890,19 +892,20 @@ class Engine:
     def save_tune_cache(self):
         if not self._tune_cache_path or not getattr(self, "_tune_dirty", False):
             return
-        data = {}
-        if os.path.exists(self._tune_cache_path):
-            try:
-                with open(self._tune_cache_path) as f:
-                    data = json.load(f)
-            except ValueError:                      # another rank's half-written file from before the rename below existed
-                data = {}
-        data[self._dtype_name] = {json.dumps(list(k)): v for k, v in self._tuned.items()}
-        tmp = "%s.%d.tmp" % (self._tune_cache_path, os.getpid())          # ranks sharing one cache path: whole files only
-        with open(tmp, "w") as f:
-            json.dump(data, f)
-        os.replace(tmp, self._tune_cache_path)
-        self._tune_dirty = False
+        with _TUNE_IO_LOCK:                         # other lanes' tuners insert into the shared table meanwhile: snapshot it
+            data = {}
+            if os.path.exists(self._tune_cache_path):
+                try:
+                    with open(self._tune_cache_path) as f:
+                        data = json.load(f)
+                except ValueError:                  # another rank's half-written file from before the rename below existed
+                    data = {}
+            data[self._dtype_name] = {json.dumps(list(k)): v for k, v in list(self._tuned.items())}
+            tmp = "%s.%d.%d.tmp" % (self._tune_cache_path, os.getpid(), threading.get_ident())   # whole files only, one tmp per writer
+            with open(tmp, "w") as f:
+                json.dump(data, f)
+            os.replace(tmp, self._tune_cache_path)
+            self._tune_dirty = False
 
     def new_plan(self) -> Plan:
         return Plan(self.lib)

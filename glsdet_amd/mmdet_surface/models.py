@@ -35,8 +35,17 @@ _HEAD = (("multi_level_cls_convs", "cls_convs"), ("multi_level_reg_convs", "reg_
          ("multi_level_conv_obj", "obj_preds"))
 
 
+_DW = (("depthwise_conv", "dconv"), ("pointwise_conv", "pconv"))     # mmcv DepthwiseSeparableConvModule -> drone DWConv (baseConv.py:22-30)
+
+
 def _csp_inner(k: str) -> str:
-    for a, b in _CSP:
+    for a, b in _CSP + _DW:
+        k = re.sub(r"(^|\.)%s(\.|$)" % a, r"\g<1>%s\g<2>" % b, k)
+    return k
+
+
+def _dw(k: str) -> str:
+    for a, b in _DW:
         k = re.sub(r"(^|\.)%s(\.|$)" % a, r"\g<1>%s\g<2>" % b, k)
     return k
 
@@ -62,7 +71,7 @@ def mmdet_to_drone_key(k: str) -> str:
         r = k[len("bbox_head."):]
         for a, b in _HEAD:
             if r.startswith(a + "."):
-                return "head.%s.%s" % (b, r[len(a) + 1:])
+                return "head.%s.%s" % (b, _dw(r[len(a) + 1:]))
     raise KeyError(k)
 
 
@@ -78,18 +87,27 @@ def _check_cfgs(conv_cfg, norm_cfg, act_cfg, use_depthwise):
         raise NotImplementedError("only BN(eps=1e-3) is folded by the HIP path, got %r" % (norm_cfg,))
     if dict(act_cfg).get("type") != "Swish":
         raise NotImplementedError("only Swish/SiLU activations are lowered, got %r" % (act_cfg,))
-    if use_depthwise:
-        raise NotImplementedError("use_depthwise=True is not lowered yet")
+    # use_depthwise=True (configs/yolox/yolox_nano_8x8_300e_coco.py): mmcv's DepthwiseSeparableConvModule = depthwise kxk ConvModule
+    # + pointwise 1x1 ConvModule, each conv + BN + act -- the drone tree's DWConv, lowered by glsdet_dwconv2d + a 1x1 (nets.py)
 
 
-def _mm_csp(t: _Table, p: str, cin: int, cout: int, n: int):
+def _mm_conv(t: _Table, p: str, cin: int, cout: int, k: int, depthwise: bool):
+    """ConvModule, or DepthwiseSeparableConvModule with its registration order (depthwise_conv, then pointwise_conv)."""
+    if depthwise:
+        t.conv_bn(p + ".depthwise_conv", cin, cin, k, groups=cin)
+        t.conv_bn(p + ".pointwise_conv", cin, cout, 1)
+    else:
+        t.conv_bn(p, cin, cout, k)
+
+
+def _mm_csp(t: _Table, p: str, cin: int, cout: int, n: int, depthwise: bool = False):
     hid = int(cout * 0.5)
     t.conv_bn(p + ".main_conv", cin, hid, 1)
     t.conv_bn(p + ".short_conv", cin, hid, 1)
     t.conv_bn(p + ".final_conv", 2 * hid, cout, 1)
     for i in range(n):
         t.conv_bn("%s.blocks.%d.conv1" % (p, i), hid, hid, 1)
-        t.conv_bn("%s.blocks.%d.conv2" % (p, i), hid, hid, 3)
+        _mm_conv(t, "%s.blocks.%d.conv2" % (p, i), hid, hid, 3, depthwise)       # utils/csp_layer.py:44-60
 
 
 @BACKBONES.register_module()
@@ -117,18 +135,18 @@ class CSPDarknet(TableModule):
         for i, (cin, cout, nb, _add, spp) in enumerate(setting):
             cin, cout = int(cin * widen_factor), int(cout * widen_factor)
             nb = max(round(nb * deepen_factor), 1)
-            t.conv_bn("stage%d.0" % (i + 1), cin, cout, 3)
+            _mm_conv(t, "stage%d.0" % (i + 1), cin, cout, 3, use_depthwise)      # backbones/csp_darknet.py:212,232-240
             j = 1
             if spp:
                 t.conv_bn("stage%d.1.conv1" % (i + 1), cout, cout // 2, 1)
                 t.conv_bn("stage%d.1.conv2" % (i + 1), cout // 2 * 4, cout, 1)
                 j = 2
-            _mm_csp(t, "stage%d.%d" % (i + 1, j), cout, cout, nb)
+            _mm_csp(t, "stage%d.%d" % (i + 1, j), cout, cout, nb, use_depthwise)
         self.out_channels = [int(s[1] * widen_factor) for s in setting][1:]
         self._init_table(t)
 
 
-def _pafpn_table(in_channels: Sequence[int], out_channels: int, n: int, gl: bool) -> _Table:
+def _pafpn_table(in_channels: Sequence[int], out_channels: int, n: int, gl: bool, dw: bool = False) -> _Table:
     if len(in_channels) != 3:
         raise NotImplementedError("lowered for three pyramid levels")
     c = list(in_channels)
@@ -139,12 +157,12 @@ def _pafpn_table(in_channels: Sequence[int], out_channels: int, n: int, gl: bool
     # the reference's own module (round 1 interleaved them, which only the ORDER of state_dict() shows)
     t.conv_bn("reduce_layers.0", c[2], c[1], 1)
     t.conv_bn("reduce_layers.1", c[1], c[0], 1)
-    _mm_csp(t, "top_down_blocks.0", (2 + extra) * c[1], c[1], n)
-    _mm_csp(t, "top_down_blocks.1", 2 * c[0], c[0], n)
-    t.conv_bn("downsamples.0", c[0], c[0], 3)
-    t.conv_bn("downsamples.1", c[1], c[1], 3)
-    _mm_csp(t, "bottom_up_blocks.0", (2 + extra) * c[0], c[1], n)
-    _mm_csp(t, "bottom_up_blocks.1", 2 * c[1], c[2], n)
+    _mm_csp(t, "top_down_blocks.0", (2 + extra) * c[1], c[1], n, dw)
+    _mm_csp(t, "top_down_blocks.1", 2 * c[0], c[0], n, dw)
+    _mm_conv(t, "downsamples.0", c[0], c[0], 3, dw)                          # necks/yolox_pafpn.py:55,84-93
+    _mm_conv(t, "downsamples.1", c[1], c[1], 3, dw)
+    _mm_csp(t, "bottom_up_blocks.0", (2 + extra) * c[0], c[1], n, dw)
+    _mm_csp(t, "bottom_up_blocks.1", 2 * c[1], c[2], n, dw)
     for i in range(3):
         t.conv_bn("out_convs.%d" % i, c[i], out_channels, 1)
     if gl:
@@ -169,7 +187,7 @@ class YOLOXPAFPN(TableModule):
         if dict(upsample_cfg) != dict(scale_factor=2, mode="nearest"):
             raise NotImplementedError("only nearest x2 upsampling is lowered")
         self.in_channels, self.out_channels = list(in_channels), out_channels
-        self._init_table(_pafpn_table(in_channels, out_channels, num_csp_blocks, self.gl))
+        self._init_table(_pafpn_table(in_channels, out_channels, num_csp_blocks, self.gl, bool(use_depthwise)))
 
 
 @NECKS.register_module()
@@ -202,7 +220,7 @@ class YOLOXHead(TableModule):
         for name in ("multi_level_cls_convs", "multi_level_reg_convs"):
             for i in range(3):
                 for j in range(2):
-                    t.conv_bn("%s.%d.%d" % (name, i, j), f, f, 3)
+                    _mm_conv(t, "%s.%d.%d" % (name, i, j), f, f, 3, bool(use_depthwise))    # dense_heads/yolox_head.py:146-165
         for name, co in (("multi_level_conv_cls", num_classes), ("multi_level_conv_reg", 4), ("multi_level_conv_obj", 1)):
             for i in range(3):
                 t.plain("%s.%d" % (name, i), f, co, 1)

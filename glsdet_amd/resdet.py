@@ -17,6 +17,7 @@ Graph-level choices (all numerically the reference's arithmetic):
 """
 from __future__ import annotations
 
+import threading
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
@@ -654,6 +655,7 @@ class HipGflDetector:
         else:
             self.num_classes = len(self.cfg["proxies_list"])
         self._compiled: Dict[Tuple, _Compiled] = {}
+        self._cache_lock = threading.Lock()       # plan cache: looked up / LRU-touched / evicted by several lanes' threads
 
     def _emit(self, eng: Engine, img: torch.Tensor):
         b, c = ResDetBuilder(eng, self.sd), self.cfg
@@ -674,9 +676,10 @@ class HipGflDetector:
         """post: None or dict(score_thr, iou_thr, nms_pre=1000, max_per_img=100, max_cand, rescale=False)
         (the reference's test_cfg keys, base_dense_head.py:168,295-298)."""
         key = (n, H, W, tuple(sorted(post.items())) if post else None, use_graph, instance)
-        if key in self._compiled:
-            self._compiled[key] = self._compiled.pop(key)          # most recently used last
-            return self._compiled[key]
+        with self._cache_lock:
+            if key in self._compiled:
+                self._compiled[key] = self._compiled.pop(key)      # most recently used last
+                return self._compiled[key]
         eng = Engine(self.dtype, self.device, autotune=self.autotune)
         c = _Compiled()
         c.eng, c.post, c.nb, c.scale = eng, post, None, None
@@ -709,14 +712,16 @@ class HipGflDetector:
                 with torch.cuda.stream(c.graph_stream):
                     c.plan.capture(c.graph_stream)
                 c.graph_stream.synchronize()
-        self._compiled[key] = c
+        # (two threads asking for the same key at once both build; the second insert wins, the first plan is dropped: correct, rare)
         # LRU cap on resident plans (each holds its activations, an NMS workspace and, today, its own copy of the packed
         # weights): the UFPMP fine stage compiles one plan per padded mosaic shape and lane -- without a cap HBM grows with
         # every new shape over a data set.  GLSDET_MAX_PLANS (default 24) plans stay; evicted ones are rebuilt on demand.
         import os as _os
         cap = int(_os.environ.get("GLSDET_MAX_PLANS", "24"))
-        while len(self._compiled) > max(1, cap):
-            self._compiled.pop(next(iter(self._compiled)))
+        with self._cache_lock:
+            self._compiled[key] = c
+            while len(self._compiled) > max(1, cap):
+                self._compiled.pop(next(iter(self._compiled)))
         return c
 
     def run(self, c: _Compiled, img: Optional[torch.Tensor] = None, img_hw: Optional[torch.Tensor] = None,

@@ -662,8 +662,20 @@ def yolox_mmdet_cases():
 
             def forward(self, x):
                 return self.activate(self.bn(self.conv(x)))
+        class DepthwiseSeparableConvModule(nn.Module):
+            """mmcv.cnn.DepthwiseSeparableConvModule restated (mmcv is not installable here): a depthwise ConvModule
+            (groups = in_channels, the caller's kernel / stride / padding) followed by a pointwise 1x1 ConvModule, both with
+            the caller's norm_cfg / act_cfg ('default' for the dw_* / pw_* overrides), attribute names as upstream."""
+            def __init__(self, cin, cout, k, stride=1, padding=0, dilation=1, norm_cfg=None, act_cfg=dict(type="ReLU"), **kw):
+                super().__init__()
+                self.depthwise_conv = ConvModule(cin, cin, k, stride=stride, padding=padding, dilation=dilation, groups=cin,
+                                                 norm_cfg=norm_cfg, act_cfg=act_cfg, **kw)
+                self.pointwise_conv = ConvModule(cin, cout, 1, norm_cfg=norm_cfg, act_cfg=act_cfg, **kw)
+
+            def forward(self, x):
+                return self.pointwise_conv(self.depthwise_conv(x))
         noop = lambda *a, **k: None
-        mmcv.cnn.ConvModule, mmcv.cnn.DepthwiseSeparableConvModule, mmcv.cnn.bias_init_with_prob = ConvModule, None, (lambda p_: 0.0)
+        mmcv.cnn.ConvModule, mmcv.cnn.DepthwiseSeparableConvModule, mmcv.cnn.bias_init_with_prob = ConvModule, DepthwiseSeparableConvModule, (lambda p_: 0.0)
         _stub("mmcv.cnn.utils")
         _stub("mmcv.cnn.utils.weight_init", constant_init=noop)
         _stub("mmcv.ops", batched_nms=None)
@@ -709,8 +721,19 @@ def yolox_mmdet_cases():
             def forward(self, x):
                 cls, reg, obj = self.bbox_head(self.neck(self.backbone(x)))
                 return torch.cat([torch.cat((r, o, c), 1).flatten(1) for c, r, o in zip(cls, reg, obj)], 1)
+        class DetNano(nn.Module):    # configs/yolox/yolox_nano_8x8_300e_coco.py:4-11 (use_depthwise=True everywhere) with 10 classes
+            def __init__(self):
+                super().__init__()
+                self.backbone = bb.CSPDarknet(deepen_factor=0.33, widen_factor=0.25, use_depthwise=True)
+                self.neck = nk.YOLOXPAFPN(in_channels=[64, 128, 256], out_channels=64, num_csp_blocks=1, use_depthwise=True)
+                self.bbox_head = yh.YOLOXHead(num_classes=10, in_channels=64, feat_channels=64, use_depthwise=True)
+
+            def forward(self, x):
+                cls, reg, obj = self.bbox_head(self.neck(self.backbone(x)))
+                return torch.cat([torch.cat((r, o, c), 1).flatten(1) for c, r, o in zip(cls, reg, obj)], 1)
         with torch.no_grad():
             block("yolox_s_mmdet", Det, (2, 3, 96, 128), calibrate=True)
+            block("yolox_nano_mmdet", DetNano, (2, 3, 96, 128), seed=1, calibrate=True)
             head = yh.YOLOXHead(num_classes=10, in_channels=128, feat_channels=128)
             priors = torch.cat(head.prior_generator.grid_priors([(12, 16), (6, 8), (3, 4)], device="cpu", with_stride=True))
             preds = synth_input((2, priors.shape[0], 4), 9)
@@ -735,6 +758,9 @@ def main():
     if "--resdet-only" in sys.argv:
         resdet_cases()
         head_cases()
+        yolox_mmdet_cases()
+        return
+    if "--yolox-mmdet-only" in sys.argv:
         yolox_mmdet_cases()
         return
     if "--attention-only" in sys.argv:

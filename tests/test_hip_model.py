@@ -454,7 +454,7 @@ def test_two_graph_instances_in_flight_replay_bit_identically(golden, shapes):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("dtype", ["f32", "f16"])
-@pytest.mark.parametrize("workload", ["yolox_s_glfusion_1344x800_bs8", "mp_det_res50_gl_1344x800_bs8"])
+@pytest.mark.parametrize("workload", ["yolox_s_glfusion_1344x800_bs8", "mp_det_res50_gl_1344x800_bs8", "yolox_s_glfusion_640x640_bs8"])
 def test_every_conv_variant_agrees_on_the_benchmark_shapes(workload, dtype):
     """Each kernel variant shadows every conv of the benchmark detector that it accepts, at the benchmark's own
     size and on its own data, layer by layer (tools/variant_check.py, Engine.shadow): in exact-f32 mode within

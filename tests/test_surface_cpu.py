@@ -173,3 +173,103 @@ def test_ranks_agree_gloo_world2(tmp_path):
         procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     outs = [p.communicate(timeout=240)[0].decode() for p in procs]
     assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+
+
+def _reference_uninterleave(part_list, size):
+    """collect_results_cpu / collect_results_gpu, /root/reference/yolox-ufp/mmdet/apis/test.py:150-155,186-190, restated:
+    `for res in zip(*part_list): ordered_results.extend(list(res))`, then `ordered_results[:size]`."""
+    ordered = []
+    for res in zip(*part_list):
+        ordered.extend(list(res))
+    return ordered[:size]
+
+
+@pytest.mark.parametrize("world,per_rank,size", [(8, 8, 64), (8, 8, 61), (3, 7, 19), (2, 3, 5), (4, 1, 3)])
+def test_unpack_in_dataset_order_equals_the_reference_uninterleave(world, per_rank, size):
+    """BASELINE config 4 (64 images over 8 GPUs) and counts the world size does not divide: the exchange record unpacked
+    in data-set order equals the reference's zip / extend / [:size] on per-rank result lists (DistributedSampler order,
+    the sampler's padding images dropped)."""
+    import numpy as np
+    import torch
+    from glsdet_amd.dist import shard_indices, unpack_in_dataset_order
+    cap = 6
+    rng = np.random.default_rng(world * 100 + size)
+    g = np.zeros((world, per_rank, cap + 1, 7), np.float32)
+    part_list = []
+    for r in range(world):
+        part = []
+        for slot in range(per_rank):
+            k = int(rng.integers(0, cap + 1))
+            rows = rng.uniform(0, 1, (k, 7)).astype(np.float32)
+            rows[:, 0] = 1000 * r + slot                  # tag: where the rows came from
+            g[r, slot, :k] = rows
+            g[r, slot, cap, 0] = k
+            part.append(rows)
+        part_list.append(part)
+    want = _reference_uninterleave(part_list, size)
+    got = unpack_in_dataset_order(torch.from_numpy(g), num_images=size)
+    assert len(got) == len(want) == size
+    for i, (a, b) in enumerate(zip(got, want)):
+        np.testing.assert_array_equal(a, b)
+        if len(a):
+            assert int(a[0, 0]) == 1000 * (i % world) + i // world
+    # and the sampler side: image i is handled by rank i % world at slot i // world
+    for r in range(world):
+        assert shard_indices(size, r, world) == [i for i in range(size) if i % world == r]
+
+
+_TUNE_WORKER = r'''
+import os, sys
+sys.path.insert(0, %(root)r)
+import torch, torch.distributed as dist
+from glsdet_amd import engine
+from glsdet_amd.dist import share_tuning
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+assert share_tuning(0) == 0                              # no process group yet: a no-op
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%(port)d", rank=rank, world_size=world)
+if rank == 0:                                            # what Engine(autotune=True) leaves behind on the tuning rank
+    engine._SHARED_TUNED["f16"] = {(8, 100, 168, 128, 1, True, 0): 0x20d, ("chain", 8, 50, 84, 256): -1, ("multi", 4, 1, 1, 3, 3, 8): 0x108}
+    engine._SHARED_TUNED["f32"] = {(1, 25, 42, 512): 9}
+else:                                                    # a rank that tuned something on its own keeps it unless rank 0 says otherwise
+    engine._SHARED_TUNED["f16"] = {(8, 100, 168, 128, 1, True, 0): 13, ("own", 1): 5}
+n = share_tuning(0)
+t = engine._SHARED_TUNED
+assert t["f16"][(8, 100, 168, 128, 1, True, 0)] == 0x20d and t["f16"][("chain", 8, 50, 84, 256)] == -1 and t["f32"][(1, 25, 42, 512)] == 9
+assert t["f16"][("multi", 4, 1, 1, 3, 3, 8)] == 0x108
+assert (("own", 1) in t["f16"]) == (rank == 1) and n == (4 if rank == 0 else 5)
+dist.barrier(); dist.destroy_process_group()
+print("rank", rank, "ok")
+'''
+
+
+def test_share_tuning_gloo_world2(tmp_path):
+    """every rank runs the kernel variants rank 0 measured (bench.py N > 1): one object broadcast of the tuning table"""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    script = tmp_path / "t.py"
+    script.write_text(_TUNE_WORKER % {"root": ROOT, "port": port})
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    outs = [p.communicate(timeout=240)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+
+
+@pytest.mark.parametrize("spec,want_rc", [("ok", 0), ("die:1:3", 3), ("die:0:5", 5)])
+def test_bench_launcher_two_rank_rehearsal_exit_codes(spec, want_rc):
+    """`python bench.py --gpus 2` without a launcher starts its own ranks (bench.spawn_ranks).  CPU rehearsal over gloo
+    (GLSDET_BENCH_STUB): all ranks leave cleanly -> 0 and rank 0's line on stdout; one rank dies while the other waits in a
+    collective -> the launcher stops the survivor and returns the dead rank's code instead of hanging."""
+    import time
+    env = dict(os.environ, GLSDET_BENCH_STUB=spec)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    t0 = time.time()
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, timeout=240)
+    assert p.returncode == want_rc, (p.returncode, p.stderr.decode()[-2000:])
+    assert time.time() - t0 < 120
+    if want_rc == 0:
+        import json
+        assert json.loads(p.stdout.decode().strip().splitlines()[-1]) == {"stub": "ok", "n_gpus": 2}
