@@ -87,7 +87,10 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvArgs a, const 
   constexpr int NR = TM * TN * (32 / (2 * OV));    // residual chunks (= DMA instructions) per wave and tile
   static_assert(TM >= 1 && TN >= 1 && NIW >= 1 && NIX >= 1 && NS >= 3, "tile shape");
   static_assert(CO_T % (4 * RPI) == 0 && PX_T % (4 * RPI) == 0, "whole DMA pieces");
-  constexpr int NST = TM * TN * (32 / OV);         // 16-byte stores per lane and tile (always issued: out-of-range lanes store out of range)
+  constexpr int NST = TM * TN * (32 / (2 * OV));   // 16-byte stores per lane and tile: 2 (fp16 out) / 4 (fp32 out) per 32 x 32 block, always
+                                                   // issued (out-of-range lanes store out of range).  Must be EXACT: an overcount lets the
+                                                   // stage wait pass with operand DMAs still in flight (found by tools/variant_check.py on
+                                                   // ResNet's 256 -> 64 layer at 200 x 336 -- a handful of wrong elements, fuzz tests green)
   constexpr int KEND_ = (63 - NI * (NS - 2)) / NST;                        // store groups a six-bit vmcnt can still allow for
   constexpr int KEND = KEND_ < NS - 1 ? KEND_ : NS - 1;
   static_assert(NI * (NS - 2) <= 63 && KEND >= 0 && NI * (NS - 1) <= 63, "vmcnt is six bits");
