@@ -315,7 +315,7 @@ def calibrate_yolox_head(sd, kind, img, args, dev):
 
 
 # --------------------------------------------------------------------------------------------- one workload
-def run_workload(args, workload, rank, world, dev, with_cpu_baseline, nsteps=None, nwindows=None):
+def run_workload(args, workload, rank, world, dev, with_cpu_baseline, nsteps=None, nwindows=None, leg=""):
     """Build, calibrate, time (warmup + exactly --steps steps between barriers) and profile per op ONE workload.
     -> (result dict, elapsed seconds) on every rank."""
     import torch.distributed as dist
@@ -496,7 +496,7 @@ def run_workload(args, workload, rank, world, dev, with_cpu_baseline, nsteps=Non
                 "algorithmic_gflop_per_image": round(2.0 * (alg_conv_gmac + alg_mm_gmac), 2),
                 "executed_conv_gflop_per_image": round(executed_conv_flops / bs / 1e9, 2)}
     if args.op_table and rank == 0:
-        path = args.op_table if workload == args.workload else args.op_table + "." + workload
+        path = args.op_table if (workload == args.workload and not leg) else args.op_table + "." + (leg or workload)
         with open(path, "w") as f:
             f.write("idx\tkind\tms\tgflop\ttflops\tMB\tGBps\tname\n")
             for i, (o, t) in enumerate(zip(ops, ms)):
@@ -796,7 +796,7 @@ def main():
         progress("leg f32_strict (the mode that meets north_star's 1e-4 / 1e-3: exact-f32 MFMA)")
         a32 = copy.copy(args)
         a32.dtype = "f32"
-        r32 = run_workload(a32, args.workload, rank, world, dev, False, nsteps=max(5, min(args.steps, 40)), nwindows=3)
+        r32 = run_workload(a32, args.workload, rank, world, dev, False, nsteps=max(5, min(args.steps, 40)), nwindows=3, leg="f32_strict")
         legs["f32_strict"] = dict(r32, dtype="f32", n_gpus=world,
                                   note="same workload, same protocol, fp32 storage + exact-f32 MFMA (v_mfma_f32_32x32x2_f32): the mode the "
                                        "f32 parity tests hold to max(1e-4, 2 x fp64 noise); roofline against the 157.3 TFLOP/s fp32 matrix peak")

@@ -10,7 +10,7 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "lib", "libglsdet_hip.so")
-ABI_VERSION = 12
+ABI_VERSION = 13
 CAPTURE_LOCK = threading.RLock()        # hipGraph captures are serialised across host threads
 
 F16, F32 = 0, 1
@@ -41,7 +41,7 @@ class ConvDesc(C.Structure):
 
 class ConvChain(C.Structure):
     _fields_ = [("y2", View), ("w2", C.c_void_p), ("scale2", C.c_void_p), ("bias2", C.c_void_p),
-                ("act2", C.c_int32), ("c0", C.c_int32), ("cin2", C.c_int32), ("_pad", C.c_int32)]
+                ("act2", C.c_int32), ("c0", C.c_int32), ("cin2", C.c_int32), ("flags", C.c_int32)]
 
 
 _SIGS = {

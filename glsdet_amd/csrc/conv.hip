@@ -383,7 +383,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
           v = add_chunk(v, *reinterpret_cast<const u32x4*>(a.res + ro * (long)sizeof(TO)), (TO*)nullptr, a.act_post);
         }
         const long yo = gls_pix_off(p, HoWo, a.Wo, a.y_sn, a.y_sh, a.y_sw, a.y_lin, a) + co;
-        *reinterpret_cast<u32x4*>(a.y + yo * (long)sizeof(TO)) = v;
+        if (!CH || !a.y_skip) *reinterpret_cast<u32x4*>(a.y + yo * (long)sizeof(TO)) = v;
       }
     }
     if constexpr (CH && sizeof(T) == sizeof(TO)) {
@@ -418,7 +418,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
         const int px_l = q / OCPR, cc = q - px_l * OCPR;
         u32x4 v = *reinterpret_cast<const u32x4*>(smem + px_l * ORS + cc * 16);
         if (a.res) v = add_chunk(v, rv[b], (TO*)nullptr, a.act_post);
-        *reinterpret_cast<u32x4*>(a.y + yo[b] * (long)sizeof(TO)) = v;
+        if (!CH || !a.y_skip) *reinterpret_cast<u32x4*>(a.y + yo[b] * (long)sizeof(TO)) = v;
       }
     }
   }
@@ -641,6 +641,7 @@ static int make_conv_args(const glsdet_conv_desc* d, int hint, ConvArgs& a, doub
   a.y2_sn = a.y2_sh = a.y2_sw = 0;
   a.c2_0 = a.cin2 = a.cout2 = a.cout2_pad = a.kpad2 = a.act2 = a.y2_lin = 0;
   a.w2_bytes = 0;
+  a.y_skip = 0;
   a.gn_part = nullptr; a.gn_cpg = a.gn_groups = 0;
   const int64_t xalloc = (const char*)x.alloc_hi - (const char*)x.alloc_lo;
   const int64_t wbytes = (int64_t)a.cout_pad * a.kpad * dtype_size(x.dtype);
@@ -689,6 +690,13 @@ static int add_chain(const glsdet_conv_desc* d, const glsdet_conv_chain* c, Conv
   a.y2_lin = (c->y2.sh == (int64_t)y.w * c->y2.sw && c->y2.sn == (int64_t)y.h * c->y2.sh) ? 1 : 0;
   *flops += 2.0 * (double)a.M * c->y2.c * c->cin2;
   *bytes += (double)a.M * c->y2.c * es + (double)a.cout2_pad * a.kpad2 * es;
+  if (c->flags & ~GLSDET_CHAIN_SKIP_Y) GLS_FAIL(GLSDET_E_ARG, "conv2d_chain: unknown flags %d", c->flags);
+  if (c->flags & GLSDET_CHAIN_SKIP_Y) {
+    // y is not stored: legal only when the chained conv reads ALL of y (then one cout tile holds it) and nothing else is fused in
+    if (c->c0 != 0 || c->cin2 != y.c || d->res.base) GLS_FAIL(GLSDET_E_ARG, "conv2d_chain: SKIP_Y needs c0 == 0, cin2 == y.c and no residual");
+    a.y_skip = 1;
+    *bytes -= (double)a.M * y.c * es;
+  }
   return 0;
 }
 // the chained product runs in the workgroup whose cout tile holds its input channels: one tile must hold them all

@@ -50,6 +50,7 @@ struct ConvArgs {
   long y2_sn, y2_sh, y2_sw;
   int c2_0, cin2, cout2, cout2_pad, kpad2, act2, y2_lin;
   unsigned w2_bytes;
+  int y_skip;                 // chained form only (GLSDET_CHAIN_SKIP_Y): y itself is read by nothing but the chained conv and is not stored
   // GroupNorm statistics of the output (glsdet_conv2d_gnstats): per (image, pixel tile, wave, group) the sum and the sum
   // of squares of the STORED values, fp64, at gn_part[(((img * tiles + tile) * 4 + wave) * gn_groups + group) * 2]; nullptr: none
   double* gn_part;
@@ -561,7 +562,7 @@ __device__ __forceinline__ void halo_store_and_chain(unsigned char* smem, const 
     const bool chain = a.w2 != nullptr && co0 <= a.c2_0 && a.c2_0 + a.cin2 <= co0 + CO_T;
     if (chain) {
       if (a.res) halo_store_tile_keep<TO, CO_T, PW>(smem, a, img, ty0, tx0, co0, tid);
-      else halo_store_tile<TO, CO_T, PW>(smem, a, img, ty0, tx0, co0, tid);
+      else if (!a.y_skip) halo_store_tile<TO, CO_T, PW>(smem, a, img, ty0, tx0, co0, tid);
       auto y2pix = [&](int px_l, bool& ok) -> long {
         int oy, ox;
         pix_to_xy16<PW>(px_l, oy, ox);

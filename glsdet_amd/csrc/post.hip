@@ -1,6 +1,8 @@
 // Per-anchor decode, class-max + threshold + compaction, and batched (per-class) NMS.
 // HBM / latency bound integer-and-compare work: no MFMA; coalesced reads, LDS-staged
 // tiles for the O(n^2) passes, 64-bit wave ballots as the suppression bitmask.
+#include <stdlib.h>
+#include <type_traits>
 #include <string.h>
 
 #include "common.h"
@@ -66,14 +68,16 @@ __global__ __launch_bounds__(256) void reset_counters_kernel(int* cnt, int n, in
 // ---------------------------------------------------------------------------- NMS
 // workspace layout (per call): see nms_layout()
 struct NmsWs {
-  int* cnt;            // [n]   candidates found (unclamped)
+  int* cnt;            // [n]   candidates found (unclamped); [n .. 2n): set by nms_fused_kernel for the images it finished
   float4* cbox;        // [n][max_cand]  candidate boxes (xyxy), arrival order
   float4* cext;        // [n][max_cand]  obj, cls_conf, cls_id, score
   int* canchor;        // [n][max_cand]
   float* cscore;       // [n][max_cand]  score again, contiguous (scalar-cache friendly)
   float4* sbox;        // [n][max_cand]  sorted by score desc
   float4* sext;        // [n][max_cand]
-  unsigned long long* mask;  // [n][nw][max_cand]  (column-block major)
+  unsigned long long* mask;  // [n][nw][max_cand]  (column-block major; the class-segmented path: row-major words per class)
+  unsigned long long* skey;  // [n][max_cand]  class-segmented path: sort keys (class | ~score | anchor) in segment order
+  int* seg;                  // [n][GLS_NMSF_SEG]  class-segmented path: segment table per image
 };
 
 // utils_bbox.py:380-385 (cxcywh->xyxy), :398 class max, :403 threshold
@@ -134,11 +138,12 @@ __global__ __launch_bounds__(256) void nms_filter_kernel(const float* __restrict
 // (score desc, anchor asc) order.  Exact and deterministic.  Workgroup = 64 candidates x 4
 // slices of the comparison range; tiles of 256 (score, anchor) pairs go through LDS and each
 // thread scans its quarter of the tile (broadcast reads), partial ranks are summed in LDS.
-__global__ __launch_bounds__(256) void nms_rank_kernel(int max_cand, NmsWs ws) {
+__global__ __launch_bounds__(256) void nms_rank_kernel(int max_cand, NmsWs ws, int fused = 0) {
   __shared__ float s_score[256];
   __shared__ int s_anchor[256];
   __shared__ int s_part[256];
   const int b = blockIdx.y;
+  if (fused && ws.cnt[gridDim.y + b]) return;      // nms_fused_kernel handled this image
   const int n = min(ws.cnt[b], max_cand);
   if (blockIdx.x * 64 >= n) return;
   const int il = threadIdx.x & 63, slice = threadIdx.x >> 6;
@@ -173,8 +178,9 @@ __global__ __launch_bounds__(256) void nms_rank_kernel(int max_cand, NmsWs ws) {
 // Stored column-block major so that the scan reads 64 consecutive rows of one column block
 // as one coalesced 512-byte wave load.  The grid is fixed; each 64-thread block walks the
 // (row block, column block) pairs of the ACTUAL candidate count (known only on the device).
-__global__ __launch_bounds__(64) void nms_mask_kernel(int max_cand, int nw, float thr, NmsWs ws, float one = 0.f) {
+__global__ __launch_bounds__(64) void nms_mask_kernel(int max_cand, int nw, float thr, NmsWs ws, float one = 0.f, int fused = 0) {
   const int b = blockIdx.y;
+  if (fused && ws.cnt[gridDim.y + b]) return;
   const int n = min(ws.cnt[b], max_cand);
   const int nb = (n + 63) >> 6;
   __shared__ float4 cbx[64];
@@ -228,11 +234,12 @@ __device__ __forceinline__ unsigned long long wave_or(unsigned long long v) {
 // A sweep that changes nothing proves the fixed point.  One 1024-thread workgroup / image.
 #define GLS_NMS_MAXW 512    // 512 * 64 = 32768 candidates max
 __global__ __launch_bounds__(1024) void nms_scan_kernel(int max_cand, int nw, int max_det, NmsWs ws, float* dets,
-                                                        int* count) {
+                                                        int* count, int fused = 0) {
   __shared__ unsigned long long s_keep[GLS_NMS_MAXW];
   __shared__ int s_prefix[GLS_NMS_MAXW];
   __shared__ int s_changed;
   const int b = blockIdx.x;
+  if (fused && ws.cnt[gridDim.x + b]) return;
   const int n = min(ws.cnt[b], max_cand);
   const long base = (long)b * max_cand;
   const unsigned long long* maskT = ws.mask + (long)b * nw * max_cand;
@@ -287,6 +294,387 @@ __global__ __launch_bounds__(1024) void nms_scan_kernel(int max_cand, int nw, in
       if (pos < max_det) {
         const float4 bx = ws.sbox[base + i];
         const float4 ex = ws.sext[base + i];
+        float* d = dets + ((long)b * max_det + pos) * 7;
+        d[0] = bx.x; d[1] = bx.y; d[2] = bx.z; d[3] = bx.w; d[4] = ex.x; d[5] = ex.y; d[6] = ex.z;
+      }
+    }
+  }
+}
+
+
+// ---------------------------------------------------------------------------- class-segmented NMS (round 3)
+// filter -> rank -> mask -> scan was 0.21 ms of a 2.7 ms serial step: an O(n^2) rank sort over the chip, an n x n IoU bitmask
+// over ALL candidate pairs although only same-class pairs can suppress (utils_bbox.py:413-419 batched_nms), and a fixed-point
+// scan that re-reads the whole mask once per sweep.  Now:
+//   nms_sort_kernel (one 1024-thread workgroup per image): bitonic sort in LDS by (class, score desc, anchor asc) -- the
+//      candidates of a class become one contiguous segment, in the order greedy NMS visits them; boxes / extras / keys are
+//      stored in that order together with the segment table (start, length, mask offset, task prefix per class);
+//   nms_cmask_kernel (chip wide): IoU bitmask of the same-class block pairs only (a tenth of the pairs for ten balanced
+//      classes), a 64-thread workgroup per (class, row block, column block) task;
+//   nms_cscan_kernel (one workgroup per image): greedy scan, one wave per class, blocked and right-looking -- inside a
+//      64-candidate block the keep bits are resolved sequentially with v_readlane on the block's diagonal words, then the
+//      kept rows' words are OR-ed into the dead masks of the later blocks: every mask word is read ONCE; the kept candidates
+//      are compacted, bitonic-sorted by (score desc, anchor asc) -- the order torchvision's batched_nms returns and the one
+//      the old path produces -- and written out.
+// (First cut of the round: all three phases in ONE workgroup per image.  Correct, and slower than the old path -- 0.24 vs
+// 0.21 ms: 200 k IoUs per image are too much for one CU.)  Same keep set and order as the old path by construction:
+// suppression only acts inside a class, and inside a class both visit the candidates in (score desc, anchor asc) order.
+// Images with more than GLS_NMSF_MAX candidates (or anchors / classes beyond the key's bit fields) are left to the old
+// kernels, which skip the images handled here.
+#define GLS_NMSF_MAX 4096
+#define GLS_NMSF_SEG (256 + 256 + 260 + 260)      // ints per image: segment start, length, mask offset, task prefix
+__device__ __forceinline__ unsigned f2ord(float f) {            // float -> unsigned with the same order (also for negative / zero scores)
+  const unsigned u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+// Bitonic sort of P = 1024 * E (key, value) pairs held E per thread (element i = e * 1024 + tid) by 1024 threads.  A plain
+// LDS network with a barrier per stage cost ~0.9 us per stage (66 stages for 2048 elements: 61 us, rocprofv3); here a
+// compare-exchange with stride j >= 1024 stays inside the thread's registers, j < 64 is a lane shuffle, and only the
+// strides 64 .. 512 (14 of the 66 stages at P = 2048) go through LDS with barriers.  Ascending; keys must be distinct.
+template <int E>
+__device__ __forceinline__ void bitonic_sort_regs(unsigned long long (&key)[E], unsigned short (&val)[E], unsigned long long* xk,
+                                                  unsigned short* xv, int tid) {
+  constexpr int P = 1024 * E;
+#pragma unroll 1
+  for (int k = 2; k <= P; k <<= 1) {
+#pragma unroll 1
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      if (j >= 1024) {                              // partner in this thread (STATIC register indices: a runtime index would
+        auto cx = [&](auto ea, auto eb) {           // send the arrays to scratch memory)
+          constexpr int A_ = decltype(ea)::value, B_ = decltype(eb)::value;
+          if constexpr (B_ < E) {
+            const bool up = ((A_ * 1024 + tid) & k) == 0;
+            if ((key[A_] > key[B_]) == up) {
+              const unsigned long long t = key[A_]; key[A_] = key[B_]; key[B_] = t;
+              const unsigned short tv = val[A_]; val[A_] = val[B_]; val[B_] = tv;
+            }
+          }
+        };
+        using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+        using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
+        if (j == 1024) { cx(I0{}, I1{}); cx(I2{}, I3{}); }
+        else { cx(I0{}, I2{}); cx(I1{}, I3{}); }
+      } else if (j >= 64) {                         // partner in another wave: through LDS
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+          xk[e * 1024 + tid] = key[e];
+          xv[e * 1024 + tid] = val[e];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+          const int i = e * 1024 + tid;
+          const unsigned long long pk = xk[i ^ j];
+          const unsigned short pv = xv[i ^ j];
+          const bool keepmin = ((i & k) == 0) == ((i & j) == 0);
+          if (keepmin ? (pk < key[e]) : (pk > key[e])) {
+            key[e] = pk;
+            val[e] = pv;
+          }
+        }
+        __syncthreads();
+      } else {                                      // partner lane: shuffles
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+          const int i = e * 1024 + tid;
+          const unsigned lo = __shfl_xor((unsigned)key[e], j, 64), hi = __shfl_xor((unsigned)(key[e] >> 32), j, 64);
+          const unsigned pv = __shfl_xor((unsigned)val[e], j, 64);
+          const unsigned long long pk = ((unsigned long long)hi << 32) | lo;
+          const bool keepmin = ((i & k) == 0) == ((i & j) == 0);
+          if (keepmin ? (pk < key[e]) : (pk > key[e])) {
+            key[e] = pk;
+            val[e] = (unsigned short)pv;
+          }
+        }
+      }
+    }
+  }
+}
+// sort the first P (1024, 2048 or 4096) entries of key / val (LDS) in place; all 1024 threads call it
+__device__ __forceinline__ void bitonic_sort_kv(unsigned long long* key, unsigned short* val, int P, int tid) {
+#define GLS_SORT_E(E_)                                                              \
+  {                                                                                 \
+    unsigned long long k_[E_];                                                      \
+    unsigned short v_[E_];                                                          \
+    for (int e = 0; e < E_; ++e) { k_[e] = key[e * 1024 + tid]; v_[e] = val[e * 1024 + tid]; } \
+    __syncthreads();                                                                \
+    bitonic_sort_regs<E_>(k_, v_, key, val, tid);                                   \
+    for (int e = 0; e < E_; ++e) { key[e * 1024 + tid] = k_[e]; val[e * 1024 + tid] = v_[e]; } \
+    __syncthreads();                                                                \
+  }
+  if (P <= 1024) GLS_SORT_E(1)
+  else if (P <= 2048) GLS_SORT_E(2)
+  else GLS_SORT_E(4)
+#undef GLS_SORT_E
+}
+// exclusive prefix sum of v over the 1024 threads of a workgroup (every thread calls it); total in *tot.  Wave shuffles +
+// ONE exchange of the 16 wave totals through LDS: a 1024-thread __syncthreads costs ~0.8 us here (rocprofv3: 66 barrier
+// stages = 61 us), so the Hillis-Steele scans of the first cut (20 barriers each) were most of the kernels' time.
+__device__ __forceinline__ int block_scan_excl(int v, int* s_w /* [16] */, int tid, int* tot) {
+  const int lane = tid & 63, wave = tid >> 6;
+  int x = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int y = __shfl_up(x, o, 64);
+    if (lane >= o) x += y;
+  }
+  __syncthreads();                                 // (s_w may still be read from the previous call)
+  if (lane == 63) s_w[wave] = x;
+  __syncthreads();
+  int before = 0, all = 0;
+#pragma unroll
+  for (int w = 0; w < 16; ++w) {
+    const int t = s_w[w];
+    all += t;
+    if (w < wave) before += t;
+  }
+  *tot = all;
+  return before + x - v;
+}
+__device__ __forceinline__ int scan256_excl(int v, int* s_w, int tid, int* tot) {      // v must be 0 for tid >= 256
+  return block_scan_excl(tid < 256 ? v : 0, s_w, tid, tot);
+}
+__device__ __forceinline__ unsigned long long readlane64(unsigned long long v, int l) {
+  const unsigned lo = __builtin_amdgcn_readlane((unsigned)v, l), hi = __builtin_amdgcn_readlane((unsigned)(v >> 32), l);
+  return ((unsigned long long)hi << 32) | lo;
+}
+
+__global__ __launch_bounds__(1024) void nms_sort_kernel(int max_cand, int key_ok, NmsWs ws, int dbg = 0) {
+  __shared__ unsigned long long s_key[GLS_NMSF_MAX];
+  __shared__ unsigned short s_idx[GLS_NMSF_MAX];
+  __shared__ int s_seg[256], s_segn[256];
+  const int b = blockIdx.x, nimg = gridDim.x, tid = threadIdx.x;
+  const int n = min(ws.cnt[b], max_cand);
+  int* done = ws.cnt + nimg;
+  if (n > GLS_NMSF_MAX || !key_ok) {               // left to nms_rank / nms_mask / nms_scan
+    if (tid == 0) done[b] = 0;
+    return;
+  }
+  if (tid == 0) done[b] = 1;
+  int* seg = ws.seg + (long)b * GLS_NMSF_SEG;
+  int P = 1024;
+  while (P < n) P <<= 1;
+  const long base = (long)b * max_cand;
+  for (int i = tid; i < P; i += 1024) {
+    unsigned long long k = ~0ull - (unsigned)i;     // padding: distinct keys behind every real one (class byte 0xff)
+    if (i < n) {
+      const float4 ex = ws.cext[base + i];
+      k = ((unsigned long long)(unsigned)(int)ex.z << 56) | ((unsigned long long)(~f2ord(ex.w)) << 24) | (unsigned long long)(unsigned)ws.canchor[base + i];
+    }
+    s_key[i] = k;
+    s_idx[i] = (unsigned short)i;
+  }
+  if (tid < 256) s_seg[tid] = s_segn[tid] = 0;
+  __syncthreads();
+  if (!(dbg & 1)) bitonic_sort_kv(s_key, s_idx, P, tid);
+  if (!(dbg & 2))
+  for (int i = tid; i < n; i += 1024) {
+    const int o = s_idx[i];
+    ws.sbox[base + i] = ws.cbox[base + o];
+    ws.sext[base + i] = ws.cext[base + o];
+    ws.skey[base + i] = s_key[i];
+    const int c = (int)(s_key[i] >> 56);
+    if (i == 0 || (int)(s_key[i - 1] >> 56) != c) s_seg[c] = i;
+    if (i == n - 1 || (int)(s_key[i + 1] >> 56) != c) s_segn[c] = i + 1;
+  }
+  __syncthreads();
+  int len = 0, nb = 0;
+  if (tid < 256) {
+    len = s_segn[tid] - s_seg[tid];                // length (0 for absent classes: both zero)
+    nb = (len + 63) >> 6;
+    seg[tid] = s_seg[tid];
+    seg[256 + tid] = len;
+  }
+  __shared__ int s_pre[256];
+  int tot_m, tot_t;
+  const int mo = scan256_excl(len * nb, s_pre, tid, &tot_m);             // mask word offset of the class
+  const int to = scan256_excl(nb * (nb + 1) / 2, s_pre, tid, &tot_t);    // task prefix
+  if (tid < 256) {
+    seg[512 + tid] = mo;
+    seg[512 + 260 + tid] = to;
+  }
+  if (tid == 0) {
+    seg[512 + 256] = tot_m;
+    seg[512 + 260 + 256] = tot_t;
+  }
+}
+
+// one 64-thread workgroup per (class, row block rb <= column block cb) task of an image; the grid is fixed, a workgroup walks
+// the tasks of the ACTUAL segment table (known only on the device)
+__global__ __launch_bounds__(64) void nms_cmask_kernel(int max_cand, int nw, float thr, float one, NmsWs ws) {
+  const int b = blockIdx.y, nimg = gridDim.y;
+  if (!ws.cnt[nimg + b]) return;
+  const int* seg = ws.seg + (long)b * GLS_NMSF_SEG;
+  const int* toff = seg + 512 + 260;
+  const int ntask = toff[256];
+  __shared__ float4 cbx[64];
+  const long base = (long)b * max_cand;
+  unsigned long long* mask = ws.mask + (long)b * nw * max_cand;      // nw * max_cand >= sum n_c * nb_c words
+  const int lane = threadIdx.x;
+  for (int task = blockIdx.x; task < ntask; task += gridDim.x) {
+    int lo = 0, hi = 255;                          // last class whose task prefix is <= task
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (toff[mid] <= task) lo = mid;
+      else hi = mid - 1;
+    }
+    const int c = lo, s = seg[c], nc_ = seg[256 + c], nb = (nc_ + 63) >> 6;
+    int local = task - toff[c], rb = 0;
+    while (local >= nb - rb) {
+      local -= nb - rb;
+      ++rb;
+    }
+    const int cb = rb + local;
+    __syncthreads();
+    if (cb * 64 + lane < nc_) cbx[lane] = ws.sbox[base + s + cb * 64 + lane];
+    __syncthreads();
+    const int ri = rb * 64 + lane;                 // segment-local row
+    if (ri < nc_) {
+      const float4 a = ws.sbox[base + s + ri];
+      const float aarea = (a.z - a.x + one) * (a.w - a.y + one);
+      unsigned long long bits = 0;
+      const int lim = min(64, nc_ - cb * 64);
+      for (int k = 0; k < lim; ++k) {
+        if (cb * 64 + k <= ri) continue;
+        const float4 q = cbx[k];
+        const float w = fmaxf(0.f, fminf(a.z, q.z) - fmaxf(a.x, q.x) + one);
+        const float h = fmaxf(0.f, fminf(a.w, q.w) - fmaxf(a.y, q.y) + one);
+        const float inter = w * h;
+        const float iou = inter / (aarea + (q.z - q.x + one) * (q.w - q.y + one) - inter);
+        if (iou > thr) bits |= 1ull << k;
+      }
+      mask[seg[512 + c] + (long)ri * nb + cb] = bits;
+    }
+  }
+}
+
+__global__ __launch_bounds__(1024) void nms_cscan_kernel(int max_cand, int nw, int max_det, NmsWs ws, float* dets, int* count, int dbg = 0) {
+  __shared__ unsigned long long s_key2[GLS_NMSF_MAX];
+  __shared__ unsigned short s_val[GLS_NMSF_MAX];
+  __shared__ unsigned char s_flag[GLS_NMSF_MAX];
+  __shared__ int s_scan[1024];
+  const int b = blockIdx.x, nimg = gridDim.x;
+  if (!ws.cnt[nimg + b]) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = min(ws.cnt[b], max_cand);
+  const int* seg = ws.seg + (long)b * GLS_NMSF_SEG;
+  const long base = (long)b * max_cand;
+  const unsigned long long* mask = ws.mask + (long)b * nw * max_cand;
+  __shared__ int s_cs[256], s_cn[256], s_cm[256];   // segment table of this image: start, length, mask word offset per class
+  if (tid < 256) {
+    s_cs[tid] = seg[tid];
+    s_cn[tid] = seg[256 + tid];
+    s_cm[tid] = seg[512 + tid];
+  }
+  for (int i = tid; i < n; i += 1024) s_flag[i] = 0;
+  __syncthreads();
+  // greedy scan, a wave per class
+  if (!(dbg & 4))
+  for (int c = wave; c < 256; c += 16) {
+    const int nc_ = s_cn[c];
+    if (nc_ == 0) continue;
+    const int s = s_cs[c], nb = (nc_ + 63) >> 6;
+    const unsigned long long* M = mask + s_cm[c];
+    unsigned long long dead_reg = 0ull;            // lane L: OR of the kept earlier rows' words for column block L
+    for (int wb = 0; wb < nb; ++wb) {
+      const int ri = wb * 64 + lane;
+      const bool valid = ri < nc_;
+      const unsigned long long word = valid ? M[(long)ri * nb + wb] : 0ull;
+      const int left = nc_ - wb * 64;
+      unsigned long long alive = (left >= 64 ? ~0ull : ((1ull << left) - 1ull)) & ~readlane64(dead_reg, wb);
+      for (int t = 0; t < 64; ++t)
+        if ((alive >> t) & 1ull) alive &= ~readlane64(word, t);
+      const bool kept = valid && ((alive >> lane) & 1ull);
+      if (kept) s_flag[s + ri] = 1;
+      for (int w2 = wb + 1; w2 < nb; ++w2) {
+        const unsigned long long v = kept ? M[(long)ri * nb + w2] : 0ull;
+        const unsigned long long r = wave_or(v);
+        if (lane == w2) dead_reg |= r;
+      }
+    }
+  }
+  __syncthreads();
+  // The kept candidates in class-grouped order are <= 256 runs, each already sorted by (score desc, anchor asc): the output
+  // position of a kept candidate is the number of kept candidates with a smaller key -- its index inside its own run plus a
+  // binary search in every other non-empty run (ten classes: ~70 LDS reads per candidate instead of a 55-stage sort).
+  int P = 1024;
+  while (P < n) P <<= 1;
+  const int per = P >> 10;                         // consecutive positions per thread (1, 2 or 4)
+  int mine = 0;
+  for (int e = 0; e < per; ++e) {
+    const int p = tid * per + e;
+    if (p < n && s_flag[p]) ++mine;
+  }
+  int K;
+  const int q0 = block_scan_excl(mine, s_scan, tid, &K);
+  {
+    int q = q0;
+    for (int e = 0; e < per; ++e) {
+      const int p = tid * per + e;
+      if (p < n) {
+        s_val[p] = (unsigned short)q;              // kept candidates before position p (= compacted index of p if kept)
+        if (s_flag[p]) {
+          s_key2[q] = ws.skey[base + p] & 0x00ffffffffffffffull;      // (score desc, anchor asc)
+          ++q;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // run table: compacted start and length of every class with kept candidates
+  __shared__ int s_rs[256], s_rl[256], s_nrun;
+  if (tid < 256) {
+    const int nc_ = s_cn[tid], st = s_cs[tid];
+    int rs = 0, rl = 0;
+    if (nc_ > 0) {
+      rs = s_val[st];
+      const int last = st + nc_ - 1;
+      rl = s_val[last] + (s_flag[last] ? 1 : 0) - rs;
+    }
+    s_rs[tid] = rs;
+    s_rl[tid] = rl;
+  }
+  __syncthreads();
+  {                                                // pack the non-empty runs to the front
+    const int a = tid < 256 ? s_rs[tid] : 0, l = tid < 256 ? s_rl[tid] : 0;
+    int tot;
+    const int m = scan256_excl(l > 0 ? 1 : 0, s_scan, tid, &tot);
+    if (tid < 256 && l > 0) {
+      s_rs[m] = a;
+      s_rl[m] = l;
+    }
+    if (tid == 0) s_nrun = tot;
+    __syncthreads();
+  }
+  if (tid == 0) {
+    count[b] = min(K, max_det);
+    count[nimg + b] = K;
+  }
+  const int nrun = s_nrun;
+  if (!(dbg & 8))
+  for (int e = 0; e < per; ++e) {
+    const int p = tid * per + e;
+    if (p < n && s_flag[p]) {
+      const int q = s_val[p];
+      const unsigned long long kq = s_key2[q];
+      int pos = 0;
+      for (int r = 0; r < nrun; ++r) {
+        const int a = s_rs[r], l = s_rl[r];
+        if (q >= a && q < a + l) {
+          pos += q - a;                            // its own run
+        } else {
+          int lo = 0, hi = l;                      // elements of run r with a key below kq
+          while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (s_key2[a + mid] < kq) lo = mid + 1;
+            else hi = mid;
+          }
+          pos += lo;
+        }
+      }
+      if (pos < max_det) {
+        const float4 bx = ws.sbox[base + p];
+        const float4 ex = ws.sext[base + p];
         float* d = dets + ((long)b * max_det + pos) * 7;
         d[0] = bx.x; d[1] = bx.y; d[2] = bx.z; d[3] = bx.w; d[4] = ex.x; d[5] = ex.y; d[6] = ex.z;
       }
@@ -448,7 +836,7 @@ static long nms_layout(int n, int max_cand, NmsWs* ws, char* base, bool with_mas
   const int nw = (max_cand + 63) / 64;
   long off = 0;
   auto take = [&](long bytes) { long o = off; off = align_up(off + bytes, 256); return o; };
-  const long o_cnt = take((long)n * 4);
+  const long o_cnt = take((long)n * 8);            // [n] candidate counts + [n] "the fused kernel handled this image" flags
   const long o_cbox = take((long)n * max_cand * 16);
   const long o_cext = take((long)n * max_cand * 16);
   const long o_can = take((long)n * max_cand * 4);
@@ -456,6 +844,8 @@ static long nms_layout(int n, int max_cand, NmsWs* ws, char* base, bool with_mas
   const long o_sbox = take((long)n * max_cand * 16);
   const long o_sext = take((long)n * max_cand * 16);
   const long o_mask = with_mask ? take((long)n * max_cand * nw * 8) : 0;
+  const long o_skey = take((long)n * max_cand * 8);
+  const long o_seg = take((long)n * (256 + 256 + 260 + 260) * 4);
   if (ws && base) {
     ws->cnt = (int*)(base + o_cnt);
     ws->cbox = (float4*)(base + o_cbox);
@@ -465,6 +855,8 @@ static long nms_layout(int n, int max_cand, NmsWs* ws, char* base, bool with_mas
     ws->sbox = (float4*)(base + o_sbox);
     ws->sext = (float4*)(base + o_sext);
     ws->mask = (unsigned long long*)(base + o_mask);
+    ws->skey = (unsigned long long*)(base + o_skey);
+    ws->seg = (int*)(base + o_seg);
   }
   return off;
 }
@@ -537,16 +929,28 @@ extern "C" int glsdet_nms(const float* pred, int32_t n, int32_t A, int32_t num_c
   op.kind = 6;
   op.flops = 0;
   op.bytes = (double)n * A * (5 + num_classes) * 4.0;
-  op.name = "nms(filter+rank+mask+scan)";
+  static const bool no_fused = getenv("GLSDET_NO_FUSED_NMS") != nullptr;       // A/B switch: the three-kernel path of rounds 1-2
+  const int key_ok = (A < (1 << 24) && num_classes <= 255) ? 1 : 0;           // bit fields of the fused kernel's sort key
+  op.name = no_fused ? "nms(filter+rank+mask+scan)" : "nms(filter + class sort + same-class mask + blocked scan)";
   op.launch = [=](hipStream_t st) -> int {
-    hipLaunchKernelGGL(reset_counters_kernel, dim3(1), dim3(256), 0, st, ws.cnt, n, status);
+    hipLaunchKernelGGL(reset_counters_kernel, dim3(1), dim3(256), 0, st, ws.cnt, 2 * n, status);
     long g = ((long)n * A + 255) / 256;
     if (g > 8192) g = 8192;
     hipLaunchKernelGGL(nms_filter_kernel, dim3((unsigned)g), dim3(256), 0, st, pred, n, A, num_classes, box_mode,
                        conf_thres, max_cand, ws, status);
-    hipLaunchKernelGGL(nms_rank_kernel, dim3((max_cand + 63) / 64, n), dim3(256), 0, st, max_cand, ws);
-    hipLaunchKernelGGL(nms_mask_kernel, dim3(2048, n), dim3(64), 0, st, max_cand, nw, nms_thres, ws);
-    hipLaunchKernelGGL(nms_scan_kernel, dim3(n), dim3(1024), 0, st, max_cand, nw, max_det, ws, dets, count);
+    int fused = 0;
+    if (!no_fused) {
+      const int dbg = getenv("GLSDET_NMS_DBG") ? atoi(getenv("GLSDET_NMS_DBG")) : 0;      // timing knock-outs (results invalid)
+      hipLaunchKernelGGL(nms_sort_kernel, dim3(n), dim3(1024), 0, st, max_cand, key_ok, ws, dbg);
+      hipLaunchKernelGGL(nms_cmask_kernel, dim3(512, n), dim3(64), 0, st, max_cand, nw, nms_thres, 0.f, ws);
+      hipLaunchKernelGGL(nms_cscan_kernel, dim3(n), dim3(1024), 0, st, max_cand, nw, max_det, ws, dets, count, dbg);
+      fused = 1;
+    }
+    if (!fused || max_cand > GLS_NMSF_MAX || !key_ok) {      // images the fused kernel cannot take (its flags decide per image)
+      hipLaunchKernelGGL(nms_rank_kernel, dim3((max_cand + 63) / 64, n), dim3(256), 0, st, max_cand, ws, fused);
+      hipLaunchKernelGGL(nms_mask_kernel, dim3(2048, n), dim3(64), 0, st, max_cand, nw, nms_thres, ws, 0.f, fused);
+      hipLaunchKernelGGL(nms_scan_kernel, dim3(n), dim3(1024), 0, st, max_cand, nw, max_det, ws, dets, count, fused);
+    }
     GLS_HIP(hipGetLastError());
     return 0;
   };

@@ -59,7 +59,10 @@ class HipDetector:
                 c.decoded = eng.decode(c.levels, self.num_classes, H, W, mode=post.get("mode", 0),
                                        strides=[8, 16, 32] if post.get("mode", 0) == 1 else None,
                                        scale_factors=c.scale)
-                c.nmsb = eng.nms_buffers(n, A, min(post.get("max_cand", A), A), post.get("max_det", 1000))
+                # candidate capacity per image: 4096 unless the caller asks for more (the class-segmented NMS kernels take up to
+                # 4096 candidates per image; beyond that the three-kernel path of rounds 1-2 runs as well).  More candidates
+                # than the capacity raise the status flag -> HipDetector.collect says "raise max_cand".
+                c.nmsb = eng.nms_buffers(n, A, min(post.get("max_cand", 4096), A), post.get("max_det", 1000))
                 eng.nms(c.decoded, self.num_classes, post.get("mode", 0), post["conf_thres"], post["nms_thres"], c.nmsb)
                 if post.get("exchange_cap"):
                     eng.pack_detections(c.nmsb, int(post["exchange_cap"]))

@@ -251,10 +251,11 @@ class Engine:
         return out
 
     def conv_chain(self, x: TView, packed, stride: int, pad: int, act: str, out: TView, res: Optional[TView],
-                   packed2, act2: str, c0: int, cin2: int, out2: TView, res_first: bool = False) -> bool:
+                   packed2, act2: str, c0: int, cin2: int, out2: TView, res_first: bool = False, skip_y: bool = False) -> bool:
         """conv (as Engine.conv) + in the same launch a 1x1 conv (packed2, act2) on channels [c0, c0 + cin2) of its result
         -> out2 (glsdet_conv2d_chain).  Returns False, having launched nothing, when no kernel takes the fused problem
-        (the caller then emits the two convs)."""
+        (the caller then emits the two convs).  skip_y: nothing else reads `out` -- it is not stored (GLSDET_CHAIN_SKIP_Y;
+        `out` is then only a scratch view for the tuner's comparison and the shadow check)."""
         wdev, sdev, bdev, cout, R, S = packed
         w2, s2, b2, cout2, R2, S2 = packed2
         assert R2 == 1 and S2 == 1 and out2.c == ceil_to(cout2, 8)
@@ -269,10 +270,11 @@ class Engine:
         c.y2 = out2.as_c()
         c.w2, c.scale2, c.bias2 = w2.data_ptr(), s2.data_ptr(), b2.data_ptr()
         c.act2, c.c0, c.cin2 = ACT[act2], c0, cin2
+        c.flags = 1 if skip_y else 0
         st = _stream_ptr(self.stream)
         if self.autotune:
             key = ("chain", x.n, x.h, x.w, x.c, x.sn, x.sh, x.sw, out.c, out.sn, out.sh, out.sw, R, S, stride, pad,
-                   res is not None, out.dtype, c0, c.cin2, out2.c, out2.sn, out2.sh, out2.sw)
+                   res is not None, out.dtype, c0, c.cin2, out2.c, out2.sn, out2.sh, out2.sw, bool(skip_y))
             if key not in self._tuned:
                 best, us = C.c_int32(0), C.c_float(0)
                 rc = self.lib.glsdet_conv2d_chain_tune(C.byref(d), C.byref(c), st, C.byref(best), C.byref(us))
@@ -295,11 +297,13 @@ class Engine:
                 return False
             d.tile_hint = self._tuned[key]
         sh = None
-        if self.shadow is not None and self.shadow.get("hint"):           # the variant under test computes y (unfused) first
+        if self.shadow is not None and self.shadow.get("hint") and not skip_y:   # the variant under test computes y (unfused) first
             sh = self._shadow_begin([d], [out], self.shadow["hint"], multi=False)
         ok = self.lib.glsdet_conv2d_chain(C.byref(d), C.byref(c), st) == 0
         if ok and self.shadow is not None:
             self._shadow_end(sh)
+            if skip_y:                                # y was not stored: produce it for the stand-alone 1x1 of the check below
+                self.conv(x, packed, stride, pad, act, out=out, tile_hint=1)
             # and the chained product against a stand-alone 1x1 on the stored y: bit for bit
             ref = self.tensor(out2.n, out2.h, out2.w, out2.c, out2.dtype)
             self.conv(out.channels(c0, c0 + cin2), packed2, 1, 0, act2, out=ref, tile_hint=1)

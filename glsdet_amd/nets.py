@@ -170,8 +170,31 @@ class NetBuilder:
         self._rec(nxt, t, 0, w2.shape[0])
         return t
 
-    def csp(self, p: str, x: TView, shortcut: bool, out: Optional[TView] = None) -> TView:
-        """CSPLayer (darknet.py:66-112).  Where the fused kernel applies and pays, a Bottleneck (1x1 -> 3x3 [+ x],
+    def _csp_entry(self, prefixes, x: Optional[TView], dst: TView, down):
+        """conv1 | conv2 of a CSPLayer (in the order `prefixes`) -> dst.  down = (prefix, input) of the 3x3 stride-2 BaseConv
+        that produces the layer's input x and is read by nothing else (darknet.py:174-195): where the chained kernel takes
+        the pair (and beats the two tuned launches), conv1 | conv2 ride in ITS launch and its output is never stored
+        (Engine.conv_chain(skip_y=True)); otherwise it is emitted first.  -> None (dst is written either way)."""
+        if down is not None:
+            dp, dx = down
+            cin2 = self.conv_out_channels(dp)
+            hid2 = sum(self.conv_out_channels(q) for q in prefixes)
+            ok = False
+            if not os.environ.get("GLSDET_NO_DOWN_CHAIN") and not os.environ.get("GLSDET_NO_CHAIN") and hid2 <= 128 and \
+                    not any(self.is_depthwise(q) for q in list(prefixes) + [dp]):
+                pk = self._pack(dp, [self._bn_part(dp)], dx.c)
+                pk2 = self._pack("+".join(prefixes), [self._bn_part(q) for q in prefixes], ceil_to(cin2, 8))
+                ho, wo = (dx.h + 2 - 3) // 2 + 1, (dx.w + 2 - 3) // 2 + 1
+                scratch = self.e.tensor(dx.n, ho, wo, cin2)
+                ok = self.e.conv_chain(dx, pk, 2, 1, "silu", scratch, None, pk2, "silu", 0, scratch.c, dst, skip_y=True)
+            if ok:
+                return
+            x = self.cba(dp, dx, 2)
+        self.cba(list(prefixes), x, out=dst)
+
+    def csp(self, p: str, x: Optional[TView], shortcut: bool, out: Optional[TView] = None, down=None) -> TView:
+        """CSPLayer (darknet.py:66-112).  down: see _csp_entry (x is then None: the layer's input exists only inside the
+        producing launch).  Where the fused kernel applies and pays, a Bottleneck (1x1 -> 3x3 [+ x],
         darknet.py:61-64) is ONE launch that recomputes the 1x1 on the 3x3's halo (glsdet_bottleneck): the hidden tensor
         never reaches memory.  That form cannot run in place, so the main branch ping-pongs between two channel slots
         P | Q of one buffer [P | short | Q]; conv1|conv2 write [main | short] into [P | short] for an even number of
@@ -186,17 +209,21 @@ class NetBuilder:
         # (tracing keeps the unfused form: a trace holds EVERY stored tensor, and the fused form equals it bit for bit)
         if n and hid in (32, 64, 128) and not os.environ.get("GLSDET_NO_BNECK_FUSION") and self.trace is None and \
                 not self.is_depthwise("%s.m.0.conv2" % p) and self.sd["%s.m.0.conv2.conv.weight" % p].shape[-1] == 3:
-            buf = self.e.tensor(x.n, x.h, x.w, 3 * hid)
+            if x is None:
+                dn, dh, dw = down[1].n, (down[1].h + 2 - 3) // 2 + 1, (down[1].w + 2 - 3) // 2 + 1
+            else:
+                dn, dh, dw = x.n, x.h, x.w
+            buf = self.e.tensor(dn, dh, dw, 3 * hid)
             P, Q = buf.channels(0, hid), buf.channels(2 * hid, 3 * hid)
-            scratch = self.e.tensor(x.n, x.h, x.w, hid)
+            scratch = self.e.tensor(dn, dh, dw, hid)
             cur, oth = (P, Q) if n % 2 == 0 else (Q, P)
             probe = lambda i, src, dst: self.e.bottleneck(src, self._pack("%s.m.%d.conv1" % (p, i), [self._bn_part("%s.m.%d.conv1" % (p, i))], hid),
                                                           "silu", self._pack("%s.m.%d.conv2" % (p, i), [self._bn_part("%s.m.%d.conv2" % (p, i))], hid),
                                                           "silu", dst, src if shortcut else None, scratch)
             if n % 2 == 0:
-                self.cba([p + ".conv1", p + ".conv2"], x, out=buf.channels(0, 2 * hid))          # [main | short] -> [P | short]
+                self._csp_entry([p + ".conv1", p + ".conv2"], x, buf.channels(0, 2 * hid), down)          # [main | short] -> [P | short]
             else:
-                self.cba([p + ".conv2", p + ".conv1"], x, out=buf.channels(hid, 3 * hid))        # [short | main] -> [short | Q]
+                self._csp_entry([p + ".conv2", p + ".conv1"], x, buf.channels(hid, 3 * hid), down)        # [short | main] -> [short | Q]
             for i in range(n):
                 if not probe(i, cur, oth):
                     t = self.cba("%s.m.%d.conv1" % (p, i), cur, out=scratch)
@@ -205,10 +232,17 @@ class NetBuilder:
                     self._rec("%s.m.%d.conv2" % (p, i), oth, 0, hid)
                 cur, oth = oth, cur
             return self.cba(p + ".conv3", buf.channels(0, 2 * hid), out=out)
-        cat = self.e.tensor(x.n, x.h, x.w, 2 * hid)
-        t = self._cba_chain([p + ".conv1", p + ".conv2"], x, "%s.m.0.conv1" % p, hid, cat) if n else None
-        if t is None:
-            self.cba([p + ".conv1", p + ".conv2"], x, out=cat)          # [main | short]
+        if x is None and down is not None and not (self.trace is None and 2 * hid <= 128):
+            x, down = self.cba(down[0], down[1], 2), None               # (wider layers / tracing: the producer is emitted on its own)
+        if x is None:
+            cat = self.e.tensor(down[1].n, (down[1].h + 2 - 3) // 2 + 1, (down[1].w + 2 - 3) // 2 + 1, 2 * hid)
+            self._csp_entry([p + ".conv1", p + ".conv2"], None, cat, down)
+            t = None
+        else:
+            cat = self.e.tensor(x.n, x.h, x.w, 2 * hid)
+            t = self._cba_chain([p + ".conv1", p + ".conv2"], x, "%s.m.0.conv1" % p, hid, cat) if n else None
+            if t is None:
+                self.cba([p + ".conv1", p + ".conv2"], x, out=cat)          # [main | short]
         a = cat.channels(0, hid)
         for i in range(n):
             if t is None:
@@ -258,13 +292,22 @@ class NetBuilder:
             x = self.cba(q, self.e.focus_pack(img))
         att = lambda i: self.has("%s.lsk%d.proj_1.weight" % (p, i))     # new/darknet_att.py:161-201
         for i, name in enumerate(("dark2", "dark3", "dark4")):
+            down = None
             if not (fused_down and name == "dark2"):
-                x = self.cba("%s.%s.0" % (p, name), x, 2)
+                d0 = "%s.%s.0" % (p, name)
+                # the stride-2 conv feeds the CSPLayer alone: where the layer's conv1 | conv2 fit the chained kernel (<= 128
+                # output channels: dark2 / dark3 of YOLOX-s) they ride in its launch and its output never reaches memory
+                if self.trace is None and not self.is_depthwise(d0) and 2 * self.conv_out_channels("%s.%s.1.conv1" % (p, name)) <= 128 \
+                        and self.sd[d0 + ".conv.weight"].shape[-1] == 3:
+                    down = (d0, x)
+                    x = None
+                else:
+                    x = self.cba(d0, x, 2)
             if att(i + 2):
-                x = self.csp("%s.%s.1" % (p, name), x, True)
+                x = self.csp("%s.%s.1" % (p, name), x, True, down=down)
                 x = self.attention("%s.lsk%d" % (p, i + 2), x, out=homes.get(name))
             else:
-                x = self.csp("%s.%s.1" % (p, name), x, True, out=homes.get(name))
+                x = self.csp("%s.%s.1" % (p, name), x, True, out=homes.get(name), down=down)
             f[name] = x
         x = self.cba(p + ".dark5.0", x, 2)
         x = self.spp(p + ".dark5.1", x)

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GLSDET_ABI_VERSION 12
+#define GLSDET_ABI_VERSION 13
 
 enum { GLSDET_F16 = 0, GLSDET_F32 = 1 };
 enum { GLSDET_ACT_NONE = 0, GLSDET_ACT_SILU = 1, GLSDET_ACT_RELU = 2, GLSDET_ACT_LRELU = 3,
@@ -120,8 +120,13 @@ typedef struct glsdet_conv_chain {
   const void*  w2;         /* [cout_pad(y2.c)][kpad(1,1,cin2)] elements of y.dtype               */
   const float* scale2;
   const float* bias2;
-  int32_t act2, c0, cin2, _pad;
+  int32_t act2, c0, cin2;
+  int32_t flags;           /* 0 or GLSDET_CHAIN_SKIP_Y (ABI 13; the field was padding before)      */
 } glsdet_conv_chain;
+/* y is read by nothing but the chained conv: it is not stored (its view is still validated).  Needs c0 == 0, cin2 == y.c,
+ * no residual.  The stride-2 BaseConv in front of a CSPLayer (drone/models/base/darknet.py:174-195: `dark3 = Sequential(
+ * Conv(.., 3, 2), CSPLayer(..))`) + the layer's conv1 | conv2 then move the 3x3's output through LDS only.          */
+#define GLSDET_CHAIN_SKIP_Y 1
 int     glsdet_conv2d_chain(const glsdet_conv_desc* d, const glsdet_conv_chain* c, void* stream);
 int     glsdet_conv2d_chain_tune(const glsdet_conv_desc* d, const glsdet_conv_chain* c, void* stream, int32_t* best_hint,
                                  float* best_us);

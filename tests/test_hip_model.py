@@ -641,3 +641,42 @@ def test_bottleneck_entry_point_equals_two_convs_bit_for_bit(engines, mode, cin0
         d2b = desc(hid, xv, p2, 3, rv)
         assert eng.lib.glsdet_bottleneck(C.byref(d1), C.byref(d2b), hint, _stream_ptr(eng.stream)) != 0
         assert "in place" in eng.lib.glsdet_last_error().decode()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["f32", "f16"])
+@pytest.mark.parametrize("cin,hid,n,hw", [(32, 32, 1, (40, 52)), (64, 64, 3, (37, 45)), (32, 32, 2, (21, 19)), (64, 64, 1, (16, 16)),
+                                          (16, 24, 1, (30, 34)), (128, 128, 1, (18, 22))])
+def test_downsampling_conv_chained_into_the_csp_entry_equals_the_unfused_launches_bit_for_bit(engines, monkeypatch, mode, cin, hid, n, hw):
+    """darknet.py:174-195 `Sequential(BaseConv(.., 3, 2), CSPLayer(..))`: the layer's conv1 | conv2 chained onto the stride-2
+    conv that alone feeds them (glsdet_conv2d_chain with GLSDET_CHAIN_SKIP_Y: the 3x3's output is never stored) against the
+    separate launches: identical bits, one launch fewer where the chained kernel takes the pair (<= 128 chained channels),
+    the same number where it does not (hid 128); and against the oracle."""
+    from glsdet_amd.arch import _Table
+    from glsdet_amd.nets import NetBuilder
+    from glsdet_amd.synth import synth_input, synth_state_dict
+    eng = engines[mode]
+    t = _Table()
+    t.conv_bn("d", cin, 2 * hid, 3)
+    t.csp("m", 2 * hid, 2 * hid, n, False)
+    sd = synth_state_dict(t, 5)
+    x = synth_input((2, cin, hw[0], hw[1]), 9)
+    outs, nops = [], []
+    for unfused in (True, False):
+        if unfused:
+            monkeypatch.setenv("GLSDET_NO_DOWN_CHAIN", "1")
+        else:
+            monkeypatch.delenv("GLSDET_NO_DOWN_CHAIN", raising=False)
+        plan = eng.new_plan()
+        with plan:
+            out = NetBuilder(eng, sd).csp("m", None, True, down=("d", _upload(eng, x)))
+        plan.run()
+        torch.cuda.synchronize()
+        outs.append(out.to_nchw().cpu())
+        nops.append(plan.num_ops)
+    r = (lambda v: v.half().float()) if mode == "f16" else (lambda v: v)
+    want = O.csp_layer(sd, "m", r(O.base_conv(sd, "d", r(x), 2)), True)
+    assert float((outs[0] - want).abs().max()) <= (5e-5 if mode == "f32" else 2e-2) * max(1.0, float(want.abs().max()))
+    assert torch.equal(outs[0], outs[1])
+    fused = 2 * hid <= 128 and (cin * (4 if mode == "f32" else 2)) % 64 == 0      # the chained form needs whole K steps per tap
+    assert nops[1] == nops[0] - (1 if fused else 0), nops
