@@ -87,6 +87,10 @@ typedef struct glsdet_conv_desc {
                             * 8 / 9 halo with the weight tiles in an LDS-DMA ring (64- / 128-row cout tiles) | 10 / 11 the same with
                             *   64-byte channel chunks (64 / 128 rows) | 12 / 13 the 8-wave form: 128 cout rows x 8 x 32 pixels per
                             *   512-thread workgroup (128- / 64-byte chunks; no residual) | 3 weight-stationary 1x1 |
+                            * 0x100 | h, 0x200 | h (h = 8..11, 13): ring kernel h on 10 x 12 resp. 6 x 21 pixel tiles (h = 13:
+                            *   10 x 24 resp. 6 x 42) instead of 8 x 16 (8 x 32) -- fewer wasted lanes on 50 x 84 / 25 x 42 maps |
+                            * 16..31 the persistent LDS-DMA 1x1 kernel, variant hint - 16 (csrc/conv_gemm.hip: tile, ring
+                            *   depth, K panel, weight-resident, single shot) |
                             * co_tile<<16|px_tile (|0x8000: 64-byte K steps); 128<<16|0 = the 8-wave 128 x 256 tile */
 } glsdet_conv_desc;
 

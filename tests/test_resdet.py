@@ -696,3 +696,32 @@ def test_gl_fusion_detector_vs_oracle(mode):
         base_err = max(float((g.cpu() - w).abs().max()) for g, w in zip(pc + pr, bc + br)) / base_scale
         print("   plain MPDet f16 at the same seeds: %.2e of max |logit|" % base_err)
         assert abs_err / scale <= 1.5 * base_err + 0.05
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("assoc", ["gram", "gram+fold", "pair"])
+def test_gl_fusion_plugin_f16_at_the_benchmark_level_size(engines, assoc):
+    """the folded associations of the ResNet GL plug-in store G', T and Qm in fp16 and contract over
+    N = 4200 pixels and C + 64 channels at the benchmark's C3 level; the unit tests above stop at 13 x 21 maps.  Here: C = 512
+    on a 100 x 168 map (quadrants 50 x 84, N = 4200 -- what `mp_det_res50_gl_1344x800_bs8` runs at C3), a post-ReLU input
+    (non-negative, scale 2) as the backbone delivers it, fp16: no inf / NaN anywhere in the output, the error against the
+    fp32 oracle on fp16-rounded operands within the f16 bar of the small cases, and within 2 x the error of the reference's
+    own order of products ('dir') on the same data."""
+    from glsdet_amd.resdet import ResDetBuilder
+    from tests.test_hip_ops import _to_view
+    eng = engines["f16"]
+    c, hw = 512, (100, 168)
+    sd = _gl_plugin_sd("g", c, 3, "linear")
+    x = torch.relu(O.synth_input((1, c, hw[0], hw[1]), 11)) * 2.0
+    torch.set_num_threads(max(1, min(len(os.sched_getaffinity(0)), 32)))
+    with torch.no_grad():
+        want = _r(x, "f16") + O.patch_conv_nonlocal_new(sd, "g", _r(x, "f16"))
+    outs = {}
+    for a in (assoc, "dir"):
+        out = ResDetBuilder(eng, sd).gl_fusion("g", _to_view(eng, x), a.split("+")[0], fold=a.endswith("+fold"))
+        torch.cuda.synchronize()
+        outs[a] = out.to_nchw().cpu()
+        assert bool(torch.isfinite(outs[a]).all()), "%s: inf / NaN in the fp16 result" % a
+    err, base = _err(outs[assoc], want), _err(outs["dir"], want)
+    print("gl_fusion f16 C=512 @100x168 %s: %.2e of max |out| %.1f (reference order 'dir': %.2e)" % (assoc, err, float(want.abs().max()), base))
+    assert err <= 3e-2 and err <= 2.0 * base + 2e-3
