@@ -28,7 +28,9 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 constexpr int RS = KB + 16, CPRW = KB / 16, RPL = 256 / KB, RPI = 64 / CPRW;
 constexpr int CO_T = 128, PH = 14, PW = 38;
 constexpr int A_BYTES = CO_T * KB;
-constexpr int NI = CO_T / RPI / WAVES;
+constexpr int NIW = (CO_T / RPI) / WAVES;         // DMA pieces per wave and tap; 0 when a tap's tile has fewer pieces than waves
+constexpr int NI = NIW > 0 ? NIW : 1;            // (KB = 32: 4 pieces of 32 rows, issued by waves 0..3)
+constexpr bool SOME_WAVES = NIW == 0;
 constexpr int PATCH_OFF = RING * A_BYTES;
 constexpr int LDS = PATCH_OFF + PH * PW * RS;
 constexpr int KK = KB / 32;
@@ -57,9 +59,11 @@ __global__ __launch_bounds__(WAVES * 64) void loop_kernel(const unsigned char* _
   auto dma_next = [&]() __attribute__((always_inline)) {
 #ifndef NO_DMA
     unsigned char* dst = smem + dslot * A_BYTES + wave * 1024;
+    if (!SOME_WAVES || wave < CO_T / RPI) {
 #pragma unroll
     for (int q = 0; q < NI; ++q)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lds_ptr)(dst + q * WAVES * 1024), 16, (int)(wd[q] + dadd), 0, 0, 0);
+    }
     dslot = dslot + 1 == RING ? 0 : dslot + 1;
     dadd = (dadd + 256) & 2047;
 #endif

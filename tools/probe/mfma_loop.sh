@@ -23,6 +23,10 @@ run "-DKB=128 -DRING=4 -DPIPE"
 run "-DWAVES=4"
 run "-DWAVES=4 -DPIPE"
 run "-DWAVES=4 -DKB=128 -DRING=3" 
+run "-DKB=32 -DNSTEPS=392" 1024
+run "-DKB=32 -DNSTEPS=392" 512
+run "-DKB=32 -DNSTEPS=392 -DPIPE" 1024
+run "-DKB=32 -DNSTEPS=392 -DRING=6" 1024
 run "" 256
 run "-DPIPE" 256
 run "-DPIPE" 1024
