@@ -69,20 +69,20 @@ __global__ __launch_bounds__(256) void focus_stem_kernel(const StemArgs a) {
   const long plane = (long)a.H * a.W;
   const float* ibase = a.img + (long)img * 3 * plane;
 
-  // image loads of one tile: NL float2 per thread (channel, image row, packed column), held in registers so that the
-  // NEXT tile's loads are in flight while the current tile is multiplied and stored
-  constexpr int NQ = 3 * (2 * PH) * PW, NL = (NQ + 255) / 256;
-  float2 pre[NL];
+  // image loads of one tile: thread q < PH * PW owns packed pixel q and loads its six float2 (channel x image row: the
+  // TL|TR resp. BL|BR pairs), held in registers so that the NEXT tile's loads are in flight while the current tile is
+  // multiplied and stored; the 16 packed channels then go to LDS as whole 16-byte chunks
+  constexpr int NPP = PH * PW;
+  const int ppy = tid / PW, ppx = tid - ppy * PW;
+  float2 pre[6];
   auto issue_loads = [&](int tx0) __attribute__((always_inline)) {
+    const int Y = ty0 - 1 + ppy, X = tx0 - 1 + ppx;          // packed coordinates; outside the packed image: zero padding
+    const bool in = tid < NPP && (unsigned)Y < (unsigned)a.Ho && (unsigned)X < (unsigned)a.Wo;
+    const float* p0 = ibase + (long)(2 * Y) * a.W + 2 * X;
 #pragma unroll
-    for (int i = 0; i < NL; ++i) {
-      const int q = tid + i * 256;
-      const int px = q % PW, r = q / PW;
-      const int iy_l = r % (2 * PH), c = r / (2 * PH);
-      const int Y = ty0 - 1 + (iy_l >> 1), X = tx0 - 1 + px;   // packed coordinates; outside the packed image: zero padding
+    for (int i = 0; i < 6; ++i) {                            // i = dy * 3 + c
       pre[i] = float2{0.f, 0.f};
-      if (q < NQ && (unsigned)Y < (unsigned)a.Ho && (unsigned)X < (unsigned)a.Wo)
-        pre[i] = *reinterpret_cast<const float2*>(ibase + c * plane + (long)(2 * Y + (iy_l & 1)) * a.W + 2 * X);
+      if (in) pre[i] = *reinterpret_cast<const float2*>(p0 + (i % 3) * plane + (i / 3) * a.W);
     }
   };
   issue_loads(sx * STRIP * TW);
@@ -91,22 +91,18 @@ __global__ __launch_bounds__(256) void focus_stem_kernel(const StemArgs a) {
     if (tx >= a.tiles_x) break;                     // uniform
     const int tx0 = tx * TW;
     __syncthreads();                                // the previous tile's store phase is done with sP
-    // ---- packed patch: one float2 = the dx = 0 | 1 pair of one packed pixel
+    // ---- packed patch: channels [TL c0-2 | BL c0-2 | TR c0-2 | BR c0-2 | 0 0 0 0] of pixel `tid`
+    if (tid < NPP) {
+      T v[16];
 #pragma unroll
-    for (int i = 0; i < NL; ++i) {
-      const int q = tid + i * 256;
-      if (q < NQ) {
-        const int px = q % PW, r = q / PW;
-        const int iy_l = r % (2 * PH), c = r / (2 * PH);
-        const int py = iy_l >> 1, dy = iy_l & 1;
-        T* dst = reinterpret_cast<T*>(sP + (py * PW + px) * PRS);
-        dst[dy * 3 + c] = (T)pre[i].x;              // TL (dy 0) / BL (dy 1): channels 0..2 / 3..5
-        dst[6 + dy * 3 + c] = (T)pre[i].y;          // TR / BR: channels 6..8 / 9..11
+      for (int i = 0; i < 6; ++i) {
+        v[i] = (T)pre[i].x;                           // TL (dy 0) / BL (dy 1): channels 0..2 / 3..5
+        v[6 + i] = (T)pre[i].y;                       // TR / BR: channels 6..8 / 9..11
       }
-    }
-    for (int q = tid; q < PH * PW; q += 256) {      // channels 12..15
-      T* dst = reinterpret_cast<T*>(sP + q * PRS) + 12;
-      dst[0] = dst[1] = dst[2] = dst[3] = (T)0.f;
+      v[12] = v[13] = v[14] = v[15] = (T)0.f;
+      unsigned char* dst = sP + tid * PRS;
+#pragma unroll
+      for (int k = 0; k < 16 * ES / 16; ++k) *reinterpret_cast<u32x4*>(dst + k * 16) = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(v) + k * 16);
     }
     if (s + 1 < STRIP && tx + 1 < a.tiles_x) issue_loads(tx0 + TW);
     __syncthreads();
