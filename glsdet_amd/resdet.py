@@ -60,6 +60,15 @@ class ResDetBuilder:
         self.e = eng
         self.sd = {k: v.detach().cpu() for k, v in sd.items()}
         self._packed = {}
+        self.trace = None       # tests: dict name -> NCHW fp32 snapshot of every stored tensor (eager emission only)
+
+    def _rec(self, name: str, v: TView, c0: int = 0, c1: Optional[int] = None) -> TView:
+        """Per-layer trace for the teacher-forced parity test (tests/test_resdet.py): a snapshot of the tensor the op at
+        `name` just stored, under the store-point names of oracle/mpdet_oracle.py.  Eager emission only."""
+        if self.trace is not None:
+            t = v.to_nchw()
+            self.trace[name] = t[:, c0:(c1 if c1 is not None else t.shape[1])].cpu()
+        return v
 
     # ------------------------------------------------------------------ weights
     def _pack(self, key, parts, cin_pad):
@@ -88,14 +97,15 @@ class ResDetBuilder:
     def bottleneck(self, p: str, x: TView, stride: int) -> TView:
         """resnet.py:263-303 (style='pytorch': the stride sits on the 3x3)."""
         e = self.e
-        t = e.conv(x, self._pack(p + ".conv1", [self._bn_part(p + ".conv1", p + ".bn1")], x.c), 1, 0, "relu")
-        t = e.conv(t, self._pack(p + ".conv2", [self._bn_part(p + ".conv2", p + ".bn2")], t.c), stride, 1, "relu")
+        t = self._rec(p + ".conv1", e.conv(x, self._pack(p + ".conv1", [self._bn_part(p + ".conv1", p + ".bn1")], x.c), 1, 0, "relu"))
+        t = self._rec(p + ".conv2", e.conv(t, self._pack(p + ".conv2", [self._bn_part(p + ".conv2", p + ".bn2")], t.c), stride, 1, "relu"))
         idn = x
         if p + ".downsample.0.weight" in self.sd:
             idn = e.conv(x, self._pack(p + ".downsample", [self._bn_part(p + ".downsample.0", p + ".downsample.1")], x.c),
                          stride, 0, "none")
-        return e.conv(t, self._pack(p + ".conv3", [self._bn_part(p + ".conv3", p + ".bn3")], t.c), 1, 0, "relu",
-                      res=idn, res_first=True)
+            self._rec(p + ".downsample", idn)
+        return self._rec(p + ".conv3", e.conv(t, self._pack(p + ".conv3", [self._bn_part(p + ".conv3", p + ".bn3")], t.c), 1, 0, "relu",
+                                              res=idn, res_first=True))
 
     def resnet(self, p: str, img: torch.Tensor, depth: int = 50, out_indices: Sequence[int] = (0, 1, 2, 3)) -> List[TView]:
         """resnet.py:631-646."""
@@ -106,7 +116,7 @@ class ResDetBuilder:
             key = (p + ".conv1", "rstem")
             if key not in self._packed:
                 self._packed[key] = e.pack_resnet_stem(*self._bn_part(p + ".conv1", p + ".bn1"))
-            if getattr(self, "trace", None) is None and not os.environ.get("GLSDET_NO_RSTEM_POOL"):
+            if not os.environ.get("GLSDET_NO_RSTEM_POOL"):
                 x = e.resnet_stem_pool(img, self._packed[key])            # ... and the max pool in its epilogue
             else:
                 x = e.pool2d(e.resnet_stem(img, self._packed[key], "relu"), 3, 2, 1)
@@ -114,6 +124,7 @@ class ResDetBuilder:
             x = e.nchw_pack(img)
             x = e.conv(x, self._pack(p + ".conv1", [self._bn_part(p + ".conv1", p + ".bn1")], x.c), 2, 3, "relu")
             x = e.pool2d(x, 3, 2, 1)
+        self._rec(p + ".maxpool", x)
         outs = []
         for i, nblocks in enumerate(STAGE_BLOCKS[depth]):
             for j in range(nblocks):
@@ -503,13 +514,16 @@ class ResDetBuilder:
         #   "window" (default): all of it, gl_lateral;  "deferred": channel_conv composed with the lateral conv, per pixel;
         #   "stored": the plug-in output as a tensor, then the lateral conv
         tail = "stored" if os.environ.get("GLSDET_NO_LATERAL_FOLD") else os.environ.get("GLSDET_GL_TAIL", "window")
+        if self.trace is not None:
+            tail = "stored"          # (a trace holds the plug-in's output as the tensor the reference has there)
+        conv = lambda name, x, stride, pad, _c=conv: self._rec(name, _c(name, x, stride, pad))
         for i, inp in enumerate(inputs):
             if isinstance(inp, GlPending):
                 last = i == len(inputs) - 1
                 if i < start_level:
                     inputs[i] = None                                         # a level the FPN does not read at all
                 elif (mode == "on_input" and last) or (inp.p + ".channel_conv.weight") not in self.sd or tail == "stored":
-                    inputs[i] = self.gl_fusion(inp.p, inp.x, inp.assoc)      # stored: the extra level reads C5 itself / BaseConv channel_cat
+                    inputs[i] = self._rec(inp.p, self.gl_fusion(inp.p, inp.x, inp.assoc))   # stored: the extra level reads C5 itself / BaseConv channel_cat
                 elif tail == "deferred":
                     inputs[i] = self.gl_fusion(inp.p, inp.x, inp.assoc, defer=True)
         lat = []
@@ -523,6 +537,7 @@ class ResDetBuilder:
                 lat.append(conv(name, inp, 1, 0))
         for i in range(n_lat - 1, 0, -1):
             e.upsample_add(lat[i], lat[i - 1])
+            self._rec("%s.topdown.%d" % (p, i - 1), lat[i - 1])
         outs = [conv("%s.fpn_convs.%d.conv" % (p, i), lat[i], 1, 1) for i in range(n_lat)]
         if num_outs > len(outs):
             if not add_extra_convs:
@@ -585,15 +600,21 @@ class ResDetBuilder:
         pk0 = self._pack(p + ".tower0", [raw(n) for n in names0], feats[0].c)
         both, pre = self._conv_levels(feats, [pk0] * L, 1, gn_groups=64)
         ga, be = self._gn_params(p + ".tower0", names0)
-        e.groupnorm_multi(both, 64, [ga] * L, [be] * L, GN_EPS, "relu", pre=pre)
+        rec = lambda i, kind, ts: [self._rec("%s.%s_convs.%d.%s@%d" % (p, ("cls", "reg")[k % 2], i, kind, k // 2), t)
+                                   for k, t in enumerate(ts)] if self.trace is not None else None
         cur = [t.channels(j * f, (j + 1) * f) for t in both for j in (0, 1)]      # level-major: cls_l, reg_l
+        rec(0, "conv", cur)
+        e.groupnorm_multi(both, 64, [ga] * L, [be] * L, GN_EPS, "relu", pre=pre)
+        rec(0, "gn", cur)
         for i in range(1, stacked):
             names = ["%s.%s_convs.%d" % (p, which, i) for which in ("cls", "reg")]
             pks = [self._pack(n, [raw(n)], f) for n in names]
             gb = [self._gn_params(n, [n]) for n in names]
             cur, pre = self._conv_levels(cur, pks * L, 1, per_level=2, gn_groups=32)
+            rec(i, "conv", cur)
             e.groupnorm_multi(cur, 32, [gb[j][0] for _ in range(L) for j in (0, 1)],
                               [gb[j][1] for _ in range(L) for j in (0, 1)], GN_EPS, "relu", pre=pre)
+            rec(i, "gn", cur)
         return cur[0::2], cur[1::2]
 
     def _reg_preds(self, p: str, regs: Sequence[TView]) -> List[TView]:
@@ -620,6 +641,8 @@ class ResDetBuilder:
         reg = self._reg_preds(p, rs)
         pkf = self._pack(p + ".gfl_cls_conv", [self._plain_part(p + ".gfl_cls_conv")], cs[0].c)
         fs = self._conv_levels(cs, [pkf] * len(cs), 1)
+        for l, t in enumerate(fs):
+            self._rec("%s.gfl_cls_conv@%d" % (p, l), t)
         w = centers.reshape(centers.shape[0], centers.shape[1], 1, 1)
         pkp = self._pack(p + ".proxies", [(w, torch.ones(w.shape[0]), torch.zeros(w.shape[0]))], fs[0].c)
         dots = self._conv_levels(fs, [pkp] * len(fs), 0, out_dtype=F32)
@@ -657,8 +680,9 @@ class HipGflDetector:
         self._compiled: Dict[Tuple, _Compiled] = {}
         self._cache_lock = threading.Lock()       # plan cache: looked up / LRU-touched / evicted by several lanes' threads
 
-    def _emit(self, eng: Engine, img: torch.Tensor):
+    def _emit(self, eng: Engine, img: torch.Tensor, trace: Optional[dict] = None):
         b, c = ResDetBuilder(eng, self.sd), self.cfg
+        b.trace = trace
         stages = b.resnet("backbone", img, c["depth"], c["out_indices"])
         levels = c["gl_levels"]
         if levels is None:
@@ -748,6 +772,17 @@ class HipGflDetector:
     def run_async(c: _Compiled):
         assert c.plan.captured, "run_async needs compile(..., use_graph=True)"
         c.plan.launch(c.graph_stream)
+
+    def forward_traced(self, img: torch.Tensor):
+        """forward_raw emitted EAGERLY (no plan) with a snapshot of every stored tensor: (cls, reg, {store point: NCHW fp32})
+        under the names of oracle/mpdet_oracle.py.  The traced graph is the unfused one where a fusion removes a tensor the
+        reference has (stem + pool stay one launch: one store; the plug-in's output is stored, not folded into the lateral)."""
+        eng = Engine(self.dtype, self.device)
+        tr: Dict[str, torch.Tensor] = {}
+        cls, reg = self._emit(eng, img.to(eng.device, torch.float32).contiguous(), tr)
+        torch.cuda.synchronize(eng.device)
+        bins = 4 * (self.cfg["reg_max"] + 1)
+        return [l.to_nchw(self.num_classes) for l in cls], [l.to_nchw(bins) for l in reg], tr
 
     def forward_raw(self, img: torch.Tensor) -> Tuple[List[torch.Tensor], List[torch.Tensor]]:
         """Reference-shaped head outputs: (cls_scores, bbox_preds), per level NCHW fp32

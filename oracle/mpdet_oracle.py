@@ -27,6 +27,14 @@ the same order).  What the fixtures cannot cover is ``mmcv.ops.batched_nms`` (a 
 step, as for torchvision's in the YOLOX path -- and so does the GL-fusion plug-in's WIRING on ResNet (this build's own,
 DESIGN.md A12; the plug-in module itself is the pinned Patch_Conv_NonLocal_new).
 State-dict key names are mmdet's (torchvision ResNet names for the backbone).
+
+fp16-storage emulation (round 3): inside ``with glsdet_oracle.fp16_storage():`` every tensor is rounded to fp16 where the HIP
+path's f16 mode stores fp16 -- the image, every conv weight (the normalised proxies included), the pooled stem output, every
+Bottleneck conv after its epilogue (conv3 after the residual add and ReLU), the FPN laterals, each top-down sum, the FPN
+outputs, every tower conv before AND after its GroupNorm + ReLU, the MPHead feature -- and stays fp32 where the HIP path
+keeps fp32 (BN / GN statistics and affine, accumulators, the regression and proxy logits).  The plug-in's folded
+associations reorder its products, so its rounding points are those of glsdet_oracle.patch_conv_nonlocal_new (a model of the
+HIP plug-in's storage, not its replica).
 """
 from __future__ import annotations
 
@@ -36,6 +44,7 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
+from . import glsdet_oracle as _G
 from .glsdet_oracle import batched_nms, patch_conv_nonlocal_new
 
 Tensor = torch.Tensor
@@ -43,6 +52,16 @@ SD = Dict[str, Tensor]
 RESNET_BN_EPS = 1e-5           # nn.BatchNorm2d default (mmcv build_norm_layer(dict(type='BN')))
 GN_EPS = 1e-5                  # nn.GroupNorm default
 STAGE_BLOCKS = {50: (3, 4, 6, 3), 101: (3, 4, 23, 3)}     # resnet.py arch_settings
+
+
+def _q(x: Tensor, name: str) -> Tensor:
+    """a store point of the HIP path (glsdet_oracle._q: rounds under fp16_storage, feeds TRACE / FORCE)"""
+    return _G._q(x, name)
+
+
+def _w(sd: SD, key: str) -> Tensor:
+    """a conv weight as the HIP path holds it (fp16 under fp16_storage)"""
+    return _G._qw(sd[key], key[:-len(".weight")])
 
 
 def _bn(sd: SD, p: str, x: Tensor) -> Tensor:
@@ -53,20 +72,20 @@ def _bn(sd: SD, p: str, x: Tensor) -> Tensor:
 def bottleneck(sd: SD, p: str, x: Tensor, stride: int) -> Tensor:
     """resnet.py:263-303, style='pytorch' (stride on the 3x3): relu(bn3(conv3(relu(bn2(conv2(
     relu(bn1(conv1(x)))))))) + identity) with identity = downsample(x) when present."""
-    out = torch.relu(_bn(sd, p + ".bn1", F.conv2d(x, sd[p + ".conv1.weight"])))
-    out = torch.relu(_bn(sd, p + ".bn2", F.conv2d(out, sd[p + ".conv2.weight"], None, stride, 1)))
-    out = _bn(sd, p + ".bn3", F.conv2d(out, sd[p + ".conv3.weight"]))
+    out = _q(torch.relu(_bn(sd, p + ".bn1", F.conv2d(x, _w(sd, p + ".conv1.weight")))), p + ".conv1")
+    out = _q(torch.relu(_bn(sd, p + ".bn2", F.conv2d(out, _w(sd, p + ".conv2.weight"), None, stride, 1))), p + ".conv2")
+    out = _bn(sd, p + ".bn3", F.conv2d(out, _w(sd, p + ".conv3.weight")))
     identity = x
     if p + ".downsample.0.weight" in sd:          # res_layer.py:39-61: 1x1 conv (stride s) + BN
-        identity = _bn(sd, p + ".downsample.1", F.conv2d(x, sd[p + ".downsample.0.weight"], None, stride))
-    return torch.relu(out + identity)
+        identity = _q(_bn(sd, p + ".downsample.1", F.conv2d(x, _w(sd, p + ".downsample.0.weight"), None, stride)), p + ".downsample")
+    return _q(torch.relu(out + identity), p + ".conv3")       # (the HIP epilogue adds the identity before its one store)
 
 
 def resnet(sd: SD, p: str, x: Tensor, depth: int = 50, out_indices: Sequence[int] = (0, 1, 2, 3)) -> List[Tensor]:
     """resnet.py:631-646: 7x7 s2 conv + BN + ReLU, 3x3 s2 max pool (pad 1), four stages."""
     pre = p + "." if p else ""
-    x = torch.relu(_bn(sd, pre + "bn1", F.conv2d(x, sd[pre + "conv1.weight"], None, 2, 3)))
-    x = F.max_pool2d(x, 3, 2, 1)
+    x = torch.relu(_bn(sd, pre + "bn1", F.conv2d(_q(x, "input"), _w(sd, pre + "conv1.weight"), None, 2, 3)))
+    x = _q(F.max_pool2d(x, 3, 2, 1), pre + "maxpool")          # (stem + pool are one kernel: one store; max and rounding commute)
     outs = []
     for i, nblocks in enumerate(STAGE_BLOCKS[depth]):
         for j in range(nblocks):
@@ -76,8 +95,9 @@ def resnet(sd: SD, p: str, x: Tensor, depth: int = 50, out_indices: Sequence[int
     return outs
 
 
-def _conv_b(sd: SD, p: str, x: Tensor, stride: int = 1, pad: int = 0) -> Tensor:
-    return F.conv2d(x, sd[p + ".weight"], sd.get(p + ".bias"), stride, pad)
+def _conv_b(sd: SD, p: str, x: Tensor, stride: int = 1, pad: int = 0, store: bool = True, tag: str = "") -> Tensor:
+    y = F.conv2d(x, _w(sd, p + ".weight"), sd.get(p + ".bias"), stride, pad)
+    return _q(y, p + tag) if store else y
 
 
 def fpn(sd: SD, p: str, inputs: Sequence[Tensor], start_level: int = 0, num_outs: int = 5,
@@ -87,7 +107,7 @@ def fpn(sd: SD, p: str, inputs: Sequence[Tensor], start_level: int = 0, num_outs
     n_lat = len(inputs) - start_level
     lat = [_conv_b(sd, "%s.lateral_convs.%d.conv" % (p, i), inputs[i + start_level]) for i in range(n_lat)]
     for i in range(n_lat - 1, 0, -1):
-        lat[i - 1] = lat[i - 1] + F.interpolate(lat[i], size=lat[i - 1].shape[2:], mode="nearest")
+        lat[i - 1] = _q(lat[i - 1] + F.interpolate(lat[i], size=lat[i - 1].shape[2:], mode="nearest"), "%s.topdown.%d" % (p, i - 1))
     outs = [_conv_b(sd, "%s.fpn_convs.%d.conv" % (p, i), lat[i], 1, 1) for i in range(n_lat)]
     if num_outs > len(outs):
         if not add_extra_convs:
@@ -103,35 +123,46 @@ def fpn(sd: SD, p: str, inputs: Sequence[Tensor], start_level: int = 0, num_outs
     return outs
 
 
-def conv_gn_relu(sd: SD, p: str, x: Tensor, groups: int = 32) -> Tensor:
-    """mmcv ConvModule(norm_cfg=GN32): 3x3 conv without bias -> GroupNorm -> ReLU."""
-    y = F.conv2d(x, sd[p + ".conv.weight"], None, 1, 1)
-    return torch.relu(F.group_norm(y, groups, sd[p + ".gn.weight"], sd[p + ".gn.bias"], GN_EPS))
+def conv_gn_relu(sd: SD, p: str, x: Tensor, groups: int = 32, tag: str = "") -> Tensor:
+    """mmcv ConvModule(norm_cfg=GN32): 3x3 conv without bias -> GroupNorm -> ReLU.  tag: suffix of the two store-point
+    names (the towers are shared by the levels: '@<level>')."""
+    y = _q(F.conv2d(x, _w(sd, p + ".conv.weight"), None, 1, 1), p + ".conv" + tag)
+    return _q(torch.relu(F.group_norm(y, groups, sd[p + ".gn.weight"], sd[p + ".gn.bias"], GN_EPS)), p + ".gn" + tag)
 
 
-def _towers(sd: SD, p: str, x: Tensor, stacked: int) -> Tuple[Tensor, Tensor]:
+def _towers(sd: SD, p: str, x: Tensor, stacked: int, level: int = 0) -> Tuple[Tensor, Tensor]:
     c = r = x
     for i in range(stacked):
-        c = conv_gn_relu(sd, "%s.cls_convs.%d" % (p, i), c)
+        c = conv_gn_relu(sd, "%s.cls_convs.%d" % (p, i), c, tag="@%d" % level)
     for i in range(stacked):
-        r = conv_gn_relu(sd, "%s.reg_convs.%d" % (p, i), r)
+        r = conv_gn_relu(sd, "%s.reg_convs.%d" % (p, i), r, tag="@%d" % level)
     return c, r
+
+
+def _reg_pred(sd: SD, p: str, r: Tensor, l: int) -> Tensor:
+    """gfl_head.py:198-201: Scale_l(gfl_reg(reg_feat)).float().  Under fp16_storage mmcv's Scale is folded into the fp16
+    weights, as the HIP path packs them (one rounding of w * s instead of w)."""
+    s = sd["%s.scales.%d.scale" % (p, l)]
+    if _G._EMU is not None and _G._EMU(p + ".gfl_reg.weight"):
+        b = sd.get(p + ".gfl_reg.bias")
+        return F.conv2d(r, _G._qw(sd[p + ".gfl_reg.weight"] * s, p + ".gfl_reg"), None if b is None else b * s, 1, 1).float()
+    return (_conv_b(sd, p + ".gfl_reg", r, 1, 1, store=False) * s).float()
 
 
 def gfl_head(sd: SD, p: str, feats: Sequence[Tensor], stacked: int = 4) -> Tuple[List[Tensor], List[Tensor]]:
     """gfl_head.py:179-203; the towers and predictors are SHARED by all levels, Scale is per level."""
     cls, reg = [], []
     for l, x in enumerate(feats):
-        c, r = _towers(sd, p, x, stacked)
-        cls.append(_conv_b(sd, p + ".gfl_cls", c, 1, 1))
-        reg.append((_conv_b(sd, p + ".gfl_reg", r, 1, 1) * sd["%s.scales.%d.scale" % (p, l)]).float())
+        c, r = _towers(sd, p, x, stacked, l)
+        cls.append(_conv_b(sd, p + ".gfl_cls", c, 1, 1, store=False))
+        reg.append(_reg_pred(sd, p, r, l))
     return cls, reg
 
 
 def forward_proxy(feat: Tensor, proxies: Tensor, proxies_list: Sequence[int], gamma: float) -> Tensor:
     """mp_head.py:105-121: cosine similarity to every proxy; per class a softmax(gamma*sim)
     weighted mean of that class's similarities, times gamma."""
-    centers = F.normalize(proxies, p=2, dim=1)
+    centers = _G._qw(F.normalize(proxies, p=2, dim=1), "proxies")
     feat = F.normalize(feat, p=2, dim=1)
     sim = feat.matmul(centers.t())
     out, pos = [], 0
@@ -148,9 +179,9 @@ def mp_head(sd: SD, p: str, feats: Sequence[Tensor], proxies_list: Sequence[int]
     forward_proxy per position."""
     cls, reg = [], []
     for l, x in enumerate(feats):
-        c, r = _towers(sd, p, x, stacked)
-        reg.append((_conv_b(sd, p + ".gfl_reg", r, 1, 1) * sd["%s.scales.%d.scale" % (p, l)]).float())
-        f = _conv_b(sd, p + ".gfl_cls_conv", c, 1, 1)
+        c, r = _towers(sd, p, x, stacked, l)
+        reg.append(_reg_pred(sd, p, r, l))
+        f = _conv_b(sd, p + ".gfl_cls_conv", c, 1, 1, tag="@%d" % l)
         b, ch, h, w = f.shape
         s = forward_proxy(f.permute(0, 2, 3, 1).reshape(-1, ch), sd[p + ".proxies"], proxies_list, gamma)
         cls.append(s.reshape(b, h, w, -1).permute(0, 3, 1, 2).contiguous())
@@ -226,7 +257,7 @@ def gl_fusion_inputs(sd: SD, p: str, stages: Sequence[Tensor]) -> List[Tensor]:
     for i, f in enumerate(stages):
         q = "%s.gl_fusion.%d" % (p, i)
         if q + ".feat_patchconv_lt_nonlocal.theta.weight" in sd:
-            out[i] = f + patch_conv_nonlocal_new(sd, q, f)
+            out[i] = _q(f + patch_conv_nonlocal_new(sd, q, f), q)
     return out
 
 
