@@ -38,6 +38,8 @@ class NetBuilder:
         self._packed = {}
         self._override = {}     # BaseConv name -> (w, scale, bias) replacing the state_dict's (compose_1x1_input)
         self.trace = None       # tests: dict name -> NCHW fp32 snapshot of every stored tensor (eager emission only)
+        self.composed = None    # tests: dict filled with name -> (w, scale, bias) of every host-composed conv; when set, a
+        #                         trace keeps the composed forms (the tensors they remove are then simply not in the trace)
 
     def _rec(self, name: str, v: TView, c0: int = 0, c1: Optional[int] = None):
         """Per-layer trace for the parity tests (tests/test_f16_emulation.py): a snapshot of the tensor the
@@ -378,6 +380,8 @@ class NetBuilder:
         Wn = torch.cat([W[:, :c0], W[:, c0:c1] @ wl, W[:, c1:]], 1)
         bn = b.double() + s.double() * (W[:, c0:c1] @ bl)
         self._override[consumer] = (Wn.float().reshape(w.shape[0], -1, 1, 1), s, bn.float())
+        if self.composed is not None:
+            self.composed[consumer] = self._override[consumer]
 
     def patch_conv(self, p: str, x: TView, stride: int, with_nonlocal: bool, out: Optional[TView] = None,
                    z_out: Optional[TView] = None) -> TView:
@@ -613,6 +617,8 @@ class NetBuilder:
         W1 = w1.double().reshape(w1.shape[0], -1)
         w = torch.einsum("om,mikl->oikl", W1, wid).float()
         b = (b1.double() + s1.double() * (W1 @ bid)).float()
+        if self.composed is not None:
+            self.composed[stem] = (w, s1, b)
         pk = self._pack(stem + "*" + ident, [(w, s1, b)], x.c)
         y = self.e.conv(x, pk, 1, wid.shape[-1] // 2, "silu")
         self._rec(stem, y, 0, w.shape[0])
@@ -634,7 +640,7 @@ class NetBuilder:
         # composed with them, the concat holds the block's [lr | tb] tensor instead and the channel_conv is never launched
         pc1 = p + ".Patch_conv_feat1"
         zc = 2 * self.conv_out_channels(pc1 + ".feat_patchconv_lt") if gl else 0
-        fold1 = gl and self.trace is None and not os.environ.get("GLSDET_NO_PATCH_FOLD") and self.has(pc1 + ".channel_conv.bias") \
+        fold1 = gl and (self.trace is None or self.composed is not None) and not os.environ.get("GLSDET_NO_PATCH_FOLD") and self.has(pc1 + ".channel_conv.bias") \
             and zc < c4 and not self.is_depthwise(p + ".C3_p4.conv1")
         cat_p4 = e.tensor(n, h4, w4, 2 * c4 + (zc if fold1 else extra * c4))      # [up(P5) | feat2 | (feat1_patch)]
         cat_p3 = e.tensor(n, h3, w3, 2 * c3)                # [up(P4) | feat1]
@@ -668,7 +674,7 @@ class NetBuilder:
         self._p5_identity = None
         if gl:
             # (a trace holds every stored tensor, P5_Identity's output among them: tracing keeps the two-launch form)
-            if fold_p5 and self.trace is None and not os.environ.get("GLSDET_NO_HEAD_FOLD"):
+            if fold_p5 and (self.trace is None or self.composed is not None) and not os.environ.get("GLSDET_NO_HEAD_FOLD"):
                 self._p5_identity = p + ".P5_Identity"
             else:
                 P5o = self.identity_conv(p + ".P5_Identity", P5o)
@@ -752,12 +758,13 @@ class NetBuilder:
         return outs
 
 
-def build_forward(kind: str, eng: Engine, sd, img: torch.Tensor, trace: Optional[dict] = None):
+def build_forward(kind: str, eng: Engine, sd, img: torch.Tensor, trace: Optional[dict] = None, composed: Optional[dict] = None):
     """Emit the whole raw forward of a `kind` in {'base','gl','cross'} detector for the static input
     tensor `img` (NCHW fp32 on the device).  Returns (list of fp32 level views, num_classes).
-    trace: dict filled with a snapshot of every stored tensor (eager emission only; parity tests)."""
+    trace: dict filled with a snapshot of every stored tensor (eager emission only; parity tests).  composed: dict filled
+    with the host-composed convs' (w, scale, bias); a trace then keeps the composed forms the benchmark runs."""
     b = NetBuilder(eng, sd)
-    b.trace = trace
+    b.trace, b.composed = trace, composed
     if kind not in ("base", "gl", "cross"):
         raise ValueError("unknown detector kind %r" % kind)
     fold = kind == "gl" and not b.is_depthwise("head.stems.2")

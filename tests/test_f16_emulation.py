@@ -129,6 +129,123 @@ def test_every_kernel_is_within_one_fp16_ulp_on_its_own_inputs(golden, shapes, t
     assert dl <= 5e-5
 
 
+def _oracle_sd_with_composed_weights(sd, composed):
+    """A state_dict under which the ORACLE computes the composed convs of the benchmarked GL-fusion plan with the composed
+    weights themselves (so that they are rounded to fp16 as ONE matrix, as the HIP path packs them):
+      Patch_conv_feat1.channel_conv -> [I ; 0]: its output is the block's [lr | tb] tensor padded with zero channels (exact),
+          C3_p4.conv1 / conv2 read it through the composed columns W[:, c0:c1] Wlin (zero columns under the padding);
+      P5_Identity -> the composed k x k conv to the stem's width in its first rows (no bias; its output is not a store point
+          of the HIP plan and stays fp32: see `select`), head.stems.2 -> [I | 0] with the composed bias through its BN.
+    BN of a composed consumer: gamma = the folded scale, beta = the composed bias, mean 0, var 1 - eps."""
+    sd = dict(sd)
+
+    def set_bn(p, s, b):
+        sd[p + ".bn.weight"], sd[p + ".bn.bias"] = s.clone().float(), b.clone().float()
+        sd[p + ".bn.running_mean"] = torch.zeros_like(s, dtype=torch.float32)
+        sd[p + ".bn.running_var"] = torch.full_like(s, 1.0 - O.BN_EPS, dtype=torch.float32)
+
+    lin = "backbone.Patch_conv_feat1.channel_conv"
+    c4, zc = sd[lin + ".weight"].shape[:2]
+    for cons in ("backbone.C3_p4.conv1", "backbone.C3_p4.conv2"):
+        w, s_, b_ = composed[cons]
+        co, cin = w.shape[:2]
+        assert cin == 2 * c4 + zc and sd[cons + ".conv.weight"].shape[1] == 3 * c4
+        sd[cons + ".conv.weight"] = torch.cat([w, torch.zeros(co, c4 - zc, 1, 1)], 1)
+        set_bn(cons, s_, b_)
+    eye = torch.zeros(c4, zc, 1, 1)
+    eye[:zc, :, 0, 0] = torch.eye(zc)
+    sd[lin + ".weight"], sd[lin + ".bias"] = eye, torch.zeros(c4)
+    stem, ident = "head.stems.2", "backbone.P5_Identity"
+    w, s_, b_ = composed[stem]
+    f, cin, k, _ = w.shape
+    full = torch.zeros_like(sd[ident + ".conv.weight"])
+    assert full.shape[1:] == w.shape[1:] and sd[stem + ".conv.weight"].shape[1] == full.shape[0]
+    full[:f] = w
+    sd[ident + ".conv.weight"], sd[ident + ".conv.bias"] = full, torch.zeros(full.shape[0])
+    eye = torch.zeros(f, full.shape[0], 1, 1)
+    eye[:, :f, 0, 0] = torch.eye(f)
+    sd[stem + ".conv.weight"] = eye
+    set_bn(stem, s_, b_)
+    return sd, (lambda name: name != ident + ".conv"), {lin, ident + ".conv"}
+
+
+def test_oracle_on_the_composed_state_dict_equals_the_oracle_in_fp32(golden, shapes):
+    """CPU: the construction the GPU test below relies on.  With the compositions done as NetBuilder does them (float64 on the
+    host: compose_1x1_input, stem_of_identity) and nothing rounded, the oracle on the rewritten state_dict returns the
+    reference's logits (fp32 re-association only)."""
+    from glsdet_amd.nets import NetBuilder
+    meta, sd, x, outs, _ = model_case(golden, shapes, "gl_tiny_seed0")
+    b = NetBuilder(None, sd)
+    b.composed = {}
+    c4 = sd["backbone.Patch_conv_feat1.channel_conv.weight"].shape[0]
+    for cons in ("backbone.C3_p4.conv1", "backbone.C3_p4.conv2"):
+        b.compose_1x1_input(cons, 2 * c4, 3 * c4, "backbone.Patch_conv_feat1.channel_conv")
+    w1, s1, b1 = b._bn_part("head.stems.2")
+    wid, bid = sd["backbone.P5_Identity.conv.weight"].double(), sd["backbone.P5_Identity.conv.bias"].double()
+    W1 = w1.double().reshape(w1.shape[0], -1)
+    b.composed["head.stems.2"] = (torch.einsum("om,mikl->oikl", W1, wid).float(), s1, (b1.double() + s1.double() * (W1 @ bid)).float())
+    sd2, select, gone = _oracle_sd_with_composed_weights(sd, b.composed)
+    with torch.no_grad():
+        got = O.FORWARDS["gl"](sd2, x)
+    scale = max(float(w.abs().max()) for w in outs)
+    err = max(float((g - w).abs().max()) for g, w in zip(got, outs)) / scale
+    assert err <= 2e-5, err
+    assert select("backbone.P5_Identity.conv.weight") and not select("backbone.P5_Identity.conv") and len(gone) == 2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", ["gl_s_seed0", "gl_tiny_seed0", "gl_nano_seed0"])
+def test_composed_convs_of_the_benchmarked_plan_are_within_one_fp16_ulp(golden, shapes, tag):
+    """a trace used to switch the host-composed convs off (Patch_conv_feat1.channel_conv into C3_p4.conv1 /
+    conv2, P5_Identity into head.stems.2), so the one-ulp test above verified a different op sequence than the captured plan.
+    Here the trace KEEPS them (build_forward(composed=...)): the two tensors they remove are not in it, every other store
+    point is, and the forced emulation runs on a state_dict that makes the oracle multiply by the very same composed weights
+    (_oracle_sd_with_composed_weights).  Same bar: one fp16 ulp + 3e-5 x max|tensor| per stored element."""
+    from glsdet_amd.engine import Engine
+    from glsdet_amd.nets import build_forward
+    meta, sd, x, outs, _ = model_case(golden, shapes, tag)
+    assert meta["model"] == "gl"
+    tr, comp = {}, {}
+    hip, nc, _ = build_forward("gl", Engine("f16"), sd, x.cuda().float().contiguous(), trace=tr, composed=comp)
+    torch.cuda.synchronize()
+    got = [o.to_nchw(5 + nc).cpu() for o in hip]
+    assert set(comp) == {"backbone.C3_p4.conv1", "backbone.C3_p4.conv2", "head.stems.2"}, sorted(comp)
+    sd2, select, gone = _oracle_sd_with_composed_weights(sd, comp)
+    assert not (gone & set(tr)), "the composed-away tensors must not exist in the HIP trace"
+    ref = {}
+    O.TRACE, O.FORCE = ref, tr
+    try:
+        with torch.no_grad(), O.fp16_storage(select):
+            emu = O.FORWARDS["gl"](sd2, x)
+    finally:
+        O.TRACE = O.FORCE = None
+    missing = sorted(set(ref) - set(tr) - {"input"} - gone)
+    assert not missing, "tensors the HIP trace does not cover: %s" % missing[:8]
+    worst, n_el, n_diff = ("", 0.0), 0, 0
+    per = {}
+    for name, want in ref.items():
+        if name == "input" or name in gone:
+            continue
+        have = tr[name]
+        assert have.shape == want.shape, (name, have.shape, want.shape)
+        d = (have - want).abs()
+        tol = _ulp16(torch.maximum(have.abs(), want.abs())) + 3e-5 * float(want.abs().max())
+        over = float((d / tol).max())
+        per[name] = over
+        n_el += d.numel()
+        n_diff += int((d > 0).sum())
+        worst = max(worst, (name, over), key=lambda t: t[1])
+    scale = max(float(w.abs().max()) for w in outs)
+    dl = max(float((a - b).abs().max()) for a, b in zip(got, emu)) / scale
+    print("%s composed plan: %d stored tensors, %.2f %% of %d elements differ; worst %.2f x tol (%s); composed convs: %s; "
+          "forced logits max %.1e x max|logit|"
+          % (tag, len(ref) - 1 - len(gone), 100.0 * n_diff / n_el, n_el, worst[1], worst[0],
+             ", ".join("%s %.2f" % (k.split(".", 1)[1], per[k]) for k in sorted(comp)), dl))
+    assert worst[1] <= 1.0, worst
+    assert n_diff <= 0.10 * n_el
+    assert dl <= 5e-5
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("tag", MODELS)
 def test_f16_mode_is_as_close_to_the_reference_as_fp16_storage_allows(golden, shapes, tag):
