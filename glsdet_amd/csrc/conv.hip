@@ -16,6 +16,7 @@
 // Epilogue: scale/bias/activation in fp32 on the accumulator, tile transposed through LDS,
 // written (and the residual read) as full 16-byte channel chunks per pixel.
 #include <stdlib.h>
+#include <string.h>
 
 #include <vector>
 
@@ -30,6 +31,16 @@ constexpr int conv_lds_bytes(bool wide) {        // wide: fp32 staging of an fp1
   return (stage > epi ? stage : epi) + CO_T * 8;   // + scale | bias of the cout tile (fp32), parked in LDS for the epilogue
 }
 
+// XCD-aware tile order: the blocks that land on one XCD (blockIdx % 8 equal) walk a CONTIGUOUS run of the launch's tiles
+// (cout tile fastest, then pixel tile, then -- grouped launches -- problem), so the operand rows they share stay in that
+// XCD's L2.  In a grouped launch the run is cut from the concatenation of all problems: eight equal GEMMs land one per XCD
+// (rocprofv3 PMC on config 3's 576 x 576 x 4224 Gram products, 64 x 64 tiles, eight per launch: 330 MB fetched per launch
+// for 83 MB of operands while every XCD saw every problem).
+__device__ __forceinline__ int xcd_tile(const int bid, const int nwg) {
+  const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, local = bid >> 3;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+}
+
 // UT ("uniform tap"): Cin * sizeof(T) is a multiple of KB, so all chunks of a K step belong to ONE
 // filter tap and the tap walk (kr, ks, channel base) is scalar: a K step then costs one VALU add
 // per 16-byte chunk (plus the padding test when the conv pads) instead of ~10.
@@ -37,7 +48,7 @@ constexpr int conv_lds_bytes(bool wide) {        // wide: fp32 staging of an fp1
 // every instantiation carried its accumulators and staged chunks (64x64 tile: 60 -> 89 VGPRs, 6 -> 3 waves per SIMD;
 // the 128-row halo kernels 82-118 -> 238), which cost the plain launches 5-20 % (round 2 regression, found in the op table).
 template <typename T, typename TO, int CO_T, int PX_T, int KB, int WCO, bool UT, bool CH = false, int NTHR = 256>
-__device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid, const int nwg) {
+__device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int tile) {
   constexpr int RS = KB + 16;                    // LDS row stride, bytes
   constexpr int VEC = 16 / (int)sizeof(T);       // elements per 16-B chunk
   constexpr int KE = KB / (int)sizeof(T);        // k elements per step
@@ -55,13 +66,6 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
 
-  // XCD-aware tile order: blocks that land on one XCD (bid % 8 equal) walk a contiguous
-  // run of tiles, cout tile fastest, so the im2col rows they share stay in that XCD's L2.
-  int tile;
-  {
-    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, local = bid >> 3;
-    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
-  }
   const int ptile = gls_div(tile, a.nco_mul, a.nco_sh);
   const int co0 = (tile - ptile * a.n_co_tiles) * CO_T;
   const int px0 = ptile * PX_T;
@@ -429,7 +433,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const int bid
 
 template <typename T, typename TO, int CO_T, int PX_T, int KB, int WCO, bool UT, bool CH = false, int NTHR = 256>
 __global__ __launch_bounds__(NTHR) void conv_igemm_kernel(const ConvArgs a) {
-  conv_igemm_body<T, TO, CO_T, PX_T, KB, WCO, UT, CH, NTHR>(a, blockIdx.x, gridDim.x);
+  conv_igemm_body<T, TO, CO_T, PX_T, KB, WCO, UT, CH, NTHR>(a, xcd_tile((int)blockIdx.x, (int)gridDim.x));
 }
 
 // Several independent convolutions of the SAME shape class (kernel size, stride, channels, dtypes:
@@ -440,11 +444,25 @@ __global__ __launch_bounds__(NTHR) void conv_igemm_kernel(const ConvArgs a) {
 // (ConvArgsN: conv_common.h)
 template <typename T, typename TO, int CO_T, int PX_T, int KB, int WCO, bool UT>
 __global__ __launch_bounds__(256) void conv_igemm_multi_kernel(const ConvArgsN m) {
+  const int L = xcd_tile((int)blockIdx.x, (int)gridDim.x);
   int g = 0;
 #pragma unroll
   for (int i = 1; i < GLS_MULTI; ++i)
-    if (i < m.n && (int)blockIdx.x >= m.start[i]) g = i;
-  conv_igemm_body<T, TO, CO_T, PX_T, KB, WCO, UT>(m.p[g], (int)blockIdx.x - m.start[g], m.start[g + 1] - m.start[g]);
+    if (i < m.n && L >= m.start[i]) g = i;
+  conv_igemm_body<T, TO, CO_T, PX_T, KB, WCO, UT>(m.p[g], L - m.start[g]);
+}
+
+static_assert(sizeof(ConvArgsB) <= 4096 && sizeof(ConvArgsN) <= 4096, "the kernarg segment holds 4 KB");
+// ... and up to GLS_BATCH problems of IDENTICAL geometry (ConvArgsB: they differ in their operand addresses only)
+template <typename T, typename TO, int CO_T, int PX_T, int KB, int WCO, bool UT>
+__global__ __launch_bounds__(256) void conv_igemm_batch_kernel(const ConvArgsB m) {
+  const int L = xcd_tile((int)blockIdx.x, (int)gridDim.x);
+  const int g = gls_div(L, m.tiles_mul, m.tiles_sh);
+  ConvArgs a = m.base;
+  const ConvPtrs& q = m.p[g];
+  a.x = q.x; a.w = q.w; a.scale = q.scale; a.bias = q.bias; a.y = q.y; a.res = q.res;
+  a.x_lo = q.x_lo; a.x_off = q.x_off; a.x_bytes = q.x_bytes; a.w_bytes = q.w_bytes;
+  conv_igemm_body<T, TO, CO_T, PX_T, KB, WCO, UT>(a, L - g * m.tiles);
 }
 
 // ---- host side --------------------------------------------------------------------------
@@ -504,6 +522,48 @@ static int launch_conv_multi(const ConvArgsN& m0, hipStream_t st) {
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, st, m);
   GLS_HIP(hipGetLastError());
   return 0;
+}
+
+template <typename T, typename TO, int CO_T, int PX_T, int KB, int WCO, bool UT>
+static int launch_conv_batch(const ConvArgsB& m0, hipStream_t st) {
+  const int lds = conv_lds_bytes<CO_T, PX_T, KB, TO>(m0.base.res != nullptr);
+  static bool attr_set = false;
+  auto kern = conv_igemm_batch_kernel<T, TO, CO_T, PX_T, KB, WCO, UT>;
+  if (!attr_set && conv_lds_bytes<CO_T, PX_T, KB, TO>(true) > 64 * 1024) {
+    GLS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, conv_lds_bytes<CO_T, PX_T, KB, TO>(true)));
+    attr_set = true;
+  }
+  ConvArgsB m = m0;
+  ConvArgs& b = m.base;
+  b.n_co_tiles = (b.cout_pad + CO_T - 1) / CO_T;
+  if ((b.n_co_tiles - 1) * CO_T >= b.Cout) b.n_co_tiles = (b.Cout + CO_T - 1) / CO_T;
+  gls_fastdiv(b.n_co_tiles, &b.nco_mul, &b.nco_sh);
+  b.n_px_tiles = (b.M + PX_T - 1) / PX_T;
+  m.tiles = b.n_co_tiles * b.n_px_tiles;
+  gls_fastdiv(m.tiles, &m.tiles_mul, &m.tiles_sh);
+  const long grid = (long)m.tiles * m.n;
+  if (grid <= 0 || grid > 0x7fffffffL) GLS_FAIL(GLSDET_E_ARG, "conv2d_multi: grid %ld out of range", grid);
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, st, m);
+  GLS_HIP(hipGetLastError());
+  return 0;
+}
+
+template <typename T, typename TO>
+static int dispatch_tile_batch(const ConvArgsB& m, int co_t, int px_t, int kb, hipStream_t st) {
+  const bool ut = ((long)m.base.Cin * (long)sizeof(T)) % kb == 0;
+#define GLS_CASE(CO, PX, WCO_)                                                                      \
+  if (co_t == CO && px_t == PX) {                                                                   \
+    if (ut) return kb == 128 ? launch_conv_batch<T, TO, CO, PX, 128, WCO_, true>(m, st)             \
+                             : launch_conv_batch<T, TO, CO, PX, 64, WCO_, true>(m, st);             \
+    return kb == 128 ? launch_conv_batch<T, TO, CO, PX, 128, WCO_, false>(m, st)                    \
+                     : launch_conv_batch<T, TO, CO, PX, 64, WCO_, false>(m, st);                    \
+  }
+  GLS_CASE(128, 128, 2)
+  GLS_CASE(64, 128, 2)
+  GLS_CASE(64, 64, 2)
+#undef GLS_CASE
+  GLS_FAIL(GLSDET_E_ARG, "conv2d_multi: no kernel for tile %dx%d", co_t, px_t);
 }
 
 template <typename T, typename TO>
@@ -767,8 +827,61 @@ static int build_conv_op(const glsdet_conv_desc* d, int hint, OpRecord& op, cons
   return 0;
 }
 
+// The batched form: 9..GLS_BATCH problems whose argument blocks differ in the operand addresses only.
+static int build_conv_batch_op(const glsdet_conv_desc* d, int32_t n, int hint, OpRecord& op) {
+  if (hint && hint < 0x10000) GLS_FAIL(GLSDET_E_ARG, "conv2d_multi: more than %d descriptors run on the generic tiles only (hint %d)", GLS_MULTI, hint);
+  ConvArgsB m = {};
+  m.n = n;
+  op.kind = 0;
+  op.flops = op.bytes = 0;
+  for (int i = 0; i < n; ++i) {
+    ConvArgs a;
+    memset((void*)&a, 0, sizeof a);             // (padding and the fields only launchers fill: compared below)
+    double fl, by;
+    int rc = make_conv_args(&d[i], hint, a, &fl, &by);
+    if (rc) return rc;
+    op.flops += fl;
+    op.bytes += by;
+    ConvPtrs& q = m.p[i];
+    q.x = a.x; q.w = a.w; q.scale = a.scale; q.bias = a.bias; q.y = a.y; q.res = a.res;
+    q.x_lo = a.x_lo; q.x_off = a.x_off; q.x_bytes = a.x_bytes; q.w_bytes = a.w_bytes; q._pad = 0;
+    if (i == 0) { memcpy((void*)&m.base, &a, sizeof a); continue; }
+    if (d[i].x.dtype != d[0].x.dtype || d[i].y.dtype != d[0].y.dtype || (a.res == nullptr) != (m.base.res == nullptr))
+      GLS_FAIL(GLSDET_E_ARG, "conv2d_multi: descriptor %d is not of the shape class of descriptor 0", i);
+    // everything but the addresses must be the same bytes
+    ConvArgs t;
+    memcpy((void*)&t, &a, sizeof a);
+    const ConvArgs& b = m.base;
+    t.x = b.x; t.w = b.w; t.scale = b.scale; t.bias = b.bias; t.y = b.y; t.res = b.res;
+    t.x_lo = b.x_lo; t.x_off = b.x_off; t.x_bytes = b.x_bytes; t.w_bytes = b.w_bytes;
+    if (memcmp(&t, &b, sizeof(ConvArgs)) != 0)
+      GLS_FAIL(GLSDET_E_ARG, "conv2d_multi: more than %d descriptors must share one geometry (sizes, strides, epilogue); descriptor %d differs",
+               GLS_MULTI, i);
+  }
+  if (m.base.w2 || m.base.gn_part) GLS_FAIL(GLSDET_E_ARG, "conv2d_multi: no chained / GroupNorm form");
+  int co_t, px_t, kb;
+  ConvArgs probe = m.base;
+  const long Mtot = (long)m.base.M * n;
+  probe.M = (int)(Mtot > 0x7fffffffL ? 0x7fffffffL : Mtot);
+  pick_tile(probe, dtype_size(d[0].x.dtype), hint >= 0x10000 ? hint : 0, &co_t, &px_t, &kb);
+  if (co_t == 32) { co_t = 64; px_t = 64; }
+  if (px_t == 256) { co_t = 128; px_t = 128; }
+  const int xdt = d[0].x.dtype, ydt = d[0].y.dtype;
+  char nm[112];
+  snprintf(nm, sizeof nm, "conv_igemm_batch[%d]<%s,%s,%dx%d,kb%d> %dx%d s%d cin%d cout%d", n, xdt ? "f32" : "f16",
+           ydt ? "f32" : "f16", co_t, px_t, kb, d[0].R, d[0].S, d[0].stride, d[0].x.c, d[0].y.c);
+  op.name = nm;
+  op.launch = [m, co_t, px_t, kb, xdt, ydt](hipStream_t st) -> int {
+    if (xdt == GLSDET_F16 && ydt == GLSDET_F16) return dispatch_tile_batch<f16, f16>(m, co_t, px_t, kb, st);
+    if (xdt == GLSDET_F16 && ydt == GLSDET_F32) return dispatch_tile_batch<f16, float>(m, co_t, px_t, kb, st);
+    return dispatch_tile_batch<float, float>(m, co_t, px_t, kb, st);
+  };
+  return 0;
+}
+
 static int build_conv_multi_op(const glsdet_conv_desc* d, int32_t n, int hint, OpRecord& op) {
-  if (!d || n < 1 || n > GLS_MULTI) GLS_FAIL(GLSDET_E_ARG, "conv2d_multi: 1..%d descriptors", GLS_MULTI);
+  if (d && n > GLS_MULTI && n <= GLS_BATCH) return build_conv_batch_op(d, n, hint, op);
+  if (!d || n < 1 || n > GLS_MULTI) GLS_FAIL(GLSDET_E_ARG, "conv2d_multi: 1..%d descriptors (up to %d of one geometry)", GLS_MULTI, GLS_BATCH);
   ConvArgsN m = {};
   m.n = n;
   op.kind = 0;

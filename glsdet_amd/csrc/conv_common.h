@@ -118,6 +118,37 @@ struct MMA<float> {
   }
 };
 
+// v_mfma_f32_16x16x32_f16 (fp16 kernels that are MFMA bound): the same FLOPs per cycle as 32x32x16, but the chip holds a
+// higher clock under it -- tools/probe/mfma_loop.hip, the ring8 step on random operands, 8000 back-to-back launches:
+// 32x32x16 1302-1323 TFLOP/s, 16x16x32 1418-1430, 16x16x32 + s_setprio 1562 (constant operands: 1835 / 1942: the clock, not
+// the instruction count, is what bounds these loops).  A: lane -> row lane % 16, k slice lane / 16 (8 halves = one 16-byte
+// chunk); B likewise; D: lane -> column lane % 16, rows 4 * (lane / 16) .. + 3 (row i = what lane i supplied as A: with
+// the weight rows permuted over the lanes (m16_wrow) a lane's four values are the channels m16_wrow(4 * (lane / 16)) .. + 3).
+__device__ __forceinline__ void mma16(const u32x4& a, const u32x4& b, f32x4& c) {
+  c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+// Fragment maps of the 16x16x32 form.  The LDS serves a ds_read_b128 in 16-lane groups that pair 8 lanes of k slice a
+// (lanes {0-3, 12-15}: "half 0") with 8 lanes of slice b ({20-27}: "half 1" of the next 16), and c with d.  With the slices
+// (a, b, c, d) = chunks (0, 2, 1, 3) of the 64-byte step the two halves of a group are 32 bytes apart, and a group is
+// conflict free when each half holds 8 rows whose 16-byte columns (row * pitch / 16 mod 16) fill two residue classes mod 4
+// once each, the same two classes in both halves when they are adjacent ({c, c + 1}), complementary ones otherwise.
+//   position i = 0..7 of half h -> lane % 16
+__host__ __device__ constexpr int m16_lane(int h, int i) { return h == 0 ? (i < 4 ? i : i + 8) : i + 4; }
+//   lane % 16 -> (half, position)
+__host__ __device__ constexpr int m16_half(int n) { return (n >= 4 && n < 12) ? 1 : 0; }
+__host__ __device__ constexpr int m16_pos(int n) { return n < 4 ? n : (n < 12 ? n - 4 : n - 8); }
+//   k slice lane / 16 -> 16-byte chunk of the 64-byte step
+__host__ __device__ constexpr int m16_chunk(int sl) { return ((sl & 1) << 1) | (sl >> 1); }
+//   weights (unpadded rows of KB bytes, filled by LDS-DMA): half 0 = rows 0..7, half 1 = rows 8..15 of the 16-row block;
+//   the slot of chunk c in row r is c ^ swz: KB 128: (r / 2) & 7 (as for 32x32x16), KB 64: (r / 4) & 1
+__host__ __device__ constexpr int m16_wrow(int n) { return m16_half(n) * 8 + m16_pos(n); }
+template <int KB, bool M16>
+__host__ __device__ constexpr int w_swz(int row) {
+  return (M16 && KB == 64) ? ((row >> 2) & 1) : ((row / (256 / KB)) & (KB / 16 - 1));
+}
+//   patch rows (pitch KB + 16: 5 or 9 sixteen-byte columns) of 16 consecutive slots: half 0 = the even ones, half 1 = the odd
+__host__ __device__ constexpr int m16_px16(int n) { return 2 * m16_pos(n) + m16_half(n); }
+
 // SiLU: the exact-f32 instantiation uses the accurate expf, the fp16 one the native exp
 template <typename T>
 __device__ __forceinline__ float apply_act(float v, int act) {
@@ -298,6 +329,55 @@ struct GeoMap {
 };
 template <int TH, int TW, int PW, int NL>
 struct GeoMapHolder { static constexpr GeoMap<TH, TW, PW, NL> map{}; };
+
+// ... and for the 16x16x32 form (m16_* above): pixels are dealt to HALVES of 16-lane MFMA column blocks.  A half takes one
+// pixel of each of the 8 slot residues (mod 16) of a class pair -- type A: residues with s % 4 in {0, 1}, type B: {2, 3} --
+// and a block is two halves of one type (adjacent classes: both halves the same pair).  pix[q]: row-major pixel index of lane
+// column q = 16 * block + lane % 16, 0xffff = dead.  With an odd patch pitch every residue holds TH * TW / 16 pixels to within
+// one, so the NL / 16 blocks take all of them; a surplus pixel (none for the geometries in use) goes to any free lane.
+template <int TH, int TW, int PW, int NL>
+struct GeoMap16 {
+  unsigned short pix[NL];
+  constexpr GeoMap16() : pix{} {
+    constexpr int NB = NL / 16;
+    int cnt[16] = {};
+    int maxc[2] = {0, 0};
+    for (int p = 0; p < TH * TW; ++p) {
+      const int s = ((p / TW) * PW + p % TW) & 15, t = (s & 3) >> 1;
+      ++cnt[s];
+      if (cnt[s] > maxc[t]) maxc[t] = cnt[s];
+    }
+    // halves 0 .. maxc[0] - 1 of type A fill blocks 0 .. nbA - 1, type B the blocks behind them
+    int nbA = (maxc[0] + 1) / 2;
+    if (nbA + (maxc[1] + 1) / 2 > NB) nbA = NB / 2;
+    bool used[NL] = {};
+    int over[NL] = {};
+    int nover = 0;
+    int c2[16] = {};
+    for (int q = 0; q < NL; ++q) pix[q] = 0xffff;
+    for (int p = 0; p < TH * TW; ++p) {
+      const int s = ((p / TW) * PW + p % TW) & 15, t = (s & 3) >> 1;
+      const int k = c2[s]++;                                  // k-th pixel of this residue -> half k of its type
+      const int blk = (t == 0 ? 0 : nbA) + k / 2, lim = t == 0 ? nbA : NB;
+      const int i = ((s >> 2) << 1) | (s & 1);                // position of the residue inside its class pair: 0..7
+      if (blk < lim) {
+        const int q = blk * 16 + m16_lane(k & 1, i);
+        pix[q] = (unsigned short)p;
+        used[q] = true;
+      } else {
+        over[nover++] = p;
+      }
+    }
+    int qf = 0;
+    for (int i = 0; i < nover; ++i) {
+      while (used[qf]) ++qf;
+      pix[qf] = (unsigned short)over[i];
+      used[qf] = true;
+    }
+  }
+};
+template <int TH, int TW, int PW, int NL>
+struct GeoMap16Holder { static constexpr GeoMap16<TH, TW, PW, NL> map{}; };
 
 // Store phase of the 8 x 16 pixel-tile kernels: the staged tile (rows of ORS bytes in LDS) -> global, 16-byte chunks,
 // optional residual.  A thread's chunks are 256 / OCPR pixels apart -- one or two tile rows -- so its addresses advance
@@ -584,6 +664,27 @@ struct ConvArgsN {
   ConvArgs p[GLS_MULTI];
   int start[GLS_MULTI + 1];
   int n;
+};
+// up to GLS_BATCH problems that differ ONLY in their operand addresses (the per-image, per-quadrant GEMMs of the ResNet GL
+// plug-in: 32 equal windows per level): one full argument block + 72 bytes per problem instead of 280
+#define GLS_BATCH 32
+struct ConvPtrs {
+  const unsigned char* x;
+  const unsigned char* w;
+  const float* scale;
+  const float* bias;
+  unsigned char* y;
+  const unsigned char* res;
+  const unsigned char* x_lo;
+  unsigned x_off, x_bytes;
+  unsigned w_bytes, _pad;
+};
+struct ConvArgsB {
+  ConvArgs base;            // problem 0; n_co_tiles / n_px_tiles filled by the launcher
+  ConvPtrs p[GLS_BATCH];
+  int n, tiles;             // problems; tiles per problem
+  unsigned tiles_mul;
+  int tiles_sh;
 };
 struct HaloArgsN {
   ConvArgs p[GLS_MULTI];

@@ -504,8 +504,11 @@ template <> struct TileGeo8<0> { static constexpr int TH = 8, TW = 32; };
 template <> struct TileGeo8<1> { static constexpr int TH = 10, TW = 24; };
 template <> struct TileGeo8<2> { static constexpr int TH = 6, TW = 42; };
 
-template <typename T, int KS, int RING, int KB, int GEO8 = 0>
-__global__ __launch_bounds__(512) void conv_halo_ring8_kernel(const ConvArgs a, const int tiles_x, const int tiles_y) {
+// (amdgpu_waves_per_eu: the 64-byte-chunk forms fit two workgroups per CU by LDS, i.e. 4 waves per SIMD -- 128 registers; the
+// 16x16x32 form holds 32 fragment registers per k step instead of 16 and the allocator otherwise settles at 130-150)
+template <typename T, int KS, int RING, int KB, int GEO8 = 0, bool M16_ = false>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(KB == 64 ? 4 : 2))) void conv_halo_ring8_kernel(const ConvArgs a, const int tiles_x, const int tiles_y) {
+  constexpr bool M16 = M16_ && sizeof(T) == 2;     // v_mfma_f32_16x16x32_f16 and its fragment maps (conv_common.h)
   constexpr int TH = TileGeo8<GEO8>::TH, TW = TileGeo8<GEO8>::TW, CO_T = 128, NWV = 8;
   constexpr int LIVE = TH * TW;                    // of 256 MFMA lanes
   constexpr int RS = KB + 16, CPRW = KB / 16, RPL = 256 / KB;
@@ -551,7 +554,7 @@ __global__ __launch_bounds__(512) void conv_halo_ring8_kernel(const ConvArgs a, 
 #pragma unroll
   for (int q = 0; q < NI; ++q) {
     const int row = RPI * (wave + NWV * q) + lane / CPRW;
-    const int ch = (lane % CPRW) ^ ((row / RPL) & (CPRW - 1));
+    const int ch = (lane % CPRW) ^ w_swz<KB, M16>(row);
     wd[q] = (co0 + row) < a.cout_pad ? (unsigned)(((co0 + row) * a.kpad + ch * VEC) * (int)sizeof(T)) : GLS_OOB;
   }
   unsigned poff[NP];
@@ -608,6 +611,30 @@ __global__ __launch_bounds__(512) void conv_halo_ring8_kernel(const ConvArgs a, 
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
   const int wco = wave % 2, wpx = wave / 2;         // 2 cout halves x 4 pairs of pixel rows
   const int l31 = lane & 31, lh = lane >> 5;
+  // ---- 16x16x32 form: 4 x 4 blocks of 16 x 16 per wave; lane -> (row / pixel column n16, k slice sl)
+  constexpr int NB16 = M16 ? 4 : 1;
+  f32x4 acc16[NB16][NB16];
+  int a16_sw[KB / 64 > 0 ? KB / 64 : 1], b16_off[NB16];
+  const int n16 = lane & 15, sl = lane >> 4;
+  const int a16_row = (wco * 64 + m16_wrow(n16)) * KB;
+  auto pix16 = [&](int j) __attribute__((always_inline)) -> int {     // row-major pixel of this lane in column block j (0xffff: dead)
+    if constexpr (GEO8 == 0) return (wpx * 2 + (j >> 1)) * 32 + (j & 1) * 16 + m16_px16(n16);
+    else return GeoMap16Holder<TH, TW, PW, 256>::map.pix[(wpx * 4 + j) * 16 + n16];
+  };
+  if constexpr (M16) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc16[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kk = 0; kk < KB / 64; ++kk) a16_sw[kk] = ((m16_chunk(sl) + 4 * kk) ^ w_swz<KB, true>(m16_wrow(n16))) << 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {                  // column block wpx * 4 + j of the tile's 16
+      const int p = pix16(j);
+      const int oy = p == 0xffff ? 0 : p / TW, ox = p == 0xffff ? 0 : p - oy * TW;
+      b16_off[j] = PATCH_OFF + (oy * PW + ox) * RS + m16_chunk(sl) * 16;
+    }
+  }
   const int a_row = (wco * 64 + l31) * KB;
   int a_sw[KB / 32];
 #pragma unroll
@@ -632,6 +659,28 @@ __global__ __launch_bounds__(512) void conv_halo_ring8_kernel(const ConvArgs a, 
 
   int g = 0;
   auto mma_tap = [&](int tap_off) __attribute__((always_inline)) {
+    if constexpr (M16) {
+      const unsigned char* sA = smem + g * A_BYTES + a16_row;
+      asm volatile("s_setprio 1" ::: "memory");
+#pragma unroll
+      for (int kk = 0; kk < KB / 64; ++kk) {
+        u32x4 af[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const u32x4*>(sA + i * 16 * KB + a16_sw[kk]);
+#pragma unroll
+        for (int jh = 0; jh < 2; ++jh) {            // two column blocks at a time: 24 fragment registers live, not 32
+          u32x4 bf[2];
+#pragma unroll
+          for (int j = 0; j < 2; ++j) bf[j] = *reinterpret_cast<const u32x4*>(smem + b16_off[2 * jh + j] + tap_off + kk * 64);
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) mma16(af[i], bf[j], acc16[i][2 * jh + j]);
+        }
+      }
+      asm volatile("s_setprio 0" ::: "memory");
+      return;
+    }
     const unsigned char* sA = smem + g * A_BYTES + a_row;
 #pragma unroll
     for (int kk = 0; kk < KB / 32; ++kk) {
@@ -671,6 +720,20 @@ __global__ __launch_bounds__(512) void conv_halo_ring8_kernel(const ConvArgs a, 
   }
   halo_wait_vm_barrier<0>();
 
+  if constexpr (M16) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int co_l = wco * 64 + i * 16 + m16_wrow(4 * sl);       // D rows 4 sl .. 4 sl + 3 are the weight rows of lanes 4 sl .. + 3
+      const f32x4 sc = *reinterpret_cast<const f32x4*>(sSB + co_l * 4), bi = *reinterpret_cast<const f32x4*>(sSB + CO_T * 4 + co_l * 4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const f32x4 yv = scale_bias_act4<T>(acc16[i][j], sc, bi, a.act);
+        const float v[4] = {yv[0], yv[1], yv[2], yv[3]};
+        const int p = pix16(j);
+        if (GEO8 == 0 || p != 0xffff) store4(smem + p * ORS + co_l * (int)sizeof(T), v, (T*)nullptr);
+      }
+    }
+  } else
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -699,14 +762,14 @@ __global__ __launch_bounds__(512) void conv_halo_ring8_kernel(const ConvArgs a, 
   }
 }
 
-template <typename T, int KS, int RING, int KB, int GEO8 = 0>
+template <typename T, int KS, int RING, int KB, int GEO8 = 0, bool M16 = false>
 static int launch_halo_ring8(const ConvArgs& a, hipStream_t st) {
   constexpr int TH = TileGeo8<GEO8>::TH, TW = TileGeo8<GEO8>::TW;
   constexpr int PH = TH - 1 + KS, PW0 = TW - 1 + KS, PW = (GEO8 != 0 && PW0 % 2 == 0) ? PW0 + 1 : PW0, ORS = 128 * (int)sizeof(T) + 16;
   constexpr int stage = RING * 128 * KB + PH * PW * (KB + 16), epi = 256 * ORS;
   constexpr int lds = ((stage > epi ? stage : epi) + 15) / 16 * 16 + 128 * 8;
   static_assert(lds <= 160 * 1024, "LDS");
-  auto kern = conv_halo_ring8_kernel<T, KS, RING, KB, GEO8>;
+  auto kern = conv_halo_ring8_kernel<T, KS, RING, KB, GEO8, M16>;
   static bool attr_set = false;
   if (!attr_set) {
     GLS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
@@ -725,22 +788,35 @@ static int launch_halo_ring8(const ConvArgs& a, hipStream_t st) {
   return 0;
 }
 
+// fp16: the 16x16x32 MFMA form unless GLSDET_NO_M16 is set (A/B switch for measurements)
+static bool use_m16() {
+  static const bool on = getenv("GLSDET_NO_M16") == nullptr;
+  return on;
+}
+template <typename T, int KS, int RING, int KB, int GEO8 = 0>
+static int ring8_any(const ConvArgs& a, hipStream_t st) {
+  if constexpr (sizeof(T) == 2) {
+    if (use_m16()) return launch_halo_ring8<T, KS, RING, KB, GEO8, true>(a, st);
+  }
+  return launch_halo_ring8<T, KS, RING, KB, GEO8, false>(a, st);
+}
+
 template <typename T>
 static int halo_ring8_dispatch(const ConvArgs& a, bool k64, int geo, hipStream_t st) {
   if (geo == 0) {
     switch (a.R) {
-      case 3: return k64 ? launch_halo_ring8<T, 3, 4, 64>(a, st) : launch_halo_ring8<T, 3, 3, 128>(a, st);
-      case 5: return k64 ? launch_halo_ring8<T, 5, 4, 64>(a, st) : launch_halo_ring8<T, 5, 3, 128>(a, st);
-      case 7: return k64 ? launch_halo_ring8<T, 7, 4, 64>(a, st) : launch_halo_ring8<T, 7, 3, 128>(a, st);
+      case 3: return k64 ? ring8_any<T, 3, 4, 64>(a, st) : ring8_any<T, 3, 3, 128>(a, st);
+      case 5: return k64 ? ring8_any<T, 5, 4, 64>(a, st) : ring8_any<T, 5, 3, 128>(a, st);
+      case 7: return k64 ? ring8_any<T, 7, 4, 64>(a, st) : ring8_any<T, 7, 3, 128>(a, st);
     }
   } else if (k64) {                // the other tile geometries: 64-byte channel chunks only (the form the tuner picks at 100 x 168)
     switch (a.R * 4 + geo) {
-      case 3 * 4 + 1: return launch_halo_ring8<T, 3, 4, 64, 1>(a, st);
-      case 3 * 4 + 2: return launch_halo_ring8<T, 3, 4, 64, 2>(a, st);
-      case 5 * 4 + 1: return launch_halo_ring8<T, 5, 4, 64, 1>(a, st);
-      case 5 * 4 + 2: return launch_halo_ring8<T, 5, 4, 64, 2>(a, st);
-      case 7 * 4 + 1: return launch_halo_ring8<T, 7, 4, 64, 1>(a, st);
-      case 7 * 4 + 2: return launch_halo_ring8<T, 7, 4, 64, 2>(a, st);
+      case 3 * 4 + 1: return ring8_any<T, 3, 4, 64, 1>(a, st);
+      case 3 * 4 + 2: return ring8_any<T, 3, 4, 64, 2>(a, st);
+      case 5 * 4 + 1: return ring8_any<T, 5, 4, 64, 1>(a, st);
+      case 5 * 4 + 2: return ring8_any<T, 5, 4, 64, 2>(a, st);
+      case 7 * 4 + 1: return ring8_any<T, 7, 4, 64, 1>(a, st);
+      case 7 * 4 + 2: return ring8_any<T, 7, 4, 64, 2>(a, st);
     }
   }
   GLS_FAIL(GLSDET_E_ARG, "conv2d(halo ring8): unsupported kernel size %d / geometry %d", a.R, geo);

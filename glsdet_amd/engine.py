@@ -369,7 +369,7 @@ class Engine:
         """Up to 8 independent convs of one shape class (same k, stride, Cin, Cout) as ONE launch
         (glsdet_conv2d_multi): each alone is too small to fill the chip."""
         n = len(xs)
-        assert 1 <= n <= 8 and len(packs) == n
+        assert 1 <= n <= 32 and len(packs) == n
         outs = list(outs) if outs is not None else [None] * n
         ress = list(ress) if ress is not None else [None] * n
         arr = (ConvDesc * n)()
@@ -397,10 +397,37 @@ class Engine:
 
     def conv_many(self, xs: Sequence[TView], packs, stride: int, pad: int, act: str, outs: Sequence[TView],
                   ress: Optional[Sequence[Optional[TView]]] = None) -> List[TView]:
-        """Any number of independent convs of one shape class, eight per launch."""
+        """Any number of independent convs of one shape class: eight per launch, or -- 1x1 problems of ONE geometry (sizes,
+        strides, residual or not: the per-window GEMMs of the ResNet GL plug-in) -- up to 32 per launch (the batched form of
+        glsdet_conv2d_multi: one argument block + the operand addresses of each problem), on the tile the tuner measures."""
         ress = list(ress) if ress is not None else [None] * len(xs)
-        for i in range(0, len(xs), 8):
-            self.conv_multi(xs[i:i + 8], packs[i:i + 8], stride, pad, act, outs=outs[i:i + 8], ress=ress[i:i + 8])
+        n = len(xs)
+        geo = lambda x, pk, o, r: (x.n, x.h, x.w, x.c, x.sn, x.sh, x.sw, x.dtype, pk[3], pk[4], pk[5], o.n, o.h, o.w, o.c, o.sn, o.sh,
+                                   o.sw, o.dtype, None if r is None else (r.sn, r.sh, r.sw, r.c))
+        per = 8
+        if n > 8 and stride == 1 and pad == 0 and packs[0][4] == 1 and packs[0][5] == 1 and not os.environ.get("GLSDET_NO_BATCH") and \
+                len({geo(x, pk, o, r) for x, pk, o, r in zip(xs, packs, outs, ress)}) == 1:
+            per = 32
+        for i in range(0, n, per):
+            k = min(per, n - i)
+            hint = 0
+            if k > 8 and self.autotune:
+                key = ("batch", k, act) + geo(xs[i], packs[i], outs[i], ress[i])
+                if key not in self._tuned:
+                    arr = (ConvDesc * k)()
+                    for j in range(k):
+                        d, pk, r = arr[j], packs[i + j], ress[i + j]
+                        d.x, d.y = xs[i + j].as_c(), outs[i + j].as_c()
+                        d.res = r.as_c() if r is not None else View()
+                        d.w, d.scale, d.bias = pk[0].data_ptr(), pk[1].data_ptr(), pk[2].data_ptr()
+                        d.R, d.S, d.stride, d.pad, d.act, d.tile_hint = 1, 1, 1, 0, ACT[act], 0
+                    best, us = C.c_int32(0), C.c_float(0)
+                    check(self.lib.glsdet_conv2d_multi_tune(arr, k, _stream_ptr(self.stream), C.byref(best), C.byref(us)),
+                          "conv2d_multi_tune")
+                    self._tuned[key] = best.value
+                    self._tune_dirty = True
+                hint = self._tuned[key]
+            self.conv_multi(xs[i:i + k], packs[i:i + k], stride, pad, act, outs=outs[i:i + k], ress=ress[i:i + k], tile_hint=hint)
         return list(outs)
 
     def matrix(self, rows: int, cols: int, dtype: Optional[int] = None) -> TView:

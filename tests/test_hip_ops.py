@@ -416,6 +416,63 @@ def test_conv2d_multi_equals_separate_convs(engines, mode, case):
 
 
 @pytest.mark.parametrize("mode", ["f32", "f16"])
+@pytest.mark.parametrize("case", [
+    # n problems, cin, cout, (H, W), residual, act
+    (32, 64, 72, (9, 14), False, "none"),
+    (19, 136, 40, (5, 23), True, "relu"),
+    (9, 264, 200, (1, 70), False, "none"),
+])
+def test_conv2d_multi_batched_form_equals_separate_convs(engines, mode, case):
+    """glsdet_conv2d_multi with 9..32 descriptors of ONE geometry (the batched form: one argument block + the operand
+    addresses of each problem; the per-window GEMMs of the ResNet GL plug-in): every tile of the generic kernel, every
+    problem bit-identical to its own glsdet_conv2d on the same tile; Engine.conv_many takes the form by itself and falls
+    back to eight per launch when one problem's geometry differs; other hints and mixed geometries are refused."""
+    from glsdet_amd._lib import GlsdetError
+    eng = engines[mode]
+    n, cin, cout, (h, w), use_res, act = case
+    xs, packs, ress, refs = [], [], [], []
+    r = (lambda t: t.half().float()) if mode == "f16" else (lambda t: t)
+    for i in range(n):
+        g = torch.Generator().manual_seed(500 + i)
+        x = torch.randn(1, cin, h, w, generator=g)
+        wt = torch.randn(cout, cin, 1, 1, generator=g) / cin ** 0.5
+        sc, bi = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.2
+        res = torch.randn(1, cout, h, w, generator=g) if use_res else None
+        y = O._act(F.conv2d(r(x), r(wt)) * sc.view(1, -1, 1, 1) + bi.view(1, -1, 1, 1), act)
+        refs.append(y + r(res) if use_res else y)
+        xs.append(_to_view(eng, x))
+        packs.append(eng.pack_conv([(wt, sc, bi)], cin))
+        ress.append(_to_view(eng, res) if use_res else None)
+    for hint in (0, (64 << 16) | 64, (64 << 16) | 128, (128 << 16) | 128, (64 << 16) | 64 | 0x8000):
+        outs = eng.conv_multi(xs, packs, 1, 0, act, ress=ress, tile_hint=hint)
+        torch.cuda.synchronize()
+        for i, o in enumerate(outs):
+            _cmp(o.to_nchw(cout), refs[i], TOL[mode], "batched multi hint %x problem %d" % (hint, i))
+            if hint and not (cout <= 64 and (hint >> 16) == 128):       # (a single conv refuses a tile that is mostly padding)
+                one = eng.conv(xs[i], packs[i], 1, 0, act, res=ress[i], tile_hint=hint)
+                torch.cuda.synchronize()
+                assert torch.equal(o.to_nchw(cout), one.to_nchw(cout)), (hex(hint), i)
+    outs = [eng.tensor(1, h, w, cout) for _ in range(n)]
+    eng.conv_many(xs, packs, 1, 0, act, outs, ress=ress)
+    torch.cuda.synchronize()
+    for i, o in enumerate(outs):
+        one = eng.conv(xs[i], packs[i], 1, 0, act, res=ress[i])
+        torch.cuda.synchronize()
+        assert float((o.to_nchw(cout) - one.to_nchw(cout)).abs().max()) <= TOL[mode] * max(1.0, float(one.to_nchw(cout).abs().max()))
+    with pytest.raises(GlsdetError):
+        eng.conv_multi(xs, packs, 1, 0, act, ress=ress, tile_hint=8)             # the grouped ring kernel takes eight at most
+    odd = _to_view(eng, torch.randn(1, cin, h, w + 1))
+    with pytest.raises(GlsdetError):
+        eng.conv_multi(xs[:-1] + [odd], packs, 1, 0, act, ress=None if not use_res else ress[:-1] + [None])
+    if not use_res:                                                              # conv_many: eight per launch then
+        outs2 = [eng.tensor(1, h, w + (1 if i == n - 1 else 0), cout) for i in range(n)]
+        eng.conv_many(xs[:-1] + [odd], packs, 1, 0, act, outs2)
+        torch.cuda.synchronize()
+        for i in (0, 3, n - 2):
+            _cmp(outs2[i].to_nchw(cout), refs[i], TOL[mode], "conv_many fallback, problem %d" % i)
+
+
+@pytest.mark.parametrize("mode", ["f32", "f16"])
 def test_nonlocal_multi_unequal_sets(engines, mode):
     """glsdet_nonlocal_multi: four quadrant windows of one tensor with different extents and weights."""
     from glsdet_amd.nets import NetBuilder

@@ -3,6 +3,8 @@
 // on LDS images of the production kernel's shapes (128 cout rows x KB bytes ring slots, a padded patch).  Variants by
 // -D flags show what each element of the step costs and what a software-pipelined fragment read would buy.
 //   hipcc --offload-arch=gfx950 -O3 -o mfma_loop mfma_loop.hip [-DNO_DMA] [-DNO_BARRIER] [-DNO_WAIT] [-DPIPE] [-DSETPRIO] [-DWAVES=8] [-DKB=64]
+//   -DRANDOM: LDS images and weights hold random fp16 values (the clock the chip holds depends on the operand data);
+//   -DSHAPE16: v_mfma_f32_16x16x32_f16 (16 per step) instead of 32x32x16 (8 per step), KB = 64, conflict-free fragment maps
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -11,6 +13,7 @@
 typedef _Float16 f16;
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
 #ifndef KB
@@ -45,7 +48,16 @@ __global__ __launch_bounds__(WAVES * 64) void loop_kernel(const unsigned char* _
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const auto wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(w), (short)0, (int)w_bytes, 0x00020000);
+#ifdef RANDOM
+  for (int i = tid; i < LDS / 4; i += WAVES * 64) {
+    unsigned h = (unsigned)i * 2654435761u + blockIdx.x * 40503u;
+    h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+    const unsigned lo = (h & 0x83ffu) | ((13u + (h >> 10) % 3u) << 10), hi = ((h >> 16) & 0x83ffu) | ((13u + (h >> 26) % 3u) << 10);
+    reinterpret_cast<unsigned*>(smem)[i] = lo | (hi << 16);
+  }
+#else
   for (int i = tid; i < LDS / 16; i += WAVES * 64) reinterpret_cast<u32x4*>(smem)[i] = u32x4{0x3c003c00u + (unsigned)i, 0x38003800u, 0x34003400u, 0x30003000u};
+#endif
   __syncthreads();
   unsigned wd[NI > 0 ? NI : 1];
 #pragma unroll
@@ -88,7 +100,63 @@ __global__ __launch_bounds__(WAVES * 64) void loop_kernel(const unsigned char* _
 #pragma unroll
   for (int g = 0; g < RING - 1; ++g) dma_next();
   int g = 0, tap_off = 0, ts = 0;
-#ifdef PIPE
+#ifdef SHAPE16
+  // 16 x 16 x 32: lane n = lane % 16 -> operand row, lane / 16 -> one 16-byte k slice of the 64-byte step.  Conflict-free
+  // ds_read_b128 (the 16-lane groups pair slice a with b and c with d): slices (a, b, c, d) = chunks (0, 2, 1, 3);
+  //   weights (unpadded 64-byte rows): lanes {0-3, 12-15} -> rows 0..7, {4-11} -> rows 8..15, slot = chunk ^ ((row / 4) & 1);
+  //   patch (80-byte pitch): lanes {0-3, 12-15} -> even pixels, {4-11} -> odd pixels
+  static_assert(KB == 64 && WAVES == 8, "SHAPE16 probe: KB 64, 8 waves");
+  f32x4 acc16[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc16[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int n16 = lane & 15, sl = lane >> 4;
+  const int chunk = ((sl & 1) << 1) | (sl >> 1);
+  const int arow = n16 < 4 ? n16 : (n16 >= 12 ? n16 - 8 : n16 + 4);
+  const int bpix = n16 < 4 ? 2 * n16 : (n16 >= 12 ? 2 * (n16 - 8) : 2 * (n16 - 4) + 1);
+  int a16[4], b16[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = wco * 64 + i * 16 + arow;
+    a16[i] = row * KB + ((chunk ^ ((row >> 2) & 1)) << 4);
+    b16[i] = PATCH_OFF + ((wpx * 2 + (i >> 1)) * PW + (i & 1) * 16 + bpix) * RS + chunk * 16;
+  }
+  for (int s = 0; s < nsteps; ++s) {
+#ifndef NO_BARRIER
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(NI * (RING - 2)) : "memory");
+#endif
+    dma_next();
+    const unsigned char* sA = smem + g * A_BYTES;
+#ifdef SETPRIO
+    asm volatile("s_setprio 1" ::: "memory");
+#endif
+    u32x4 af[4], bf[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const u32x4*>(sA + a16[i]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bf[j] = *reinterpret_cast<const u32x4*>(smem + b16[j] + tap_off);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        acc16[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, af[i]), __builtin_bit_cast(f16x8, bf[j]), acc16[i][j], 0, 0, 0);
+#ifdef SETPRIO
+    asm volatile("s_setprio 0" ::: "memory");
+#endif
+    g = g + 1 == RING ? 0 : g + 1;
+    ++ts;
+    tap_off += (ts == 7) ? (PW - 7 + 1) * RS : RS;
+    ts = (ts == 7) ? 0 : ts;
+    if (tap_off >= (PH - 1) * PW * RS) tap_off = 0;
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[i & 1][j & 1][(i >> 1) * 8 + (j >> 1) * 4 + e] += acc16[i][j][e];
+#elif defined(PIPE)
   // software pipelined: the fragments of step s + 1 are read while step s is multiplied (ring slot s + 1 is certified by the
   // barrier of step s: the wait allows one stage less in flight)
   u32x4 af[2][KK][TM], bf[2][KK][TN];
@@ -185,16 +253,25 @@ int main(int argc, char** argv) {
   float* out;
   const unsigned w_bytes = 128 * 4096 + 4096;
   hipMalloc(&w, w_bytes);
+#ifdef RANDOM
+  {
+    std::vector<unsigned short> hw(w_bytes / 2);
+    unsigned h = 12345u;
+    for (auto& v : hw) { h = h * 1664525u + 1013904223u; v = (unsigned short)(((h >> 8) & 0x83ffu) | ((13u + (h >> 24) % 3u) << 10)); }
+    hipMemcpy(w, hw.data(), w_bytes, hipMemcpyHostToDevice);
+  }
+#else
   hipMemset(w, 0x3c, w_bytes);
+#endif
   hipMalloc(&out, (size_t)grid * WAVES * 64 * 4);
   hipFuncSetAttribute(reinterpret_cast<const void*>(loop_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
   hipEvent_t e0, e1;
   hipEventCreate(&e0);
   hipEventCreate(&e1);
-  for (int it = 0; it < 3; ++it) hipLaunchKernelGGL(loop_kernel, dim3(grid), dim3(WAVES * 64), LDS, 0, w, w_bytes, out, NSTEPS);
+  const int reps = argc > 2 ? atoi(argv[2]) : 20;         // (DVFS settles over ~2 s of back-to-back launches: pass ~10000)
+  for (int it = 0; it < 3 + reps / 2; ++it) hipLaunchKernelGGL(loop_kernel, dim3(grid), dim3(WAVES * 64), LDS, 0, w, w_bytes, out, NSTEPS);
   hipDeviceSynchronize();
   hipEventRecord(e0);
-  const int reps = 20;
   for (int it = 0; it < reps; ++it) hipLaunchKernelGGL(loop_kernel, dim3(grid), dim3(WAVES * 64), LDS, 0, w, w_bytes, out, NSTEPS);
   hipEventRecord(e1);
   hipEventSynchronize(e1);

@@ -26,5 +26,6 @@ rm -rf $out/pmc_f; timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE --output-format 
 rm -rf $out/pmc_w; timeout -k 10 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmc_w -- python bench.py --no-secondary --workload $WL --steps $STEPS --warmup $WARM --no-cpu-baseline --settle 0 --windows 1 > $out/pmc_w.log 2>&1
 python tools/traffic_summary.py $out $WL > $out/traffic.json
 cat $out/traffic.json
+python tools/traffic_by_kernel.py $out 2.0 > $out/traffic_by_kernel.txt
 rm -rf $out/kt $out/kt1 $out/pmc_f $out/pmc_w
 head -16 $out/kernel_stats_summary.txt
