@@ -255,8 +255,9 @@ __host__ __device__ constexpr int halo_ring_sb_off(bool wide) {
   return ((stage > epi ? stage : epi) + 15) / 16 * 16;
 }
 
-template <typename T, typename TO, int CO_T, int KS, int RING, int KB = 128, int STR = 1, bool CH = false, bool GN = false, int GEO = 0>
+template <typename T, typename TO, int CO_T, int KS, int RING, int KB = 128, int STR = 1, bool CH = false, bool GN = false, int GEO = 0, bool M16_ = false>
 __device__ __forceinline__ void conv_halo_ring_body(const ConvArgs& a, const int tiles_x, const int tiles_y, const int tile) {
+  constexpr bool M16 = M16_ && sizeof(T) == 2;     // v_mfma_f32_16x16x32_f16 and its fragment maps (conv_common.h)
   constexpr int TH = TileGeo<GEO>::TH, TW = TileGeo<GEO>::TW, WCO = 2;
   static_assert(GEO == 0 || (!CH && !GN), "other tile geometries: no chained / GroupNorm form");
   constexpr int RS = KB + 16;
@@ -308,7 +309,7 @@ __device__ __forceinline__ void conv_halo_ring_body(const ConvArgs& a, const int
 #pragma unroll
   for (int q = 0; q < NI; ++q) {
     const int row = RPI * (wave + 4 * q) + lane / CPRW;
-    const int ch = (lane % CPRW) ^ ((row / RPL) & (CPRW - 1));
+    const int ch = (lane % CPRW) ^ w_swz<KB, M16>(row);
     const bool ok = (co0 + row) < a.cout_pad;
     wd[q] = ok ? (unsigned)(((co0 + row) * a.kpad + ch * VEC) * (int)sizeof(T)) : GLS_OOB;
   }
@@ -375,6 +376,40 @@ __device__ __forceinline__ void conv_halo_ring_body(const ConvArgs& a, const int
 
   const int wco = wave % WCO, wpx = wave / WCO;
   const int l31 = lane & 31, lh = lane >> 5;
+  // ---- 16x16x32 form: TM16 x TN16 blocks of 16 x 16 per wave; lane -> (weight row / pixel column n16, k slice sl)
+  constexpr int TM16 = M16 ? WT_CO / 16 : 1, TN16 = M16 ? WT_PX / 16 : 1;
+  f32x4 acc16[TM16][TN16];
+  int a16_sw[KB / 64 > 0 ? KB / 64 : 1], b16_off[TN16];
+  const int n16 = lane & 15, sl = lane >> 4;
+  const int a16_row = (wco * WT_CO + m16_wrow(n16)) * KB;
+  // row of the staged output tile of this lane's pixel in column block j (-1: dead lane), and its (oy, ox)
+  auto pix16 = [&](int j, int& oy, int& ox) __attribute__((always_inline)) -> int {
+    if constexpr (GEO == 0) {                      // 8 x 16: block = one tile row; the store phase decodes rows with pix_to_xy16
+      oy = wpx * (WT_PX / 16) + j;
+      ox = m16_px16(n16);
+      constexpr int ROT = (16 - (PITCH & 15)) & 15;
+      return oy * 16 + ((oy & 1) ? ((ox - ROT) & 15) : ox);
+    } else {
+      const int p = GeoMap16Holder<TH, TW, PITCH, 128>::map.pix[(wpx * (WT_PX / 16) + j) * 16 + n16];
+      oy = p == 0xffff ? 0 : p / TW;
+      ox = p == 0xffff ? 0 : p - oy * TW;
+      return p == 0xffff ? -1 : p;
+    }
+  };
+  if constexpr (M16) {
+#pragma unroll
+    for (int i = 0; i < TM16; ++i)
+#pragma unroll
+      for (int j = 0; j < TN16; ++j) acc16[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kk = 0; kk < KB / 64; ++kk) a16_sw[kk] = ((m16_chunk(sl) + 4 * kk) ^ w_swz<KB, true>(m16_wrow(n16))) << 4;
+#pragma unroll
+    for (int j = 0; j < TN16; ++j) {
+      int oy, ox;
+      pix16(j, oy, ox);
+      b16_off[j] = PATCH_OFF + (oy * PITCH + ox) * RS + m16_chunk(sl) * 16;
+    }
+  }
   const int a_row = (wco * WT_CO + l31) * KB;      // + i * 32 * KB: the swizzle term (row >> 1) & 7 depends on l31 only
   int a_sw[KB / 32];
 #pragma unroll
@@ -408,6 +443,28 @@ __device__ __forceinline__ void conv_halo_ring_body(const ConvArgs& a, const int
 
   int g = 0;                                       // ring slot of the tap being multiplied
   auto mma_tap = [&](int tap_off) __attribute__((always_inline)) {
+    if constexpr (M16) {
+      const unsigned char* sA = smem + g * A_BYTES + a16_row;
+      asm volatile("s_setprio 1" ::: "memory");
+#pragma unroll
+      for (int kk = 0; kk < KB / 64; ++kk) {
+        u32x4 af[TM16];
+#pragma unroll
+        for (int i = 0; i < TM16; ++i) af[i] = *reinterpret_cast<const u32x4*>(sA + i * 16 * KB + a16_sw[kk]);
+#pragma unroll
+        for (int jh = 0; jh < TN16 / 2; ++jh) {     // two column blocks at a time (fragment registers)
+          u32x4 bf[2];
+#pragma unroll
+          for (int j = 0; j < 2; ++j) bf[j] = *reinterpret_cast<const u32x4*>(smem + b16_off[2 * jh + j] + tap_off + kk * 64);
+#pragma unroll
+          for (int i = 0; i < TM16; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) mma16(af[i], bf[j], acc16[i][2 * jh + j]);
+        }
+      }
+      asm volatile("s_setprio 0" ::: "memory");
+      return;
+    }
     const unsigned char* sA = smem + g * A_BYTES + a_row;
 #pragma unroll
     for (int kk = 0; kk < KB / 32; ++kk) {
@@ -452,6 +509,21 @@ __device__ __forceinline__ void conv_halo_ring_body(const ConvArgs& a, const int
   halo_wait_vm_barrier<0>();                        // the zero fills of the tail have landed; all waves done reading
 
   const bool wide = sizeof(TO) == 2 && a.res != nullptr;
+  if constexpr (M16) {
+#pragma unroll
+    for (int i = 0; i < TM16; ++i) {
+      const int co_l = wco * WT_CO + i * 16 + m16_wrow(4 * sl);    // D rows 4 sl .. + 3 = the weight rows of lanes 4 sl .. + 3
+      const f32x4 sc = *reinterpret_cast<const f32x4*>(sSB + co_l * 4), bi = *reinterpret_cast<const f32x4*>(sSB + CO_T * 4 + co_l * 4);
+#pragma unroll
+      for (int j = 0; j < TN16; ++j) {
+        const f32x4 yv = scale_bias_act4<T>(acc16[i][j], sc, bi, a.act);
+        const float v[4] = {yv[0], yv[1], yv[2], yv[3]};
+        int oy, ox;
+        const int pr = pix16(j, oy, ox);
+        if (GEO == 0 || pr >= 0) stage4<TO, CO_T>(smem, pr, co_l, v, wide);
+      }
+    }
+  } else
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -471,11 +543,11 @@ __device__ __forceinline__ void conv_halo_ring_body(const ConvArgs& a, const int
   halo_store_and_chain<T, TO, CO_T, PITCH, CH, GN, TH, TW>(smem, a, img, ty0, tx0, co0, tid);
 }
 
-template <typename T, typename TO, int CO_T, int KS, int RING, int KB = 128, int STR = 1, bool CH = false, bool GN = false, int GEO = 0>
+template <typename T, typename TO, int CO_T, int KS, int RING, int KB = 128, int STR = 1, bool CH = false, bool GN = false, int GEO = 0, bool M16 = false>
 __global__ __launch_bounds__(256) void conv_halo_ring_kernel(const ConvArgs a, const int tiles_x, const int tiles_y) {
   const int nwg = gridDim.x, bid = blockIdx.x;
   const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, local = bid >> 3;       // XCD-aware tile order
-  conv_halo_ring_body<T, TO, CO_T, KS, RING, KB, STR, CH, GN, GEO>(a, tiles_x, tiles_y,
+  conv_halo_ring_body<T, TO, CO_T, KS, RING, KB, STR, CH, GN, GEO, M16>(a, tiles_x, tiles_y,
                                                                (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local);
 }
 
@@ -483,13 +555,13 @@ __global__ __launch_bounds__(256) void conv_halo_ring_kernel(const ConvArgs a, c
 // l / r / t / b convs: each alone is a fraction of a round of workgroups) as ONE launch of the ring kernel; the
 // argument blocks travel in the kernarg segment as for conv_igemm_multi_kernel (conv.hip), a workgroup finds its problem
 // from the prefix of tile counts.
-template <typename T, typename TO, int CO_T, int KS, int RING, int KB, int STR, int GEO = 0>
+template <typename T, typename TO, int CO_T, int KS, int RING, int KB, int STR, int GEO = 0, bool M16 = false>
 __global__ __launch_bounds__(256) void conv_halo_ring_multi_kernel(const HaloArgsN m) {
   int g = 0;
 #pragma unroll
   for (int i = 1; i < GLS_MULTI; ++i)
     if (i < m.n && (int)blockIdx.x >= m.start[i]) g = i;
-  conv_halo_ring_body<T, TO, CO_T, KS, RING, KB, STR, false, false, GEO>(m.p[g], m.tx[g], m.ty[g], (int)blockIdx.x - m.start[g]);
+  conv_halo_ring_body<T, TO, CO_T, KS, RING, KB, STR, false, false, GEO, M16>(m.p[g], m.tx[g], m.ty[g], (int)blockIdx.x - m.start[g]);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -840,7 +912,10 @@ static int launch_halo_ring(const ConvArgs& a, hipStream_t st) {
   constexpr int ldsw = halo_ring_sb_off<T, TO, CO_T, KS, RING, KB, STR, GEO>(true) + CO_T * 8;
   int lds = halo_ring_sb_off<T, TO, CO_T, KS, RING, KB, STR, GEO>(sizeof(TO) == 2 && a.res != nullptr) + CO_T * 8;
   if (a.w2 && chain_lds_bytes<T>(CO_T, 128, a) > lds) lds = chain_lds_bytes<T>(CO_T, 128, a);
-  auto kern = conv_halo_ring_kernel<T, TO, CO_T, KS, RING, KB, STR, CH, GN, GEO>;
+  auto kern = conv_halo_ring_kernel<T, TO, CO_T, KS, RING, KB, STR, CH, GN, GEO, false>;
+  if constexpr (sizeof(T) == 2) {
+    if (use_m16()) kern = conv_halo_ring_kernel<T, TO, CO_T, KS, RING, KB, STR, CH, GN, GEO, true>;
+  }
   static int attr_lds = 64 * 1024;
   const int want_attr = lds > ldsw ? lds : ldsw;
   if (want_attr > attr_lds) {
@@ -867,7 +942,10 @@ static int launch_halo_ring_multi(const ConvArgsN& m0, hipStream_t st) {
   for (int i = 0; i < m0.n; ++i) any_res = any_res || m0.p[i].res != nullptr;
   constexpr int ldsw = halo_ring_sb_off<T, TO, CO_T, KS, RING, KB, STR, GEO>(true) + CO_T * 8;
   const int lds = halo_ring_sb_off<T, TO, CO_T, KS, RING, KB, STR, GEO>(sizeof(TO) == 2 && any_res) + CO_T * 8;
-  auto kern = conv_halo_ring_multi_kernel<T, TO, CO_T, KS, RING, KB, STR, GEO>;
+  auto kern = conv_halo_ring_multi_kernel<T, TO, CO_T, KS, RING, KB, STR, GEO, false>;
+  if constexpr (sizeof(T) == 2) {
+    if (use_m16()) kern = conv_halo_ring_multi_kernel<T, TO, CO_T, KS, RING, KB, STR, GEO, true>;
+  }
   static bool attr_set = false;
   if (!attr_set && ldsw > 64 * 1024) {
     GLS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, ldsw));
