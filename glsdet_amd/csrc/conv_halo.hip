@@ -860,11 +860,10 @@ static int launch_halo_ring8(const ConvArgs& a, hipStream_t st) {
   return 0;
 }
 
-// fp16: the 16x16x32 MFMA form unless GLSDET_NO_M16 is set (A/B switch for measurements)
-static bool use_m16() {
-  static const bool on = getenv("GLSDET_NO_M16") == nullptr;
-  return on;
-}
+// fp16: the 16x16x32 MFMA form unless GLSDET_NO_M16 is set.  Read at every launch (an op of a recorded plan keeps what it
+// was recorded with only through the environment of its replays: set it for the life of the process, as the tests that
+// compare kernel families bit for bit do -- the two MFMA shapes round differently in the last place).
+static bool use_m16() { return getenv("GLSDET_NO_M16") == nullptr; }
 template <typename T, int KS, int RING, int KB, int GEO8 = 0>
 static int ring8_any(const ConvArgs& a, hipStream_t st) {
   if constexpr (sizeof(T) == 2) {
@@ -918,8 +917,12 @@ static int launch_halo_ring(const ConvArgs& a, hipStream_t st) {
   }
   static int attr_lds = 64 * 1024;
   const int want_attr = lds > ldsw ? lds : ldsw;
-  if (want_attr > attr_lds) {
-    GLS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, want_attr));
+  if (want_attr > attr_lds) {                      // (both MFMA forms: the switch is read per launch)
+    GLS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo_ring_kernel<T, TO, CO_T, KS, RING, KB, STR, CH, GN, GEO, false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, want_attr));
+    if constexpr (sizeof(T) == 2)
+      GLS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo_ring_kernel<T, TO, CO_T, KS, RING, KB, STR, CH, GN, GEO, true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, want_attr));
     attr_lds = want_attr;
   }
   ConvArgs b = a;
@@ -948,7 +951,11 @@ static int launch_halo_ring_multi(const ConvArgsN& m0, hipStream_t st) {
   }
   static bool attr_set = false;
   if (!attr_set && ldsw > 64 * 1024) {
-    GLS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, ldsw));
+    GLS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo_ring_multi_kernel<T, TO, CO_T, KS, RING, KB, STR, GEO, false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, ldsw));
+    if constexpr (sizeof(T) == 2)
+      GLS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo_ring_multi_kernel<T, TO, CO_T, KS, RING, KB, STR, GEO, true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, ldsw));
     attr_set = true;
   }
   HaloArgsN m = {};

@@ -102,7 +102,10 @@ int     glsdet_conv2d(const glsdet_conv_desc* d, void* stream);
  * to fill the chip.  tile_hint of d[0] applies (0 = auto; 8..11 = the grouped LDS-DMA ring kernel for 3x3 problems, meaning
  * as for glsdet_conv2d, refused with GLSDET_E_ARG where it does not apply).  Results are those of n glsdet_conv2d.
  * `w` may point at an ACTIVATION matrix (rows of x.c elements at a pitch of glsdet_conv_kpad elements, zero padded):
- * the batched products of the non-local block at ResNet widths are such 1x1 "convs" with per-image weights. */
+ * the batched products of the non-local block at ResNet widths are such 1x1 "convs" with per-image weights.
+ * n = 9 .. 32 (round 3): the BATCHED form -- all descriptors must describe ONE geometry (extents, strides, epilogue, residual
+ * or not: they may differ in the operand addresses only; the 8 images x 4 quadrants of a plug-in level), the generic
+ * tiles only (tile_hint 0 or co << 16 | px); anything else is refused with GLSDET_E_ARG. */
 int     glsdet_conv2d_multi(const glsdet_conv_desc* d, int32_t n, void* stream);
 /* as glsdet_conv2d_tune, for the group: fastest tile_hint of the one-launch form and its time */
 int     glsdet_conv2d_multi_tune(const glsdet_conv_desc* d, int32_t n, void* stream, int32_t* best_hint, float* best_us);

@@ -602,11 +602,13 @@ def test_csp_with_fused_bottlenecks_equals_the_unfused_launches_bit_for_bit(engi
 @pytest.mark.parametrize("cin0,cm,hw,res,hint", [(64, 64, (30, 37), True, 0), (64, 64, (30, 37), True, 1), (128, 64, (17, 16), False, 0),
                                                  (32, 32, (25, 50), True, 0), (128, 128, (16, 33), True, 0), (128, 128, (16, 33), False, 1),
                                                  (256, 128, (9, 17), False, 0), (64, 32, (8, 16), True, 0)])
-def test_bottleneck_entry_point_equals_two_convs_bit_for_bit(engines, mode, cin0, cm, hw, res, hint):
+def test_bottleneck_entry_point_equals_two_convs_bit_for_bit(engines, monkeypatch, mode, cin0, cm, hw, res, hint):
     """glsdet_bottleneck against glsdet_conv2d twice on the same operands, bit for bit (the 3x3 by the halo ring kernel of
     the same channel-chunk size: with several chunks the accumulation order is (chunk, tap), the generic kernel's is
     (tap, chunk)): 1x1 inputs wider than the hidden tensor (several channel chunks in phase A), both chunk sizes, with
-    and without the residual; and the in-place call is refused."""
+    and without the residual; and the in-place call is refused.  fp16: bit for bit against the ring kernel on the SAME
+    MFMA shape (32x32x16, GLSDET_NO_M16: the fused kernel is built on it), and within one fp16 ulp of the default
+    16x16x32 ring kernel, whose hardware sums the 32 products of a k step in another order."""
     import ctypes as C
     from glsdet_amd._lib import ConvDesc, View
     from glsdet_amd.engine import ACT, _stream_ptr
@@ -623,7 +625,15 @@ def test_bottleneck_entry_point_equals_two_convs_bit_for_bit(engines, mode, cin0
     hid = eng.tensor(2, hw[0], hw[1], cm)
     es = 4 if mode == "f32" else 2
     kb = 64 if (hint == 1 or cm * es == 64 or (mode == "f32" and cm == 128)) else 128
+    ref16 = None
+    if mode == "f16":
+        ref16 = eng.conv(eng.conv(xv, p1, 1, 0, "silu", out=hid, tile_hint=1), p2, 1, 1, "silu", res=rv, tile_hint=10 if kb == 64 else 8)
+        torch.cuda.synchronize()
+        ref16 = ref16.to_nchw().cpu()
+        monkeypatch.setenv("GLSDET_NO_M16", "1")
     ref = eng.conv(eng.conv(xv, p1, 1, 0, "silu", out=hid, tile_hint=1), p2, 1, 1, "silu", res=rv, tile_hint=10 if kb == 64 else 8)
+    torch.cuda.synchronize()
+    monkeypatch.delenv("GLSDET_NO_M16", raising=False)
     out = eng.tensor(2, hw[0], hw[1], cm)
 
     def desc(x_, y_, pk, k, res_):
@@ -637,6 +647,10 @@ def test_bottleneck_entry_point_equals_two_convs_bit_for_bit(engines, mode, cin0
     assert rc == 0, eng.lib.glsdet_last_error().decode()
     torch.cuda.synchronize()
     assert torch.equal(out.to_nchw().cpu(), ref.to_nchw().cpu())
+    if ref16 is not None:
+        got, d = out.to_nchw().cpu(), (out.to_nchw().cpu() - ref16).abs()
+        ulp = torch.pow(2.0, torch.floor(torch.log2(torch.maximum(got.abs(), ref16.abs()).clamp(min=2.0 ** -14))) - 10)
+        assert float((d / (ulp + 3e-5 * float(ref16.abs().max()))).max()) <= 1.0 and float((d > 0).float().mean()) < 0.05
     if cin0 == cm:                                      # in place: refused, nothing launched
         d2b = desc(hid, xv, p2, 3, rv)
         assert eng.lib.glsdet_bottleneck(C.byref(d1), C.byref(d2b), hint, _stream_ptr(eng.stream)) != 0
