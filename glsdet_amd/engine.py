@@ -403,7 +403,7 @@ class Engine:
         ress = list(ress) if ress is not None else [None] * len(xs)
         n = len(xs)
         geo = lambda x, pk, o, r: (x.n, x.h, x.w, x.c, x.sn, x.sh, x.sw, x.dtype, pk[3], pk[4], pk[5], o.n, o.h, o.w, o.c, o.sn, o.sh,
-                                   o.sw, o.dtype, None if r is None else (r.sn, r.sh, r.sw, r.c))
+                                   o.sw, o.dtype) + ((-1, -1, -1, -1) if r is None else (r.sn, r.sh, r.sw, r.c))   # (flat: a tune-cache key)
         per = 8
         if n > 8 and stride == 1 and pad == 0 and packs[0][4] == 1 and packs[0][5] == 1 and not os.environ.get("GLSDET_NO_BATCH") and \
                 len({geo(x, pk, o, r) for x, pk, o, r in zip(xs, packs, outs, ress)}) == 1:

@@ -472,6 +472,30 @@ def test_conv2d_multi_batched_form_equals_separate_convs(engines, mode, case):
             _cmp(outs2[i].to_nchw(cout), refs[i], TOL[mode], "conv_many fallback, problem %d" % i)
 
 
+def test_tune_cache_keys_of_every_tuned_form_survive_the_json_file(tmp_path, monkeypatch):
+    """The tuning table is keyed by flat tuples and stored as JSON (GLSDET_TUNE_CACHE): a second engine must load what the
+    first one measured -- single convs, grouped launches, the batched form with and without a residual -- key for key."""
+    from glsdet_amd.engine import Engine
+    monkeypatch.setenv("GLSDET_TUNE_CACHE", str(tmp_path / "tune.json"))
+    eng = Engine("f16", autotune=True)
+    g = torch.Generator().manual_seed(3)
+    xs = [_to_view(eng, torch.randn(1, 64, 6, 11, generator=g)) for _ in range(12)]
+    pk = [eng.pack_conv([(torch.randn(40, 64, 1, 1, generator=g) / 8, torch.ones(40), torch.zeros(40))], 64) for _ in range(12)]
+    rs = [_to_view(eng, torch.randn(1, 40, 6, 11, generator=g)) for _ in range(12)]
+    for ress in (None, rs):
+        eng.conv_many(xs, pk, 1, 0, "none", [eng.tensor(1, 6, 11, 40) for _ in range(12)], ress=ress)
+    eng.conv_group(xs[:3], pk[:3], 1, 0, "relu")
+    eng.conv(xs[0], pk[0], 1, 0, "relu")
+    torch.cuda.synchronize()
+    eng.save_tune_cache()
+    assert sum(1 for k in eng._tuned if k[0] == "batch") >= 2
+    import json
+    with open(tmp_path / "tune.json") as f:
+        loaded = {tuple(json.loads(k)): v for k, v in json.load(f)["f16"].items()}        # (Engine.__init__'s own parse)
+    assert loaded == dict(eng._tuned) and len(loaded) >= 4
+    Engine("f16", autotune=True)                       # and a second engine loads the file without complaint
+
+
 @pytest.mark.parametrize("mode", ["f32", "f16"])
 def test_nonlocal_multi_unequal_sets(engines, mode):
     """glsdet_nonlocal_multi: four quadrant windows of one tensor with different extents and weights."""
