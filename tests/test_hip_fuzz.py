@@ -123,6 +123,15 @@ def test_conv2d_random_stride2_problem_halo_family(engines, mode, case):
     _run_case(engines, mode, case, [0, 1, 10, 11, (64 << 16) | 128, 0x10a, 0x10b, 0x20a, 0x20b])
 
 
+@pytest.mark.parametrize("case", _kxk_cases(6, 31) + _s2_cases(4, 37), ids=lambda c: "n%d_ci%d_co%d_k%d_s%d_%dx%d_%s_r%d_e%d" % c)
+def test_ring_kernels_on_the_32x32x16_mfma_shape(engines, monkeypatch, case):
+    """The fp16 ring kernels run v_mfma_f32_16x16x32_f16 by default (every f16 case above); GLSDET_NO_M16=1 selects the
+    32x32x16 form they were first written on (read per launch): the same problems, every ring hint."""
+    monkeypatch.setenv("GLSDET_NO_M16", "1")
+    hints = [0, 1, 8, 9, 10, 11, 12, 13] + GEO_HINTS if case[4] == 1 else [0, 1, 10, 11, 0x10a, 0x10b, 0x20a, 0x20b]
+    _run_case(engines, "f16", case, hints)
+
+
 def _gemm_cases(n, seed):
     """1x1 problems for the persistent LDS-DMA kernel: ragged K (Cin not a whole 128-byte panel), one to ten panels, cout
     tiles with padding rows, pixel counts that end inside a tile, strided views, both residual orders"""
