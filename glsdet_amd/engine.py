@@ -289,7 +289,7 @@ class Engine:
                     d2.R, d2.S, d2.stride, d2.pad, d2.act, d2.tile_hint = 1, 1, 1, 0, ACT[act2], 0
                     if self.lib.glsdet_conv2d_tune(C.byref(d), st, C.byref(b1), C.byref(u1)) == 0 and \
                             self.lib.glsdet_conv2d_tune(C.byref(d2), st, C.byref(b2h), C.byref(u2)) == 0 and \
-                            us.value > 0.97 * (u1.value + u2.value):
+                            us.value > 0.97 * (u1.value + u2.value) + _fuse_credit_us():
                         hint = -1
                 self._tuned[key] = hint
                 self._tune_dirty = True
@@ -345,7 +345,7 @@ class Engine:
                     h1, u1, h2, u2 = C.c_int32(0), C.c_float(0), C.c_int32(0), C.c_float(0)
                     if self.lib.glsdet_conv2d_tune(C.byref(d1), st, C.byref(h1), C.byref(u1)) == 0 and \
                             self.lib.glsdet_conv2d_tune(C.byref(d2), st, C.byref(h2), C.byref(u2)) == 0 and \
-                            us.value > 0.97 * (u1.value + u2.value) and not os.environ.get("GLSDET_FORCE_BNECK"):
+                            us.value > 0.97 * (u1.value + u2.value) + _fuse_credit_us() and not os.environ.get("GLSDET_FORCE_BNECK"):
                         hint = -1
                 self._tuned[key] = hint
                 self._tune_dirty = True
@@ -512,7 +512,7 @@ class Engine:
             best, us = C.c_int32(0), C.c_float(0)
             check(self.lib.glsdet_conv2d_multi_tune(arr, n, _stream_ptr(self.stream), C.byref(best), C.byref(us)),
                   "conv2d_multi_tune")
-            self._tuned[key] = best.value if us.value < 0.95 * single_us else -1
+            self._tuned[key] = best.value if us.value < 0.95 * single_us + (n - 1) * _fuse_credit_us() else -1
             self._tune_dirty = True
         hint = self._tuned[key]
         if hint < 0:
@@ -940,6 +940,12 @@ class Engine:
 
     def new_plan(self) -> Plan:
         return Plan(self.lib)
+
+
+def _fuse_credit_us() -> float:
+    """Experiment switch (GLSDET_FUSE_CREDIT_US, default 0): microseconds a fused form is credited per launch it removes when
+    the tuner compares it with the separate launches (the graph edge a removed launch no longer pays is not in either timing)."""
+    return float(os.environ.get("GLSDET_FUSE_CREDIT_US", "0"))
 
 
 def fold_bn(gamma, beta, mean, var, eps: float):
