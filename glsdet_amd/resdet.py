@@ -94,9 +94,29 @@ class ResDetBuilder:
         return self._packed[key]
 
     # ------------------------------------------------------------------ backbone
-    def bottleneck(self, p: str, x: TView, stride: int) -> TView:
-        """resnet.py:263-303 (style='pytorch': the stride sits on the 3x3)."""
+    def bottleneck(self, p: str, x: TView, stride: int, cat: Optional[TView] = None) -> TView:
+        """resnet.py:263-303 (style='pytorch': the stride sits on the 3x3).
+        cat: a [n, h, w, mid + cin] buffer whose channels [mid, mid + cin) ARE x (the caller had x's producer write there);
+        stride 1 with a downsample branch only.  conv2 then writes channels [0, mid) and conv3 and the downsample conv are ONE
+        1x1 over the concatenation,  relu(s3 (W3 h) + b3 + sd (Wd x) + bd) = relu([s3 W3 | sd Wd] [h ; x] + b3 + bd):
+        the identity tensor (275 MB at layer1 of the benchmark) is neither written nor read back.  BN scales ride in the
+        weights (float64 on the host), so the fp16 rounding of the composed weights differs from the reference's by what a
+        folded BN always costs; a trace keeps the reference's op sequence."""
         e = self.e
+        if cat is not None:
+            assert stride == 1 and p + ".downsample.0.weight" in self.sd
+            w1 = self.sd[p + ".conv1.weight"]
+            mid, cin = w1.shape[0], w1.shape[1]
+            assert cat.c == mid + cin and x.c == cin
+            t = e.conv(x, self._pack(p + ".conv1", [self._bn_part(p + ".conv1", p + ".bn1")], x.c), 1, 0, "relu")
+            e.conv(t, self._pack(p + ".conv2", [self._bn_part(p + ".conv2", p + ".bn2")], t.c), 1, 1, "relu", out=cat.channels(0, mid))
+            key = (p + ".conv3+downsample", cat.c)
+            if key not in self._packed:
+                w3, s3, b3 = self._bn_part(p + ".conv3", p + ".bn3")
+                wd, sd_, bd = self._bn_part(p + ".downsample.0", p + ".downsample.1")
+                w = torch.cat([w3.double() * s3.double().view(-1, 1, 1, 1), wd.double() * sd_.double().view(-1, 1, 1, 1)], 1).float()
+                self._packed[key] = e.pack_conv([(w, torch.ones(w.shape[0]), (b3.double() + bd.double()).float())], cat.c)
+            return e.conv(cat, self._packed[key], 1, 0, "relu")
         t = self._rec(p + ".conv1", e.conv(x, self._pack(p + ".conv1", [self._bn_part(p + ".conv1", p + ".bn1")], x.c), 1, 0, "relu"))
         t = self._rec(p + ".conv2", e.conv(t, self._pack(p + ".conv2", [self._bn_part(p + ".conv2", p + ".bn2")], t.c), stride, 1, "relu"))
         idn = x
@@ -111,13 +131,25 @@ class ResDetBuilder:
         """resnet.py:631-646."""
         e = self.e
         w1 = self.sd[p + ".conv1.weight"]
+        cat10 = None
         if tuple(w1.shape) == (64, 3, 7, 7) and img.shape[1] == 3 and not os.environ.get("GLSDET_NO_RSTEM_FUSION"):
             # stem conv straight from the fp32 NCHW image (glsdet_resnet_stem): no packed image, K = 7 x 8 x 4 instead of 7 x 7 x 8
             key = (p + ".conv1", "rstem")
             if key not in self._packed:
                 self._packed[key] = e.pack_resnet_stem(*self._bn_part(p + ".conv1", p + ".bn1"))
             if not os.environ.get("GLSDET_NO_RSTEM_POOL"):
-                x = e.resnet_stem_pool(img, self._packed[key])            # ... and the max pool in its epilogue
+                # layer1.0's identity branch composed with its conv3 (bottleneck(cat=)): the pooled stem output is written into
+                # the upper channels of the buffer conv3 reads
+                p10 = "%s.layer1.0" % p
+                if self.trace is None and not os.environ.get("GLSDET_NO_DOWNSAMPLE_FOLD") and p10 + ".downsample.0.weight" in self.sd \
+                        and self.sd[p10 + ".conv2.weight"].shape[-1] == 3:
+                    mid = self.sd[p10 + ".conv1.weight"].shape[0]
+                    n_, H_, W_ = img.shape[0], img.shape[2], img.shape[3]
+                    hc, wc = (H_ + 1) // 2, (W_ + 1) // 2
+                    cat10 = e.tensor(n_, (hc + 1) // 2, (wc + 1) // 2, mid + 64)
+                    x = e.resnet_stem_pool(img, self._packed[key], out=cat10.channels(mid, mid + 64))
+                else:
+                    x = e.resnet_stem_pool(img, self._packed[key])        # ... and the max pool in its epilogue
             else:
                 x = e.pool2d(e.resnet_stem(img, self._packed[key], "relu"), 3, 2, 1)
         else:
@@ -128,7 +160,8 @@ class ResDetBuilder:
         outs = []
         for i, nblocks in enumerate(STAGE_BLOCKS[depth]):
             for j in range(nblocks):
-                x = self.bottleneck("%s.layer%d.%d" % (p, i + 1, j), x, 2 if (j == 0 and i > 0) else 1)
+                x = self.bottleneck("%s.layer%d.%d" % (p, i + 1, j), x, 2 if (j == 0 and i > 0) else 1,
+                                    cat=cat10 if (i == 0 and j == 0) else None)
             if i in out_indices:
                 outs.append(x)
         return outs

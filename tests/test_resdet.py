@@ -752,6 +752,44 @@ def test_gl_fusion_detector_vs_oracle(mode):
             assert h_rms <= 1.5 * e_rms + 1e-4 and h_max <= 2.0 * e_max + 1e-3, nm
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["f32", "f16"])
+def test_layer1_downsample_composed_with_conv3(monkeypatch, mode):
+    """ResDetBuilder.bottleneck(cat=): layer1.0's identity conv + BN rides in conv3's GEMM over [h ; x] (the pooled stem output
+    is written into the upper channels of conv3's input buffer): one launch and the 4 x-wide identity tensor fewer.  Same
+    function: f32 to accumulation order against the launched form and the oracle; f16 within the error the launched form has
+    against the oracle (BN scales folded into fp16 weights round differently), never more than 1.25 x + 2e-3."""
+    from glsdet_amd.resdet import HipGflDetector
+    x = O.synth_input((2, 3, 96, 128), 13)
+    sd = calibrated_resdet_sd("gfl", 3, x)
+    with torch.no_grad():
+        want = M.resnet(sd, "backbone", x)
+    got, nops = {}, {}
+    for fold in (False, True):
+        if fold:
+            monkeypatch.delenv("GLSDET_NO_DOWNSAMPLE_FOLD", raising=False)
+        else:
+            monkeypatch.setenv("GLSDET_NO_DOWNSAMPLE_FOLD", "1")
+        from glsdet_amd.engine import Engine
+        from glsdet_amd.resdet import ResDetBuilder
+        eng = Engine(mode)
+        plan = eng.new_plan()
+        with plan:
+            outs = ResDetBuilder(eng, sd).resnet("backbone", x.cuda().float().contiguous())
+        plan.run(None)
+        torch.cuda.synchronize()
+        got[fold] = [o.to_nchw().cpu() for o in outs]
+        nops[fold] = plan.num_ops
+    assert nops[True] == nops[False] - 1, nops
+    err = {f: max(_err(g, w) for g, w in zip(got[f], want)) for f in (False, True)}
+    diff = max(_err(a, b) for a, b in zip(got[True], got[False]))
+    print("layer1.0 downsample fold %s: composed-vs-launched %.2e; vs oracle launched %.2e composed %.2e" % (mode, diff, err[False], err[True]))
+    if mode == "f32":
+        assert diff <= 1e-4 and err[True] <= 2e-4
+    else:
+        assert err[True] <= 1.25 * err[False] + 2e-3 and all(bool(torch.isfinite(g).all()) for g in got[True])
+
+
 def _ulp16(t):
     """spacing of fp16 at |t| (normal range; 2^-24 below it)"""
     e = torch.floor(torch.log2(t.abs().clamp(min=2.0 ** -14)))
