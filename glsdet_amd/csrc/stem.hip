@@ -600,17 +600,21 @@ __global__ __launch_bounds__(256) void resnet_stem_pool_kernel(const RStemArgs a
   if (tid < 32) *reinterpret_cast<f32x4*>(sSB + tid * 16) = *reinterpret_cast<const f32x4*>((tid < 16 ? a.scale : a.bias - 64) + tid * 4);
   const long plane = (long)a.H * a.W;
   const float* ibase = a.img + (long)img * 3 * plane;
-  constexpr int NQ = 3 * PH * PW, NL = (NQ + 255) / 256;
-  float pre[NL];
+  // image loads of one tile: a thread owns NL slots of the PH x PWP patch (columns >= PW are padding) and loads the three
+  // channels of each, held in registers so that the NEXT tile's loads are in flight while this one is multiplied and pooled;
+  // a slot then goes to LDS as ONE store of its four channels (c0 c1 c2 0) instead of three 2-byte stores and a zero pass
+  constexpr int NS = PH * PWP, NL = (NS + 255) / 256;
+  float pre[NL][3];
   auto issue_loads = [&](int qx0) __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
       const int q = tid + i * 256;
-      const int px = q % PW, r = q / PW;
-      const int py = r % PH, c = r / PH;
+      const int py = q / PWP, px = q - py * PWP;
       const int Y = 2 * (2 * qy0 - 1) - 3 + py, X = 2 * (2 * qx0 - 1) - 3 + px;
-      pre[i] = 0.f;
-      if (q < NQ && (unsigned)Y < (unsigned)a.H && (unsigned)X < (unsigned)a.W) pre[i] = ibase[c * plane + (long)Y * a.W + X];
+      const bool in = q < NS && px < PW && (unsigned)Y < (unsigned)a.H && (unsigned)X < (unsigned)a.W;
+      const float* p0 = ibase + (long)Y * a.W + X;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) pre[i][c] = in ? p0[c * plane] : 0.f;
     }
   };
   issue_loads(sx * STRIP * QW);
@@ -624,16 +628,11 @@ __global__ __launch_bounds__(256) void resnet_stem_pool_kernel(const RStemArgs a
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
       const int q = tid + i * 256;
-      if (q < NQ) {
-        const int px = q % PW, r = q / PW;
-        const int py = r % PH, c = r / PH;
-        reinterpret_cast<T*>(sP + (py * PWP + px) * PXB)[c] = (T)pre[i];
+      if (q < NS) {
+        T v[4] = {(T)pre[i][0], (T)pre[i][1], (T)pre[i][2], (T)0.f};
+        if constexpr (sizeof(T) == 2) *reinterpret_cast<unsigned long long*>(sP + q * PXB) = *reinterpret_cast<const unsigned long long*>(v);
+        else *reinterpret_cast<u32x4*>(sP + q * PXB) = *reinterpret_cast<const u32x4*>(v);
       }
-    }
-    for (int q = tid; q < PH * PWP; q += 256) {
-      T* dst = reinterpret_cast<T*>(sP + q * PXB);
-      dst[3] = (T)0.f;
-      if (q % PWP >= PW) dst[0] = dst[1] = dst[2] = (T)0.f;
     }
     if (s + 1 < STRIP && tx + 1 < a.tiles_x) issue_loads(qx0 + QW);
     __syncthreads();
