@@ -244,9 +244,12 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GnArgs a) {
 }
 
 // ---------------------------------------------------------------- MPHead proxy scores
-// One wave per position: |feat| by a shuffle reduction over the channel vectors, lane k < P
-// holds s_k = dots_k / max(|feat|, 1e-12); every lane walks the proxies of its own class
-// (shuffles) for the softmax-weighted mean; the first lane of a class writes the class score.
+// Sixteen lanes per position (four positions per wave): |feat| by a shuffle reduction over the lanes' channel vectors
+// (16-byte loads, the row of a position read once, coalesced); lane c < num_classes of the group then walks the proxies of
+// class c in the position's dots row (hot in L1: the group has just touched it) for the softmax-weighted mean
+// gamma * sum_j softmax(gamma s)_j s_j,  s_j = dots_j / max(|feat|, 1e-12)  (mp_head.py:105-121).  The first cut gave every
+// position a whole wave (half of its lanes idle at 256 channels, one 512-byte row in flight per wave): 0.103 ms = 1.2 TB/s on
+// the 179 k positions of the benchmark.
 struct ProxyArgs {
   int P, nc, maxcnt;
   unsigned char cls_of[256];     // class of proxy k
@@ -260,47 +263,40 @@ __global__ __launch_bounds__(256) void proxy_scores_kernel(const unsigned char* 
                                                            float gamma, const ProxyArgs a) {
   typedef typename V16<T>::type V;
   constexpr int VN = V16<T>::N;
-  const int lane = threadIdx.x & 63;
+  const int lane = threadIdx.x & 63, sub = lane & 15, grp = lane >> 4;
   const long wave = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const long nwaves = ((long)gridDim.x * blockDim.x) >> 6;
   const long total = (long)n * H * W;
-  for (long p = wave; p < total; p += nwaves) {
+  for (long p0 = wave * 4; p0 < total; p0 += nwaves * 4) {
+    const bool okp = p0 + grp < total;
+    const long p = okp ? p0 + grp : total - 1;      // (every lane takes part in the shuffles)
     const int w = (int)(p % W);
     const int h = (int)((p / W) % H);
     const int b = (int)(p / ((long)W * H));
     const unsigned char* px = f + (b * fsn + h * fsh + w * fsw) * (long)sizeof(T);
     float sq = 0.f;
-    for (int c = lane * VN; c < C; c += 64 * VN) {
+    for (int c = sub * VN; c < C; c += 16 * VN) {
       const V v = *reinterpret_cast<const V*>(px + c * (long)sizeof(T));
 #pragma unroll
       for (int e = 0; e < VN; ++e) sq += (float)v[e] * (float)v[e];
     }
 #pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) sq += __shfl_xor(sq, o, 64);
+    for (int o = 8; o >= 1; o >>= 1) sq += __shfl_xor(sq, o, 64);
     const float inv = 1.0f / fmaxf(sqrtf(sq), 1e-12f);
     const float* d = dots + b * dsn + h * dsh + w * dsw;
     float* o = out + b * osn + h * osh + w * osw;
-    for (int k0 = 0; k0 < a.P; k0 += 64) {           // P <= 64 in practice: one round
-      const int k = k0 + lane;
-      const bool live = k < a.P;
-      const float s = live ? d[k] * inv : 0.f;
-      const int c = live ? a.cls_of[k] : 0;
-      const int first = a.first[c] - k0, cnt = a.count[c];      // the class lies inside this round (host checks)
+    for (int c = sub; c < a.nc; c += 16) {
+      const int first = a.first[c], cnt = a.count[c];
       float m = -INFINITY;
-      for (int j = 0; j < a.maxcnt; ++j) {            // uniform trip count, shuffles need all lanes
-        const float sj = __shfl(s, min(max(first + j, 0), 63), 64);
-        if (j < cnt) m = fmaxf(m, sj * gamma);
-      }
+      for (int j = 0; j < cnt; ++j) m = fmaxf(m, d[first + j] * inv * gamma);
       float den = 0.f, num = 0.f;
-      for (int j = 0; j < a.maxcnt; ++j) {
-        const float sj = __shfl(s, min(max(first + j, 0), 63), 64);
-        if (j < cnt) {
-          const float e = expf(sj * gamma - m);
-          den += e;
-          num += e * sj;
-        }
+      for (int j = 0; j < cnt; ++j) {
+        const float sj = d[first + j] * inv;
+        const float e = expf(sj * gamma - m);
+        den += e;
+        num += e * sj;
       }
-      if (live && k == a.first[c]) o[c] = num / den * gamma;
+      if (okp) o[c] = num / den * gamma;
     }
   }
 }
@@ -494,8 +490,6 @@ extern "C" int glsdet_proxy_scores(const glsdet_view* feat, const glsdet_view* d
   int P = 0;
   for (int c = 0; c < num_classes; ++c) {
     if (counts[c] < 1 || counts[c] > 64) GLS_FAIL(GLSDET_E_ARG, "proxy_scores: class %d has %d proxies (1..64)", c, counts[c]);
-    if (P / 64 != (P + counts[c] - 1) / 64)
-      GLS_FAIL(GLSDET_E_ARG, "proxy_scores: the proxies of class %d straddle a 64-proxy round", c);
     if (P + counts[c] > 256) GLS_FAIL(GLSDET_E_ARG, "proxy_scores: more than 256 proxies");
     pa.first[c] = (unsigned char)P;
     if (counts[c] > pa.maxcnt) pa.maxcnt = counts[c];
@@ -515,7 +509,7 @@ extern "C" int glsdet_proxy_scores(const glsdet_view* feat, const glsdet_view* d
   op.bytes = (double)a.n * a.h * a.w * (a.c * dtype_size(a.dtype) + 4.0 * (P + num_classes));
   op.name = "proxy_scores";
   op.launch = [=](hipStream_t st) -> int {
-    const unsigned g = rgrid((long)a.n * a.h * a.w * 64);
+    const unsigned g = rgrid((long)a.n * a.h * a.w * 16);
     if (a.dtype == GLSDET_F16)
       hipLaunchKernelGGL(proxy_scores_kernel<f16>, dim3(g), dim3(256), 0, st, (const unsigned char*)a.base, a.sn, a.sh, a.sw, (const float*)d.base, d.sn, d.sh, d.sw, (float*)o.base, o.sn, o.sh, o.sw, a.n, a.h, a.w, a.c, gamma, pa);
     else
