@@ -204,12 +204,24 @@ def test_two_stage_pipeline_runs_end_to_end():
     rows = c.nb["dets"][0, :k].cpu().numpy()
     per_class = [rows[rows[:, 6] == cc][:, :5] for cc in range(10)]
     want = U.map_back_and_merge(per_class, mid["chips"])
+    # float32 (device) vs float64 (restatement) IoF / IoU AT a threshold: a detection whose IoF with its chip is 0.9 to the last
+    # bit is mapped back by one side only, and dropping it can un-suppress another row of its class (same count, other rows).
+    # So: rows are matched as sets; over all classes at most three rows may be without a partner on either side.
+    # (No range check: a fine-stage box may reach beyond the chip it is assigned to, and the reference maps it back through that
+    #  chip's transform without clipping -- ufpmp_det_eval.py:282-300.)
+    loose = 0
     for cc in range(10):
-        assert abs(len(merged[cc]) - len(want[cc])) <= 1            # float32 vs float64 IoF / IoU at the thresholds
-        if len(merged[cc]) == len(want[cc]) and len(want[cc]):
-            np.testing.assert_allclose(merged[cc], want[cc], rtol=1e-4, atol=1e-2)
-        for r in merged[cc]:
-            assert -1 <= r[0] <= 480 and -1 <= r[1] <= 270
+        g, w_ = np.asarray(merged[cc], np.float64).reshape(-1, 5), np.asarray(want[cc], np.float64).reshape(-1, 5)
+        if len(g) == len(w_) and (len(g) == 0 or np.allclose(g, w_, rtol=1e-4, atol=1e-2)):
+            continue
+        assert abs(len(g) - len(w_)) <= 1, (cc, len(g), len(w_))
+        if len(g) and len(w_):
+            dist = np.abs(g[:, None, :] - w_[None, :, :]).max(-1)
+            tol = 1e-2 + 1e-4 * max(np.abs(g).max(), np.abs(w_).max())
+            loose += int((dist.min(1) > tol).sum()) + int((dist.min(0) > tol).sum())
+        else:
+            loose += len(g) + len(w_)
+    assert loose <= 3, loose
     # the two-stream pipeline (coarse of frame i+1 beside fine of frame i) returns the same detections
     c1 = dict(score_thr=t1, iou_thr=0.6, nms_pre=1000, max_per_img=40)
     c2 = dict(score_thr=t2, iou_thr=0.6, nms_pre=1000, max_per_img=300)
