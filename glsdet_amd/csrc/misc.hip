@@ -365,7 +365,32 @@ __global__ __launch_bounds__(256) void nl_gram_kernel(const NlArgs a) {
   const int jbeg = z * wn.jchunk, jend = min(N, jbeg + wn.jchunk);
   const T* base = reinterpret_cast<const T*>(S.tpg) + b * S.tsn + wn.to;
   float acc = 0.f;
+  constexpr int VN = 16 / (int)sizeof(T);          // channels per 16-byte chunk
+  // whole 16-channel blocks of 16-byte-aligned rows: one vector load per thread and tile instead of 2-byte loads (thread t:
+  // matrix t / 128 (phi | g), position (t % 128) / CPB, chunk (t % 128) % CPB; fp32: two passes)
+  const bool vec = (ci % 16) == 0 && (S.tsw % VN) == 0 && (S.tsh % VN) == 0 && (S.tsn % VN) == 0 && (wn.to % VN) == 0 &&
+                   ((uintptr_t)S.tpg & 15) == 0;
   for (int j0 = jbeg; j0 < jend; j0 += 64) {
+    if (vec) {
+      constexpr int CPB = 16 / VN;                 // chunks per 16-channel block: 2 (fp16) / 4 (fp32)
+#pragma unroll
+      for (int e = 0; e < CPB / 2; ++e) {
+        const int t = threadIdx.x + e * 256;
+        const int mat = t / (64 * CPB), r = t - mat * 64 * CPB;
+        const int jj = r / CPB, ch = r - jj * CPB;
+        const int j = j0 + jj;
+        typename Vec16<T>::type v;
+#pragma unroll
+        for (int k = 0; k < VN; ++k) v[k] = (T)0.f;
+        if (j < jend) {
+          const T* px = base + (j / W) * S.tsh + (j % W) * S.tsw;
+          v = *reinterpret_cast<const typename Vec16<T>::type*>(px + (mat ? 2 * ci + c2_0 : ci + c1_0) + ch * VN);
+        }
+        float(*dst)[17] = mat ? gg : ph;
+#pragma unroll
+        for (int k = 0; k < VN; ++k) dst[jj][ch * VN + k] = (float)v[k];
+      }
+    } else {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int idx = threadIdx.x + e * 256;
@@ -379,6 +404,7 @@ __global__ __launch_bounds__(256) void nl_gram_kernel(const NlArgs a) {
       }
       ph[jj][cc] = vp;
       gg[jj][cc] = vg;
+    }
     }
     __syncthreads();
 #pragma unroll 16
@@ -476,9 +502,29 @@ __global__ __launch_bounds__(256) void nl_apply_kernel(const NlArgs a) {
   float* pr = th + 64 * ld;
   const int jj = threadIdx.x & 63, grp = threadIdx.x >> 6;
   const int j = j0 + jj;
+  constexpr int VN = 16 / (int)sizeof(T);
+  // 16-byte loads / stores where the views allow it (rows and windows on 16-byte boundaries)
+  const bool vec_t = (tsw % VN) == 0 && (tsh % VN) == 0 && (tsn % VN) == 0 && (wn.to % VN) == 0 && ((uintptr_t)tpg & 15) == 0;
+  const bool vec_o = (xsw % VN) == 0 && (xsh % VN) == 0 && (xsn % VN) == 0 && (wn.xo % VN) == 0 && ((uintptr_t)x & 15) == 0 &&
+                     (osw % VN) == 0 && (osh % VN) == 0 && (osn % VN) == 0 && (wn.oo % VN) == 0 && ((uintptr_t)out & 15) == 0 &&
+                     (cx % VN) == 0 && kc >= GLS_APPLY_CO;
   float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   for (int c0 = 0; c0 < ci; c0 += kc) {
     const int kn = min(kc, ci - c0);
+    if (vec_t && (kn % VN) == 0) {                   // theta tile by 16-byte loads
+      const int cpr = kn / VN;
+      for (int idx = threadIdx.x; idx < 64 * cpr; idx += 256) {
+        const int r = idx / cpr, ch = idx - r * cpr;
+        const int jr = j0 + r;
+        typename Vec16<T>::type v;
+#pragma unroll
+        for (int k = 0; k < VN; ++k) v[k] = (T)0.f;
+        if (jr < N)
+          v = *reinterpret_cast<const typename Vec16<T>::type*>(reinterpret_cast<const T*>(tpg) + b * tsn + wn.to + (jr / W) * tsh + (jr % W) * tsw + c0 + ch * VN);
+#pragma unroll
+        for (int k = 0; k < VN; ++k) th[r * ld + ch * VN + k] = (float)v[k];
+      }
+    } else
     for (int idx = threadIdx.x; idx < 64 * kn; idx += 256) {
       const int r = idx / kn, c = idx - r * kn;
       const int jr = j0 + r;
@@ -500,6 +546,28 @@ __global__ __launch_bounds__(256) void nl_apply_kernel(const NlArgs a) {
       for (int q = 0; q < 8; ++q) acc[q] += tv * p0[q * kc + c];
     }
     __syncthreads();
+  }
+  if (vec_o) {
+    // the accumulators go through LDS ([64 pixels][32 channels + 1], the theta tile's space: 64 * (kc + 1) floats with
+    // kc >= 32) so that a thread adds x + bout to ONE 16-byte chunk of one pixel and stores it whole; lanes that hold pixels
+    // wrote 64 two-byte stores per instruction before
+    float* so = th;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) so[jj * (GLS_APPLY_CO + 1) + grp * 8 + q] = acc[q];
+    __syncthreads();
+    constexpr int CPP = GLS_APPLY_CO / VN;          // chunks per pixel
+    for (int idx = threadIdx.x; idx < 64 * CPP; idx += 256) {
+      const int r = idx / CPP, ch = idx - r * CPP;
+      const int jr = j0 + r, co = co0 + ch * VN;
+      if (jr >= N || co >= cx) continue;
+      const long px_x = b * xsn + wn.xo + (jr / W) * xsh + (jr % W) * xsw + co;
+      const long px_o = b * osn + wn.oo + (jr / W) * osh + (jr % W) * osw + co;
+      typename Vec16<T>::type v = *reinterpret_cast<const typename Vec16<T>::type*>(reinterpret_cast<const T*>(x) + px_x);
+#pragma unroll
+      for (int k = 0; k < VN; ++k) v[k] = (T)((float)v[k] + bout[co + k] + so[r * (GLS_APPLY_CO + 1) + ch * VN + k]);
+      *reinterpret_cast<typename Vec16<T>::type*>(reinterpret_cast<T*>(out) + px_o) = v;
+    }
+    return;
   }
   if (j >= N) return;
   const long poff_x = b * xsn + wn.xo + (j / W) * xsh + (j % W) * xsw;
